@@ -1,0 +1,187 @@
+// Host-side plumbing: error string, device contexts, scratch buffers, hipFFT plan cache,
+// and the host-only window entry points of the C ABI.
+#include "common.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <mutex>
+
+#include "es_kernel.hpp"
+
+namespace efgp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static std::mutex g_mu;
+static std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
+
+DeviceCtx* device_ctx(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_ctx.find(device);
+    if (it != g_ctx.end()) return it->second.get();
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+        set_error("device %d not available (hipGetDeviceCount=%d): the HIP path needs a GPU", device, count);
+        return nullptr;
+    }
+    auto ctx = std::make_unique<DeviceCtx>();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        set_error("hipGetDeviceProperties(%d) failed", device);
+        return nullptr;
+    }
+    ctx->num_cu = prop.multiProcessorCount;
+    int lds = 0;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || lds <= 0)
+        lds = 65536;
+    ctx->max_lds = lds;
+    DeviceCtx* raw = ctx.get();
+    g_ctx[device] = std::move(ctx);
+    return raw;
+}
+
+void* scratch(DeviceCtx* ctx, Slot slot, size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    if (ctx->cap[slot] >= bytes) return ctx->buf[slot];
+    size_t want = bytes + bytes / 4;
+    want = (want + 255) & ~size_t(255);
+    if (ctx->buf[slot]) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(ctx->buf[slot]);
+        ctx->buf[slot] = nullptr;
+        ctx->cap[slot] = 0;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) for scratch slot %d failed", want, (int)slot);
+        return nullptr;
+    }
+    ctx->buf[slot] = p;
+    ctx->cap[slot] = want;
+    return p;
+}
+
+int fft_plan(DeviceCtx* ctx, int rank, const int64_t* n, int64_t batch, hipStream_t stream, hipfftHandle* out) {
+    auto key = std::make_tuple(rank, n[0], rank > 1 ? n[1] : 0, rank > 2 ? n[2] : 0, batch);
+    auto it = ctx->fft_plans.find(key);
+    hipfftHandle h;
+    if (it == ctx->fft_plans.end()) {
+        int dims[3];
+        int64_t dist = 1;
+        for (int a = 0; a < rank; ++a) {
+            dims[a] = (int)n[a];
+            dist *= n[a];
+        }
+        EFGP_FFT_CHECK(hipfftCreate(&h));
+        size_t work = 0;
+        EFGP_FFT_CHECK(hipfftMakePlanMany(h, rank, dims, nullptr, 1, (int)dist, nullptr, 1, (int)dist, HIPFFT_Z2Z,
+                                          (int)batch, &work));
+        ctx->fft_plans[key] = h;
+    } else {
+        h = it->second;
+    }
+    EFGP_FFT_CHECK(hipfftSetStream(h, stream));
+    *out = h;
+    return EFGP_OK;
+}
+
+int* pinned_host(DeviceCtx* ctx, size_t bytes) {
+    if (ctx->host_pinned_bytes >= bytes) return ctx->host_pinned;
+    if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
+    ctx->host_pinned = nullptr;
+    ctx->host_pinned_bytes = 0;
+    void* p = nullptr;
+    size_t want = bytes < 4096 ? 4096 : bytes * 2;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+        set_error("hipHostMalloc(%zu) failed", want);
+        return nullptr;
+    }
+    ctx->host_pinned = (int*)p;
+    ctx->host_pinned_bytes = want;
+    return ctx->host_pinned;
+}
+
+void release_ctx(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto it = g_ctx.begin(); it != g_ctx.end();) {
+        if (device >= 0 && it->first != device) {
+            ++it;
+            continue;
+        }
+        DeviceCtx* c = it->second.get();
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();
+        for (auto& kv : c->fft_plans) (void)hipfftDestroy(kv.second);
+        for (int s = 0; s < SLOT_COUNT; ++s)
+            if (c->buf[s]) (void)hipFree(c->buf[s]);
+        if (c->host_pinned) (void)hipHostFree(c->host_pinned);
+        if (prev >= 0) (void)hipSetDevice(prev);
+        it = g_ctx.erase(it);
+    }
+}
+
+}  // namespace efgp
+
+using namespace efgp;
+
+extern "C" {
+
+int efgp_version(void) { return 1000 * 0 + 1; }
+
+const char* efgp_last_error(void) { return g_err; }
+
+int efgp_release_workspaces(int device) {
+    release_ctx(device);
+    return EFGP_OK;
+}
+
+int efgp_window_width(double tol, double sigma) { return es_width_for_tol(tol, sigma); }
+
+int64_t efgp_fine_grid_size(int64_t n_modes, double tol) {
+    (void)tol;
+    if (n_modes < 1) return 0;
+    return next_smooth_even(2 * n_modes);
+}
+
+int efgp_window_eval(double tol, double sigma, double X, int64_t* first_cell_out, double* vals_out, int* w_out,
+                     double* beta_out) {
+    EFGP_REQUIRE(first_cell_out && vals_out, "efgp_window_eval: null output");
+    EsParams p;
+    es_make_params(tol, sigma, &p);
+    const int W = p.w;
+    int64_t i0 = (int64_t)std::ceil(X - 0.5 * W);
+    double s = 2.0 * ((double)i0 - X + 0.5 * W) - 1.0;
+    const int stride = kMaxDegree + 1;
+    for (int j = 0; j < W; ++j) {
+        double acc = p.coef[j * stride + p.degree];
+        for (int k = p.degree - 1; k >= 0; --k) acc = std::fma(acc, s, p.coef[j * stride + k]);
+        vals_out[j] = acc;
+    }
+    *first_cell_out = i0;
+    if (w_out) *w_out = W;
+    if (beta_out) *beta_out = p.beta;
+    return EFGP_OK;
+}
+
+int efgp_window_deconv(double tol, int64_t nf, int64_t n_modes, double* out) {
+    EFGP_REQUIRE(out && nf > 0 && n_modes > 0 && n_modes <= nf, "efgp_window_deconv: bad sizes");
+    EsParams p;
+    es_make_params(tol, (double)nf / (double)n_modes, &p);
+    std::vector<double> f;
+    es_deconv_factors(p, nf, n_modes, &f);
+    std::memcpy(out, f.data(), sizeof(double) * (size_t)n_modes);
+    return EFGP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// Shared host-side plumbing for libefgp_hip: error reporting, per-device scratch buffers and a
+// hipFFT plan cache.  gfx950 only; no portability layers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/efgp_hip.h"
+
+namespace efgp {
+
+void set_error(const char* fmt, ...);
+
+#define EFGP_HIP_CHECK(expr)                                                                   \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            ::efgp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                              __LINE__);                                                       \
+            return EFGP_EHIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+#define EFGP_FFT_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipfftResult r__ = (expr);                                                        \
+        if (r__ != HIPFFT_SUCCESS) {                                                      \
+            ::efgp::set_error("%s failed: hipfft status %d (%s:%d)", #expr, (int)r__,     \
+                              __FILE__, __LINE__);                                        \
+            return EFGP_EHIP;                                                             \
+        }                                                                                 \
+    } while (0)
+
+#define EFGP_REQUIRE(cond, ...)              \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::efgp::set_error(__VA_ARGS__);  \
+            return EFGP_EINVAL;              \
+        }                                    \
+    } while (0)
+
+// scratch slots (grow-only device buffers, one set per device)
+enum Slot {
+    SLOT_FINE = 0,     // complex fine grids of the NUFFT (nbatch * prod nf)
+    SLOT_SLABS,        // per-workgroup partial fine grids of the spreader
+    SLOT_TOEP_PAD,     // zero-padded FFT buffer of the Toeplitz apply / CG
+    SLOT_CG_VEC,       // r, p, Ap of the CG solver
+    SLOT_CG_SCALARS,   // per-row scalars and flags of the CG solver
+    SLOT_MISC,         // reductions
+    SLOT_COUNT
+};
+
+struct DeviceCtx {
+    int device = -1;
+    int num_cu = 0;
+    int max_lds = 0;            // bytes of LDS one workgroup may use
+    void* buf[SLOT_COUNT] = {nullptr};
+    size_t cap[SLOT_COUNT] = {0};
+    // key: rank, n0, n1, n2, batch
+    std::map<std::tuple<int, int64_t, int64_t, int64_t, int64_t>, hipfftHandle> fft_plans;
+    int* host_pinned = nullptr;   // small pinned host buffer for status read-back
+    size_t host_pinned_bytes = 0;
+};
+
+// returns the context of `device` (creates it, queries properties); nullptr + error on failure
+DeviceCtx* device_ctx(int device);
+// grow-only scratch; synchronises the device before replacing a buffer.  nullptr on failure.
+void* scratch(DeviceCtx* ctx, Slot slot, size_t bytes);
+// cached batched complex-to-complex double plan bound to `stream`
+int fft_plan(DeviceCtx* ctx, int rank, const int64_t* n, int64_t batch, hipStream_t stream, hipfftHandle* out);
+int* pinned_host(DeviceCtx* ctx, size_t bytes);
+void release_ctx(int device);
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+        target = dev;
+    }
+    ~DeviceGuard() {
+        if (ok && prev >= 0 && prev != target) (void)hipSetDevice(prev);
+    }
+    int target = -1;
+};
+
+inline int64_t next_pow2(int64_t n) {
+    int64_t p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+}  // namespace efgp

@@ -1,0 +1,163 @@
+// Host-side window parameterisation (see es_kernel.hpp).  Pure C++, no device code.
+#include "es_kernel.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace efgp {
+
+double es_window(double z, double beta) {
+    double q = 1.0 - z * z;
+    if (q < 0.0) q = 0.0;
+    return std::exp(beta * (std::sqrt(q) - 1.0));
+}
+
+int es_width_for_tol(double tol, double sigma) {
+    // Measured l2 error of this window is ~5 exp(-pi w sqrt(1-1/sigma)) (calibrated against the
+    // exact transform for sigma in [1.25, 3]); invert it for w.
+    if (!(tol > 0.0)) tol = 1e-16;
+    if (tol < 1e-16) tol = 1e-16;
+    if (sigma < 1.1) sigma = 1.1;
+    double rate = M_PI * std::sqrt(1.0 - 1.0 / sigma);
+    int w = (int)std::ceil((std::log(1.0 / tol) + 1.5) / rate);
+    return std::min(kMaxWidth, std::max(2, w));
+}
+
+namespace {
+
+// window value at cell j as a function of s in [-1,1] (see EsParams::coef)
+long double cell_value(int w, double beta, int j, long double s) {
+    long double z = ((s + 1.0L) * 0.5L - 0.5L * w + j) * (2.0L / w);
+    long double q = 1.0L - z * z;
+    if (q < 0.0L) q = 0.0L;
+    return expl((long double)beta * (sqrtl(q) - 1.0L));
+}
+
+// Chebyshev interpolant of degree deg on [-1,1] -> monomial coefficients
+void cheb_fit(int w, double beta, int j, int deg, long double* mono) {
+    const int n = deg + 1;
+    std::vector<long double> fv(n), a(n);
+    const long double pi = acosl(-1.0L);
+    for (int i = 0; i < n; ++i) fv[i] = cell_value(w, beta, j, cosl(pi * (i + 0.5L) / n));
+    for (int k = 0; k < n; ++k) {
+        long double acc = 0;
+        for (int i = 0; i < n; ++i) acc += fv[i] * cosl(pi * k * (i + 0.5L) / n);
+        a[k] = acc * (k == 0 ? 1.0L : 2.0L) / n;
+    }
+    // sum_k a_k T_k(s) -> monomials, by the three-term recurrence on coefficient vectors
+    std::vector<long double> Tkm1(n, 0.0L), Tk(n, 0.0L), Tkp1(n, 0.0L);
+    for (int k = 0; k < n; ++k) mono[k] = 0.0L;
+    Tkm1[0] = 1.0L;                       // T_0
+    mono[0] += a[0];
+    if (n > 1) {
+        Tk[1] = 1.0L;                     // T_1
+        for (int m = 0; m < n; ++m) mono[m] += a[1] * Tk[m];
+    }
+    for (int k = 2; k < n; ++k) {
+        std::fill(Tkp1.begin(), Tkp1.end(), 0.0L);
+        for (int m = 0; m + 1 < n; ++m) Tkp1[m + 1] += 2.0L * Tk[m];
+        for (int m = 0; m < n; ++m) Tkp1[m] -= Tkm1[m];
+        for (int m = 0; m < n; ++m) mono[m] += a[k] * Tkp1[m];
+        Tkm1.swap(Tk);
+        Tk.swap(Tkp1);
+    }
+}
+
+double fit_error(const EsParams& p) {
+    double worst = 0.0;
+    const int stride = kMaxDegree + 1;
+    for (int j = 0; j < p.w; ++j) {
+        for (int t = 0; t <= 200; ++t) {
+            double s = -1.0 + 2.0 * t / 200.0;
+            double acc = p.coef[j * stride + p.degree];
+            for (int k = p.degree - 1; k >= 0; --k) acc = acc * s + p.coef[j * stride + k];
+            double ref = (double)cell_value(p.w, p.beta, j, s);
+            worst = std::max(worst, std::fabs(acc - ref));
+        }
+    }
+    return worst;
+}
+
+}  // namespace
+
+int es_make_params(double tol, double sigma, EsParams* p) {
+    if (!p) return -1;
+    std::memset(p, 0, sizeof(*p));
+    p->w = es_width_for_tol(tol, sigma);
+    p->beta = 0.976 * M_PI * p->w * (1.0 - 1.0 / (2.0 * sigma));
+    const int stride = kMaxDegree + 1;
+    const double target = std::max(0.05 * tol, 2e-15);
+    long double mono[kMaxDegree + 1];
+    for (int deg = std::min(kMaxDegree, std::max(4, p->w + 1)); deg <= kMaxDegree; ++deg) {
+        p->degree = deg;
+        for (int j = 0; j < p->w; ++j) {
+            cheb_fit(p->w, p->beta, j, deg, mono);
+            for (int k = 0; k <= kMaxDegree; ++k) p->coef[j * stride + k] = (k <= deg) ? (double)mono[k] : 0.0;
+        }
+        p->fit_error = fit_error(*p);
+        if (p->fit_error <= target) break;
+    }
+    return 0;
+}
+
+void es_deconv_factors(const EsParams& p, int64_t nf, int64_t n_modes, std::vector<double>* out) {
+    // Gauss-Legendre on [0,1] (integrand even); nodes by Newton iteration on P_n.
+    const int nq = 96;
+    std::vector<long double> xs(nq), wt(nq);
+    const long double pi = acosl(-1.0L);
+    for (int i = 0; i < nq; ++i) {
+        long double x = cosl(pi * (i + 0.75L) / (nq + 0.5L));
+        long double dp = 1;
+        for (int it = 0; it < 100; ++it) {
+            long double p0 = 1.0L, p1 = x;
+            for (int k = 2; k <= nq; ++k) {
+                long double pk = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k;
+                p0 = p1; p1 = pk;
+            }
+            dp = nq * (x * p1 - p0) / (x * x - 1.0L);
+            long double dx = p1 / dp;
+            x -= dx;
+            if (fabsl(dx) < 1e-19L) break;
+        }
+        {   // recompute derivative at the converged node
+            long double p0 = 1.0L, p1 = x;
+            for (int k = 2; k <= nq; ++k) {
+                long double pk = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k;
+                p0 = p1; p1 = pk;
+            }
+            dp = nq * (x * p1 - p0) / (x * x - 1.0L);
+        }
+        xs[i] = x;
+        wt[i] = 2.0L / ((1.0L - x * x) * dp * dp);
+    }
+    out->resize((size_t)n_modes);
+    const int64_t kmin = -(n_modes / 2);
+    for (int64_t i = 0; i < n_modes; ++i) {
+        long double k = (long double)(kmin + i);
+        long double arg = k * p.w * pi / (long double)nf;
+        long double acc = 0;
+        for (int q = 0; q < nq; ++q) {
+            // map node from [-1,1] to z in [0,1]:  z = (x+1)/2, weight/2; integrand even -> times 2
+            long double z = 0.5L * (xs[q] + 1.0L);
+            long double ph = expl((long double)p.beta * (sqrtl(std::max(0.0L, 1.0L - z * z)) - 1.0L));
+            acc += wt[q] * 0.5L * 2.0L * ph * cosl(arg * z);
+        }
+        long double P = 0.5L * p.w * acc;
+        (*out)[(size_t)i] = (double)(1.0L / P);
+    }
+}
+
+int64_t next_smooth_even(int64_t n) {
+    if (n < 2) n = 2;
+    if (n & 1) ++n;
+    for (;; n += 2) {
+        int64_t m = n;
+        while (m % 2 == 0) m /= 2;
+        while (m % 3 == 0) m /= 3;
+        while (m % 5 == 0) m /= 5;
+        if (m == 1) return n;
+    }
+}
+
+}  // namespace efgp

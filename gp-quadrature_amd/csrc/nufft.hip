@@ -1,0 +1,827 @@
+// NUFFT type-1 / type-2 for gfx950: hand-written spread / interpolate kernels around hipFFT
+// (rocFFT) transforms of a small fine grid.
+//
+// Replaces the FINUFFT calls of the reference (efgpnd.py:1496-1499, 1533-1549, 1679).
+//
+// Data layout in HBM
+//   x        (N,d) row-major doubles, caller-owned, read once per transform (coalesced 8d B/point)
+//   strengths real (N) / complex (N) per batch row, read once
+//   slabs    [batch][workgroup][channel][prod nf] doubles  -- per-workgroup partial fine grids that
+//            were accumulated in LDS (each workgroup streams a contiguous chunk of the points)
+//   fine     [batch][prod nf] complex -- reduced fine grid, transformed in place by hipFFT
+//   out      [batch][prod n_modes] complex
+// The fine grid is tiny for this workload (n_modes <= ~150 per dimension), so whenever it fits in
+// the 160 KB LDS of a CU the points are streamed UNSORTED and accumulated with LDS atomics; larger
+// grids fall back to global (L2) atomics.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+#include "es_kernel.hpp"
+
+namespace efgp {
+
+constexpr int kSpreadThreads = 512;
+constexpr int kInterpThreads = 256;
+
+enum StrengthMode { STR_REAL = 0, STR_COMPLEX = 1, STR_REAL_AND_ONES = 2, STR_ONES = 3 };
+
+struct GridGeom {
+    int64_t nf[3];      // fine-grid size per dimension (unused dims = 1)
+    double scale[3];    // X = scale * (x - xcen): h * nf
+    double xcen[3];
+    int64_t cells;      // prod nf
+};
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void window_values(const double* __restrict__ coef, int degree, double X, int64_t nf,
+                                              int& first, double (&val)[W]) {
+    // first covered cell and the Horner variable (see EsParams::coef)
+    double i0 = ceil(X - 0.5 * W);
+    double s = 2.0 * (i0 - X + 0.5 * W) - 1.0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) val[j] = coef[degree * W + j];
+    for (int k = degree - 1; k >= 0; --k) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) val[j] = fma(val[j], s, coef[k * W + j]);
+    }
+    int f = (int)i0;
+    if (f < 0) f += (int)nf;
+    first = f;
+}
+
+__device__ __forceinline__ double fold(double X, double nf) {
+    X -= nf * floor(X / nf);
+    // guard against X == nf after rounding
+    if (X >= nf) X -= nf;
+    if (X < 0.0) X = 0.0;
+    return X;
+}
+
+__device__ __forceinline__ int wrap(int i, int nf) { return i >= nf ? i - nf : i; }
+
+// ------------------------------------------------------------------------------------------
+// type-1 spreader.  One thread per point; grid = (workgroups, nbatch).
+//   USE_LDS: accumulate into an LDS-resident copy of the fine grid, flush to the workgroup's slab.
+//   else   : atomics straight into slab 0 (global memory, pre-zeroed).
+// ------------------------------------------------------------------------------------------
+struct SpreadArgs {
+    const double* x;
+    const double* c;          // strengths (layout by mode); batch stride c_stride doubles
+    int64_t c_stride;
+    int64_t npts;
+    GridGeom g;
+    const double* coef;       // [degree+1][W]
+    int degree;
+    int mode;                 // StrengthMode
+    int channels;             // 1 or 2
+    double* slabs;            // [batch][nslab][channels][cells]
+    int nslab;
+};
+
+template <int D, int W, bool USE_LDS>
+__global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
+    extern __shared__ double lds[];
+    const int batch = blockIdx.y;
+    const int64_t cells = a.g.cells;
+    const int C = a.channels;
+    double* slab = a.slabs + ((int64_t)batch * a.nslab + (USE_LDS ? blockIdx.x : 0)) * C * cells;
+    if (USE_LDS) {
+        for (int64_t i = threadIdx.x; i < C * cells; i += kSpreadThreads) lds[i] = 0.0;
+        __syncthreads();
+    }
+    double* acc = USE_LDS ? lds : slab;
+
+    // contiguous chunk of points per workgroup (streaming, coalesced)
+    const int64_t per = (a.npts + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per;
+    const int64_t hi = lo + per < a.npts ? lo + per : a.npts;
+    const double* cb = a.c ? a.c + (int64_t)batch * a.c_stride : nullptr;
+    const int nf0 = (int)a.g.nf[0], nf1 = (int)a.g.nf[1], nf2 = (int)a.g.nf[2];
+
+    for (int64_t n = lo + threadIdx.x; n < hi; n += kSpreadThreads) {
+        double c0 = 1.0, c1 = 1.0;
+        if (a.mode == STR_REAL) {
+            c0 = cb[n];
+        } else if (a.mode == STR_COMPLEX) {
+            const double2 cc = reinterpret_cast<const double2*>(cb)[n];
+            c0 = cc.x;
+            c1 = cc.y;
+        } else if (a.mode == STR_REAL_AND_ONES) {
+            c0 = cb[n];
+        }
+        double v0[W], v1[W], v2[W];
+        int f0 = 0, f1 = 0, f2 = 0;
+        {
+            double X = fold(a.g.scale[0] * (a.x[n * D + 0] - a.g.xcen[0]), (double)nf0);
+            window_values<W>(a.coef, a.degree, X, nf0, f0, v0);
+        }
+        if (D > 1) {
+            double X = fold(a.g.scale[1] * (a.x[n * D + 1] - a.g.xcen[1]), (double)nf1);
+            window_values<W>(a.coef, a.degree, X, nf1, f1, v1);
+        }
+        if (D > 2) {
+            double X = fold(a.g.scale[2] * (a.x[n * D + 2] - a.g.xcen[2]), (double)nf2);
+            window_values<W>(a.coef, a.degree, X, nf2, f2, v2);
+        }
+        if (D == 1) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                int i = wrap(f0 + j, nf0);
+                double w = v0[j];
+                if (USE_LDS) {
+                    __hip_atomic_fetch_add(&acc[i], w * c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (C == 2) __hip_atomic_fetch_add(&acc[cells + i], w * c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    unsafeAtomicAdd(&acc[i], w * c0);
+                    if (C == 2) unsafeAtomicAdd(&acc[cells + i], w * c1);
+                }
+            }
+        } else if (D == 2) {
+#pragma unroll
+            for (int j0 = 0; j0 < W; ++j0) {
+                const int row = wrap(f0 + j0, nf0) * nf1;
+                const double w0 = v0[j0];
+                const double a0 = w0 * c0, a1 = w0 * c1;
+#pragma unroll
+                for (int j1 = 0; j1 < W; ++j1) {
+                    int i = row + wrap(f1 + j1, nf1);
+                    if (USE_LDS) {
+                        __hip_atomic_fetch_add(&acc[i], a0 * v1[j1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (C == 2)
+                            __hip_atomic_fetch_add(&acc[cells + i], a1 * v1[j1], __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        unsafeAtomicAdd(&acc[i], a0 * v1[j1]);
+                        if (C == 2) unsafeAtomicAdd(&acc[cells + i], a1 * v1[j1]);
+                    }
+                }
+            }
+        } else {
+            for (int j0 = 0; j0 < W; ++j0) {
+                const int64_t p0 = (int64_t)wrap(f0 + j0, nf0) * nf1;
+                for (int j1 = 0; j1 < W; ++j1) {
+                    const int64_t p1 = (p0 + wrap(f1 + j1, nf1)) * nf2;
+                    const double w01 = v0[j0] * v1[j1];
+                    const double a0 = w01 * c0, a1 = w01 * c1;
+#pragma unroll
+                    for (int j2 = 0; j2 < W; ++j2) {
+                        int64_t i = p1 + wrap(f2 + j2, nf2);
+                        if (USE_LDS) {
+                            __hip_atomic_fetch_add(&acc[i], a0 * v2[j2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (C == 2)
+                                __hip_atomic_fetch_add(&acc[cells + i], a1 * v2[j2], __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else {
+                            unsafeAtomicAdd(&acc[i], a0 * v2[j2]);
+                            if (C == 2) unsafeAtomicAdd(&acc[cells + i], a1 * v2[j2]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (USE_LDS) {
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < C * cells; i += kSpreadThreads) slab[i] = lds[i];
+    }
+}
+
+// sum the slabs of one batch row into the complex fine grid: fine = ch0 + i*ch1 (ch1 = 0 if absent)
+__global__ void reduce_slabs_kernel(const double* __restrict__ slabs, int nslab, int channels, int64_t cells,
+                                    double2* __restrict__ fine) {
+    const int batch = blockIdx.y;
+    const double* base = slabs + (int64_t)batch * nslab * channels * cells;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+        double re = 0.0, im = 0.0;
+        for (int s = 0; s < nslab; ++s) {
+            const double* p = base + (int64_t)s * channels * cells;
+            re += p[i];
+            if (channels == 2) im += p[cells + i];
+        }
+        fine[(int64_t)batch * cells + i] = make_double2(re, im);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// mode <-> fine-grid index bookkeeping shared by the deconvolve / precorrect kernels
+// ------------------------------------------------------------------------------------------
+struct ModeGeom {
+    int d;
+    int64_t nm[3];      // modes per dimension
+    int64_t nf[3];
+    int64_t total;      // prod nm
+    int modeord;        // 0 CMCL, 1 FFT order
+    const double* fac[3];   // per-dimension correction factors, indexed by (k - kmin), kmin = -(nm/2)
+};
+
+__device__ __forceinline__ int64_t mode_of_slot(int64_t slot, int64_t nm, int modeord) {
+    if (modeord == 0) return slot - nm / 2;
+    return slot <= (nm - 1) / 2 ? slot : slot - nm;
+}
+
+// type 1: out[b][slot] = fac * FFT(fine)[k mod nf]; optional Hermitian split for the (y, ones) pair
+//   part = 0: plain;  part = 1: (H[k] + conj(H[-k]))/2;  part = 2: (H[k] - conj(H[-k]))/(2i)
+__global__ void deconvolve_kernel(const double2* __restrict__ fine, int64_t cells, ModeGeom m, int part,
+                                  double2* __restrict__ out) {
+    const int batch = blockIdx.y;
+    const double2* F = fine + (int64_t)batch * cells;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m.total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t rem = t;
+        int64_t idx = 0, idxn = 0;
+        double f = 1.0;
+        int64_t slots[3];
+        for (int a = m.d - 1; a >= 0; --a) {
+            slots[a] = rem % m.nm[a];
+            rem /= m.nm[a];
+        }
+        for (int a = 0; a < m.d; ++a) {
+            int64_t k = mode_of_slot(slots[a], m.nm[a], m.modeord);
+            f *= m.fac[a][k + m.nm[a] / 2];
+            int64_t p = k < 0 ? k + m.nf[a] : k;
+            int64_t q = k > 0 ? m.nf[a] - k : -k;       // index of -k
+            idx = idx * m.nf[a] + p;
+            idxn = idxn * m.nf[a] + q;
+        }
+        double2 H = F[idx];
+        double2 r;
+        if (part == 0) {
+            r = make_double2(H.x * f, H.y * f);
+        } else {
+            double2 G = F[idxn];        // H[-k]
+            if (part == 1) r = make_double2(0.5 * (H.x + G.x) * f, 0.5 * (H.y - G.y) * f);
+            else r = make_double2(0.5 * (H.y + G.y) * f, 0.5 * (G.x - H.x) * f);
+        }
+        out[(int64_t)batch * m.total + t] = r;
+    }
+}
+
+// type 2: fine[b][k mod nf] = fac * f[b][slot] (fine pre-zeroed).  herm != 0 stores the Hermitian part
+// (f[k] + conj f[-k])/2 so that the transformed grid is real (real_only outputs).
+__global__ void precorrect_kernel(const double2* __restrict__ fin, ModeGeom m, int herm, int64_t cells,
+                                  double2* __restrict__ fine) {
+    const int batch = blockIdx.y;
+    const double2* fb = fin + (int64_t)batch * m.total;
+    double2* F = fine + (int64_t)batch * cells;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m.total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t rem = t;
+        int64_t slots[3];
+        for (int a = m.d - 1; a >= 0; --a) {
+            slots[a] = rem % m.nm[a];
+            rem /= m.nm[a];
+        }
+        int64_t idx = 0, tn = 0;
+        bool has_neg = true;
+        double f = 1.0;
+        for (int a = 0; a < m.d; ++a) {
+            int64_t k = mode_of_slot(slots[a], m.nm[a], m.modeord);
+            f *= m.fac[a][k + m.nm[a] / 2];
+            idx = idx * m.nf[a] + (k < 0 ? k + m.nf[a] : k);
+            // slot of -k inside the mode box (may not exist for even sizes)
+            int64_t kn = -k;
+            int64_t kmin = -(m.nm[a] / 2), kmax = (m.nm[a] - 1) / 2;
+            if (kn < kmin || kn > kmax) has_neg = false;
+            int64_t sn = m.modeord == 0 ? kn - kmin : (kn >= 0 ? kn : kn + m.nm[a]);
+            tn = tn * m.nm[a] + sn;
+        }
+        double2 v = fb[t];
+        if (herm) {
+            double2 u = has_neg ? fb[tn] : make_double2(0.0, 0.0);
+            v = make_double2(0.5 * (v.x + u.x), 0.5 * (v.y - u.y));
+        }
+        F[idx] = make_double2(v.x * f, v.y * f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// type-2 interpolation.  One thread per point; grid = (workgroups, nbatch).
+//   CPLX: fine grid values are complex (else only the real part is used / produced).
+//   USE_LDS: the batch row's fine grid is first copied to LDS.
+// ------------------------------------------------------------------------------------------
+struct InterpArgs {
+    const double* x;
+    int64_t npts;
+    GridGeom g;
+    const double* coef;
+    int degree;
+    const double2* fine;     // [batch][cells]
+    void* out;               // [batch][npts] complex or real
+};
+
+template <int D, int W, bool CPLX, bool USE_LDS>
+__global__ __launch_bounds__(kInterpThreads) void interp_kernel(InterpArgs a) {
+    extern __shared__ double lds[];
+    const int batch = blockIdx.y;
+    const int64_t cells = a.g.cells;
+    const double2* F = a.fine + (int64_t)batch * cells;
+    if (USE_LDS) {
+        if (CPLX) {
+            double2* l2 = reinterpret_cast<double2*>(lds);
+            for (int64_t i = threadIdx.x; i < cells; i += kInterpThreads) l2[i] = F[i];
+        } else {
+            for (int64_t i = threadIdx.x; i < cells; i += kInterpThreads) lds[i] = F[i].x;
+        }
+        __syncthreads();
+    }
+    const int nf0 = (int)a.g.nf[0], nf1 = (int)a.g.nf[1], nf2 = (int)a.g.nf[2];
+    auto load = [&](int64_t i, double& re, double& im) {
+        if (USE_LDS) {
+            if (CPLX) {
+                double2 v = reinterpret_cast<const double2*>(lds)[i];
+                re = v.x;
+                im = v.y;
+            } else {
+                re = lds[i];
+                im = 0.0;
+            }
+        } else {
+            if (CPLX) {
+                double2 v = F[i];
+                re = v.x;
+                im = v.y;
+            } else {
+                re = F[i].x;
+                im = 0.0;
+            }
+        }
+    };
+    for (int64_t n = (int64_t)blockIdx.x * kInterpThreads + threadIdx.x; n < a.npts;
+         n += (int64_t)gridDim.x * kInterpThreads) {
+        double v0[W], v1[W], v2[W];
+        int f0 = 0, f1 = 0, f2 = 0;
+        {
+            double X = fold(a.g.scale[0] * (a.x[n * D + 0] - a.g.xcen[0]), (double)nf0);
+            window_values<W>(a.coef, a.degree, X, nf0, f0, v0);
+        }
+        if (D > 1) {
+            double X = fold(a.g.scale[1] * (a.x[n * D + 1] - a.g.xcen[1]), (double)nf1);
+            window_values<W>(a.coef, a.degree, X, nf1, f1, v1);
+        }
+        if (D > 2) {
+            double X = fold(a.g.scale[2] * (a.x[n * D + 2] - a.g.xcen[2]), (double)nf2);
+            window_values<W>(a.coef, a.degree, X, nf2, f2, v2);
+        }
+        double sre = 0.0, sim = 0.0;
+        if (D == 1) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                double re, im;
+                load(wrap(f0 + j, nf0), re, im);
+                sre = fma(v0[j], re, sre);
+                if (CPLX) sim = fma(v0[j], im, sim);
+            }
+        } else if (D == 2) {
+#pragma unroll
+            for (int j0 = 0; j0 < W; ++j0) {
+                const int row = wrap(f0 + j0, nf0) * nf1;
+                double rre = 0.0, rim = 0.0;
+#pragma unroll
+                for (int j1 = 0; j1 < W; ++j1) {
+                    double re, im;
+                    load(row + wrap(f1 + j1, nf1), re, im);
+                    rre = fma(v1[j1], re, rre);
+                    if (CPLX) rim = fma(v1[j1], im, rim);
+                }
+                sre = fma(v0[j0], rre, sre);
+                if (CPLX) sim = fma(v0[j0], rim, sim);
+            }
+        } else {
+            for (int j0 = 0; j0 < W; ++j0) {
+                const int64_t p0 = (int64_t)wrap(f0 + j0, nf0) * nf1;
+                double are = 0.0, aim = 0.0;
+                for (int j1 = 0; j1 < W; ++j1) {
+                    const int64_t p1 = (p0 + wrap(f1 + j1, nf1)) * nf2;
+                    double rre = 0.0, rim = 0.0;
+#pragma unroll
+                    for (int j2 = 0; j2 < W; ++j2) {
+                        double re, im;
+                        load(p1 + wrap(f2 + j2, nf2), re, im);
+                        rre = fma(v2[j2], re, rre);
+                        if (CPLX) rim = fma(v2[j2], im, rim);
+                    }
+                    are = fma(v1[j1], rre, are);
+                    if (CPLX) aim = fma(v1[j1], rim, aim);
+                }
+                sre = fma(v0[j0], are, sre);
+                if (CPLX) sim = fma(v0[j0], aim, sim);
+            }
+        }
+        if (CPLX) reinterpret_cast<double2*>(a.out)[(int64_t)batch * a.npts + n] = make_double2(sre, sim);
+        else reinterpret_cast<double*>(a.out)[(int64_t)batch * a.npts + n] = sre;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct WindowSet {          // device copies of the window data for one (tolerance, sigma, nf, n_modes) setting
+    EsParams p;
+    double* d_coef = nullptr;       // [degree+1][W]
+    double* d_fac[3] = {nullptr, nullptr, nullptr};
+    int64_t nm[3] = {0, 0, 0};
+    int64_t nf[3] = {0, 0, 0};
+};
+
+}  // namespace efgp
+
+using namespace efgp;
+
+struct efgp_nufft_s {
+    int device = 0;
+    int dim = 0;
+    int64_t npts = 0;
+    const double* x = nullptr;
+    double xcen[3] = {0, 0, 0};
+    double h = 0.0;
+    double tol = 1e-6;
+    DeviceCtx* ctx = nullptr;
+    std::vector<WindowSet*> windows;     // cached per mode-box
+};
+
+namespace efgp {
+
+static void free_window(WindowSet* w) {
+    if (!w) return;
+    if (w->d_coef) (void)hipFree(w->d_coef);
+    for (int a = 0; a < 3; ++a)
+        if (w->d_fac[a]) (void)hipFree(w->d_fac[a]);
+    delete w;
+}
+
+// window data for a mode box: fine grid = next 2^a3^b5^c size >= 2*n_modes (>= 32)
+static int get_window(efgp_nufft_s* plan, const int64_t* n_modes, hipStream_t stream, WindowSet** out) {
+    const int d = plan->dim;
+    for (WindowSet* w : plan->windows) {
+        bool same = true;
+        for (int a = 0; a < d; ++a) same = same && w->nm[a] == n_modes[a];
+        if (same) {
+            *out = w;
+            return EFGP_OK;
+        }
+    }
+    auto* w = new WindowSet();
+    double sigma_min = 1e30;
+    for (int a = 0; a < 3; ++a) {
+        w->nm[a] = a < d ? n_modes[a] : 1;
+        w->nf[a] = a < d ? std::max<int64_t>(32, next_smooth_even(2 * n_modes[a])) : 1;
+        if (a < d) sigma_min = std::min(sigma_min, (double)w->nf[a] / (double)w->nm[a]);
+    }
+    es_make_params(plan->tol, sigma_min, &w->p);
+    const int W = w->p.w, deg = w->p.degree;
+    std::vector<double> coef((size_t)(deg + 1) * W);
+    for (int k = 0; k <= deg; ++k)
+        for (int j = 0; j < W; ++j) coef[(size_t)k * W + j] = w->p.coef[j * (kMaxDegree + 1) + k];
+    if (hipMalloc((void**)&w->d_coef, coef.size() * sizeof(double)) != hipSuccess) {
+        free_window(w);
+        set_error("hipMalloc window coefficients failed");
+        return EFGP_ENOMEM;
+    }
+    if (hipMemcpyAsync(w->d_coef, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) {
+        free_window(w);
+        set_error("copy of window coefficients failed");
+        return EFGP_EHIP;
+    }
+    for (int a = 0; a < d; ++a) {
+        std::vector<double> fac;
+        es_deconv_factors(w->p, w->nf[a], w->nm[a], &fac);
+        if (hipMalloc((void**)&w->d_fac[a], fac.size() * sizeof(double)) != hipSuccess ||
+            hipMemcpyAsync(w->d_fac[a], fac.data(), fac.size() * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) {
+            free_window(w);
+            set_error("upload of correction factors failed");
+            return EFGP_EHIP;
+        }
+    }
+    plan->windows.push_back(w);
+    *out = w;
+    return EFGP_OK;
+}
+
+static GridGeom make_geom(const efgp_nufft_s* plan, const WindowSet* w) {
+    GridGeom g;
+    g.cells = 1;
+    for (int a = 0; a < 3; ++a) {
+        g.nf[a] = w->nf[a];
+        g.scale[a] = plan->h * (double)w->nf[a];
+        g.xcen[a] = plan->xcen[a];
+        g.cells *= w->nf[a];
+    }
+    return g;
+}
+
+static ModeGeom make_modes(const efgp_nufft_s* plan, const WindowSet* w, const int64_t* nm, int modeord) {
+    ModeGeom m;
+    m.d = plan->dim;
+    m.total = 1;
+    for (int a = 0; a < 3; ++a) {
+        m.nm[a] = a < plan->dim ? nm[a] : 1;
+        m.nf[a] = w->nf[a];
+        m.fac[a] = w->d_fac[a];
+        m.total *= m.nm[a];
+    }
+    m.modeord = modeord;
+    return m;
+}
+
+template <int D, int W>
+static hipError_t launch_spread_dw(bool use_lds, dim3 grid, size_t lds_bytes, hipStream_t s, const SpreadArgs& a) {
+    if (use_lds) {
+        auto k = spread_kernel<D, W, true>;
+        if (lds_bytes > 65536) {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k, grid, dim3(kSpreadThreads), lds_bytes, s, a);
+    } else {
+        hipLaunchKernelGGL((spread_kernel<D, W, false>), grid, dim3(kSpreadThreads), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_spread_d(int W, bool use_lds, dim3 grid, size_t lds_bytes, hipStream_t s, const SpreadArgs& a) {
+    switch (W) {
+#define EFGP_CASE(w_) case w_: return launch_spread_dw<D, w_>(use_lds, grid, lds_bytes, s, a);
+        EFGP_CASE(2) EFGP_CASE(3) EFGP_CASE(4) EFGP_CASE(5) EFGP_CASE(6) EFGP_CASE(7) EFGP_CASE(8) EFGP_CASE(9)
+        EFGP_CASE(10) EFGP_CASE(11) EFGP_CASE(12) EFGP_CASE(13) EFGP_CASE(14) EFGP_CASE(15) EFGP_CASE(16)
+#undef EFGP_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int D, int W, bool CPLX>
+static hipError_t launch_interp_dwc(bool use_lds, dim3 grid, size_t lds_bytes, hipStream_t s, const InterpArgs& a) {
+    if (use_lds) {
+        auto k = interp_kernel<D, W, CPLX, true>;
+        if (lds_bytes > 65536) {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k, grid, dim3(kInterpThreads), lds_bytes, s, a);
+    } else {
+        hipLaunchKernelGGL((interp_kernel<D, W, CPLX, false>), grid, dim3(kInterpThreads), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_interp_d(int W, bool cplx, bool use_lds, dim3 grid, size_t lds_bytes, hipStream_t s,
+                                  const InterpArgs& a) {
+    switch (W) {
+#define EFGP_CASE(w_)                                                                   \
+    case w_:                                                                            \
+        return cplx ? launch_interp_dwc<D, w_, true>(use_lds, grid, lds_bytes, s, a)   \
+                    : launch_interp_dwc<D, w_, false>(use_lds, grid, lds_bytes, s, a);
+        EFGP_CASE(2) EFGP_CASE(3) EFGP_CASE(4) EFGP_CASE(5) EFGP_CASE(6) EFGP_CASE(7) EFGP_CASE(8) EFGP_CASE(9)
+        EFGP_CASE(10) EFGP_CASE(11) EFGP_CASE(12) EFGP_CASE(13) EFGP_CASE(14) EFGP_CASE(15) EFGP_CASE(16)
+#undef EFGP_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+// spread + reduce + FFT; leaves the transformed fine grids in SLOT_FINE
+static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int mode, int nbatch, int isign,
+                          hipStream_t stream, double2** fine_out) {
+    DeviceCtx* ctx = plan->ctx;
+    const GridGeom g = make_geom(plan, w);
+    const int channels = (mode == STR_COMPLEX || mode == STR_REAL_AND_ONES) ? 2 : 1;
+    const size_t lds_bytes = (size_t)channels * (size_t)g.cells * sizeof(double);
+    const bool use_lds = lds_bytes <= (size_t)ctx->max_lds && plan->npts > 0;
+    int nwg = 1;
+    if (use_lds) {
+        int per_cu = std::max(1, std::min(2, (int)((size_t)ctx->max_lds / std::max<size_t>(lds_bytes, 1))));
+        int64_t want = (plan->npts + 4 * kSpreadThreads - 1) / (4 * kSpreadThreads);
+        nwg = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->num_cu * per_cu, want));
+    } else {
+        int64_t want = (plan->npts + kSpreadThreads - 1) / kSpreadThreads;
+        nwg = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->num_cu * 8, want));
+    }
+    const int nslab = use_lds ? nwg : 1;
+    const size_t slab_bytes = (size_t)nbatch * nslab * channels * (size_t)g.cells * sizeof(double);
+    double* slabs = (double*)scratch(ctx, SLOT_SLABS, slab_bytes);
+    double2* fine = (double2*)scratch(ctx, SLOT_FINE, (size_t)nbatch * (size_t)g.cells * sizeof(double2));
+    if (!slabs || !fine) return EFGP_ENOMEM;
+    if (!use_lds) EFGP_HIP_CHECK(hipMemsetAsync(slabs, 0, slab_bytes, stream));
+
+    SpreadArgs a;
+    a.x = plan->x;
+    a.c = c;
+    a.c_stride = (mode == STR_COMPLEX) ? 2 * plan->npts : plan->npts;
+    a.npts = plan->npts;
+    a.g = g;
+    a.coef = w->d_coef;
+    a.degree = w->p.degree;
+    a.mode = mode;
+    a.channels = channels;
+    a.slabs = slabs;
+    a.nslab = nslab;
+    dim3 grid(nwg, nbatch);
+    hipError_t e = hipSuccess;
+    if (plan->npts > 0) {
+        if (plan->dim == 1) e = launch_spread_d<1>(w->p.w, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
+        else if (plan->dim == 2) e = launch_spread_d<2>(w->p.w, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
+        else e = launch_spread_d<3>(w->p.w, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
+    } else {
+        EFGP_HIP_CHECK(hipMemsetAsync(slabs, 0, slab_bytes, stream));
+    }
+    if (e != hipSuccess) {
+        set_error("spread kernel launch failed: %s", hipGetErrorString(e));
+        return EFGP_EHIP;
+    }
+    {
+        int threads = 256;
+        int blocks = (int)std::min<int64_t>((g.cells + threads - 1) / threads, 1024);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks, nbatch), dim3(threads), 0, stream, slabs, nslab, channels,
+                           g.cells, fine);
+        EFGP_HIP_CHECK(hipGetLastError());
+    }
+    hipfftHandle fh;
+    int rc = fft_plan(ctx, plan->dim, g.nf, nbatch, stream, &fh);
+    if (rc != EFGP_OK) return rc;
+    EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)fine, (hipfftDoubleComplex*)fine,
+                                 isign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
+    *fine_out = fine;
+    return EFGP_OK;
+}
+
+static int run_deconvolve(efgp_nufft_s* plan, WindowSet* w, const double2* fine, const int64_t* nm, int modeord,
+                          int part, int nbatch, void* out, hipStream_t stream) {
+    ModeGeom m = make_modes(plan, w, nm, modeord);
+    int64_t cells = 1;
+    for (int a = 0; a < 3; ++a) cells *= w->nf[a];
+    int threads = 256;
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((m.total + threads - 1) / threads, 2048));
+    hipLaunchKernelGGL(deconvolve_kernel, dim3(blocks, nbatch), dim3(threads), 0, stream, fine, cells, m, part,
+                       (double2*)out);
+    EFGP_HIP_CHECK(hipGetLastError());
+    return EFGP_OK;
+}
+
+}  // namespace efgp
+
+extern "C" {
+
+int efgp_nufft_create(efgp_nufft_t** plan_out, int device, int dim, int64_t npts, const double* x,
+                      const double* xcen_host, double h, double tol) {
+    EFGP_REQUIRE(plan_out, "efgp_nufft_create: null plan_out");
+    EFGP_REQUIRE(dim >= 1 && dim <= 3, "efgp_nufft_create: dim must be 1, 2 or 3 (got %d)", dim);
+    EFGP_REQUIRE(npts >= 0, "efgp_nufft_create: negative point count");
+    EFGP_REQUIRE(npts == 0 || x, "efgp_nufft_create: null x");
+    EFGP_REQUIRE(std::isfinite(h), "efgp_nufft_create: h must be finite");
+    DeviceCtx* ctx = device_ctx(device);
+    if (!ctx) return EFGP_EHIP;
+    auto* p = new efgp_nufft_s();
+    p->device = device;
+    p->dim = dim;
+    p->npts = npts;
+    p->x = x;
+    p->h = h;
+    p->tol = tol;
+    p->ctx = ctx;
+    for (int a = 0; a < dim; ++a) p->xcen[a] = xcen_host ? xcen_host[a] : 0.0;
+    *plan_out = p;
+    return EFGP_OK;
+}
+
+int efgp_nufft_destroy(efgp_nufft_t* plan) {
+    if (!plan) return EFGP_OK;
+    DeviceGuard guard(plan->device);
+    (void)hipDeviceSynchronize();
+    for (WindowSet* w : plan->windows) free_window(w);
+    delete plan;
+    return EFGP_OK;
+}
+
+int efgp_nufft_type1(efgp_nufft_t* plan, const void* c, int c_is_complex, int nbatch, const int64_t* n_modes,
+                     int isign, int modeord, void* out, void* stream_) {
+    EFGP_REQUIRE(plan && n_modes && out, "efgp_nufft_type1: null argument");
+    EFGP_REQUIRE(nbatch >= 1, "efgp_nufft_type1: nbatch must be >= 1");
+    EFGP_REQUIRE(plan->npts == 0 || c, "efgp_nufft_type1: null strengths");
+    for (int a = 0; a < plan->dim; ++a) EFGP_REQUIRE(n_modes[a] >= 1, "efgp_nufft_type1: n_modes[%d] < 1", a);
+    EFGP_REQUIRE(isign == 1 || isign == -1, "efgp_nufft_type1: isign must be +-1");
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(plan->device);
+    WindowSet* w = nullptr;
+    int rc = get_window(plan, n_modes, stream, &w);
+    if (rc != EFGP_OK) return rc;
+    double2* fine = nullptr;
+    rc = spread_and_fft(plan, w, (const double*)c, c_is_complex ? STR_COMPLEX : STR_REAL, nbatch, isign, stream, &fine);
+    if (rc != EFGP_OK) return rc;
+    return run_deconvolve(plan, w, fine, n_modes, modeord, 0, nbatch, out, stream);
+}
+
+int efgp_nufft_type1_pair(efgp_nufft_t* plan, const double* y, const int64_t* n_modes_y, void* out_y,
+                          const int64_t* n_modes_one, void* out_ones, void* stream_) {
+    EFGP_REQUIRE(plan, "efgp_nufft_type1_pair: null plan");
+    EFGP_REQUIRE(out_y || out_ones, "efgp_nufft_type1_pair: nothing to compute");
+    EFGP_REQUIRE(!out_y || (y && n_modes_y), "efgp_nufft_type1_pair: y / n_modes_y missing");
+    EFGP_REQUIRE(!out_ones || n_modes_one, "efgp_nufft_type1_pair: n_modes_one missing");
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(plan->device);
+    // one fine grid sized for the larger box serves both
+    int64_t box[3] = {1, 1, 1};
+    for (int a = 0; a < plan->dim; ++a) {
+        int64_t m = 1;
+        if (out_y) m = std::max(m, n_modes_y[a]);
+        if (out_ones) m = std::max(m, n_modes_one[a]);
+        EFGP_REQUIRE(m >= 1, "efgp_nufft_type1_pair: bad mode count");
+        box[a] = m;
+    }
+    WindowSet* w = nullptr;
+    int rc = get_window(plan, box, stream, &w);
+    if (rc != EFGP_OK) return rc;
+    int mode = (out_y && out_ones) ? STR_REAL_AND_ONES : (out_y ? STR_REAL : STR_ONES);
+    double2* fine = nullptr;
+    rc = spread_and_fft(plan, w, y, mode, 1, -1, stream, &fine);
+    if (rc != EFGP_OK) return rc;
+    // correction factors were built for `box`; a smaller centred box indexes them with an offset
+    auto sub = [&](const int64_t* nm, int part, void* out) -> int {
+        ModeGeom m = make_modes(plan, w, nm, 0);
+        for (int a = 0; a < plan->dim; ++a) m.fac[a] = w->d_fac[a] + (box[a] / 2 - nm[a] / 2);
+        int64_t cells = 1;
+        for (int a = 0; a < 3; ++a) cells *= w->nf[a];
+        int threads = 256;
+        int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((m.total + threads - 1) / threads, 2048));
+        hipLaunchKernelGGL(deconvolve_kernel, dim3(blocks, 1), dim3(threads), 0, stream, (const double2*)fine, cells, m,
+                           part, (double2*)out);
+        EFGP_HIP_CHECK(hipGetLastError());
+        return EFGP_OK;
+    };
+    if (mode == STR_REAL_AND_ONES) {
+        rc = sub(n_modes_y, 1, out_y);
+        if (rc != EFGP_OK) return rc;
+        return sub(n_modes_one, 2, out_ones);
+    }
+    return out_y ? sub(n_modes_y, 0, out_y) : sub(n_modes_one, 0, out_ones);
+}
+
+int efgp_nufft_type2(efgp_nufft_t* plan, const void* f, int nbatch, const int64_t* n_modes, int isign, int modeord,
+                     void* out, int real_only, void* stream_) {
+    EFGP_REQUIRE(plan && f && n_modes, "efgp_nufft_type2: null argument");
+    EFGP_REQUIRE(nbatch >= 1, "efgp_nufft_type2: nbatch must be >= 1");
+    EFGP_REQUIRE(plan->npts == 0 || out, "efgp_nufft_type2: null out");
+    for (int a = 0; a < plan->dim; ++a) EFGP_REQUIRE(n_modes[a] >= 1, "efgp_nufft_type2: n_modes[%d] < 1", a);
+    EFGP_REQUIRE(isign == 1 || isign == -1, "efgp_nufft_type2: isign must be +-1");
+    if (plan->npts == 0) return EFGP_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(plan->device);
+    DeviceCtx* ctx = plan->ctx;
+    WindowSet* w = nullptr;
+    int rc = get_window(plan, n_modes, stream, &w);
+    if (rc != EFGP_OK) return rc;
+    const GridGeom g = make_geom(plan, w);
+    double2* fine = (double2*)scratch(ctx, SLOT_FINE, (size_t)nbatch * (size_t)g.cells * sizeof(double2));
+    if (!fine) return EFGP_ENOMEM;
+    EFGP_HIP_CHECK(hipMemsetAsync(fine, 0, (size_t)nbatch * (size_t)g.cells * sizeof(double2), stream));
+    ModeGeom m = make_modes(plan, w, n_modes, modeord);
+    {
+        int threads = 256;
+        int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((m.total + threads - 1) / threads, 2048));
+        hipLaunchKernelGGL(precorrect_kernel, dim3(blocks, nbatch), dim3(threads), 0, stream, (const double2*)f, m,
+                           real_only ? 1 : 0, g.cells, fine);
+        EFGP_HIP_CHECK(hipGetLastError());
+    }
+    hipfftHandle fh;
+    rc = fft_plan(ctx, plan->dim, g.nf, nbatch, stream, &fh);
+    if (rc != EFGP_OK) return rc;
+    EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)fine, (hipfftDoubleComplex*)fine,
+                                 isign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
+    const bool cplx = !real_only;
+    const size_t lds_bytes = (size_t)g.cells * (cplx ? sizeof(double2) : sizeof(double));
+    const bool use_lds = lds_bytes <= (size_t)ctx->max_lds;
+    InterpArgs a;
+    a.x = plan->x;
+    a.npts = plan->npts;
+    a.g = g;
+    a.coef = w->d_coef;
+    a.degree = w->p.degree;
+    a.fine = fine;
+    a.out = out;
+    int64_t want = (plan->npts + kInterpThreads - 1) / kInterpThreads;
+    int nwg;
+    if (use_lds) {
+        int per_cu = std::max(1, std::min(4, (int)((size_t)ctx->max_lds / std::max<size_t>(lds_bytes, 1))));
+        // each workgroup pays one fine-grid copy into LDS: keep >= 8 waves of points per workgroup
+        int64_t cap = std::max<int64_t>(1, plan->npts / (8 * kInterpThreads));
+        nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)ctx->num_cu * per_cu, want), cap));
+    } else {
+        nwg = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->num_cu * 8, want));
+    }
+    dim3 grid(nwg, nbatch);
+    hipError_t e;
+    if (plan->dim == 1) e = launch_interp_d<1>(w->p.w, cplx, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
+    else if (plan->dim == 2) e = launch_interp_d<2>(w->p.w, cplx, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
+    else e = launch_interp_d<3>(w->p.w, cplx, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
+    if (e != hipSuccess) {
+        set_error("interp kernel launch failed: %s", hipGetErrorString(e));
+        return EFGP_EHIP;
+    }
+    return EFGP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,561 @@
+// d-dimensional Toeplitz mat-vec by circulant embedding (hipFFT/rocFFT) and the Jacobi-preconditioned
+// CG solver of the EFGP normal equations, for gfx950.
+//
+// Replaces ToeplitzND (efgpnd.py:1239-1393), create_Gv/A_mean/A_var/jacobi (efgpnd.py:1572-1631) and
+// ConjugateGradients.solve (cg.py:86-244).
+//
+// Data layout in HBM
+//   vhat   [prod F]   complex: FFT of the zero-padded Toeplitz vector, pre-divided by prod F
+//   pad    [rows][prod F] complex: zero-padded operand / FFT work buffer (library scratch)
+//   x,r,p,Ap [rows][M] complex, M = prod n; per-row scalars (rz, |b|, flags) in a small scratch array
+// The whole iteration state lives on the device; the host only launches kernels and polls a status
+// word every few iterations.  Per iteration and row: one pad+scale kernel, two batched FFTs, one
+// spectral multiply, one fused update kernel (crop, A p, <p,Ap>, x/r update, norms, p update).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+#include "es_kernel.hpp"
+
+namespace efgp {
+
+constexpr int kVecThreads = 256;
+constexpr int kCgThreads = 512;
+constexpr double kDivEps = 1e-16;   // cg.py:57
+
+struct ToepGeom {
+    int d;
+    int64_t n[3];     // block size per dimension (ns)
+    int64_t F[3];     // FFT size per dimension
+    int64_t M;        // prod n
+    int64_t Ftot;     // prod F
+};
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// index of block element `flat` (row-major over n) inside the padded FFT grid, shifted by `off` per dim
+__device__ __forceinline__ int64_t pad_index(const ToepGeom& g, int64_t flat, int64_t off_mul) {
+    int64_t idx = 0, stride = 1;
+    for (int a = g.d - 1; a >= 0; --a) {
+        int64_t ia = flat % g.n[a];
+        flat /= g.n[a];
+        idx += (ia + off_mul * (g.n[a] - 1)) * stride;
+        stride *= g.F[a];
+    }
+    return idx;
+}
+
+// pad[row][:] = 0 except the leading n-box which receives scale .* src[rows[row]]
+// (scale may be null).  One launch covers all rows: grid = (blocks, nrows).
+__global__ void pad_scale_kernel(ToepGeom g, const double2* __restrict__ src, int64_t src_stride,
+                                 const double2* __restrict__ scale, const int* __restrict__ rows,
+                                 const int* __restrict__ row_active, double2* __restrict__ pad) {
+    const int slot = blockIdx.y;
+    const int row = rows ? rows[slot] : slot;
+    if (row < 0) return;
+    if (row_active && !row_active[row]) return;
+    double2* P = pad + (int64_t)slot * g.Ftot;
+    const double2* S = src + (int64_t)row * src_stride;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < g.Ftot; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t rem = t, flat = 0;
+        bool inside = true;
+        // decompose t over F (row-major) and test against n
+        int64_t coords[3];
+        for (int a = g.d - 1; a >= 0; --a) {
+            coords[a] = rem % g.F[a];
+            rem /= g.F[a];
+            inside = inside && coords[a] < g.n[a];
+        }
+        double2 v = make_double2(0.0, 0.0);
+        if (inside) {
+            for (int a = 0; a < g.d; ++a) flat = flat * g.n[a] + coords[a];
+            v = S[flat];
+            if (scale) v = cmul(v, scale[flat]);
+        }
+        P[t] = v;
+    }
+}
+
+__global__ void spectral_mul_kernel(int64_t Ftot, const double2* __restrict__ vhat, double2* __restrict__ pad) {
+    double2* P = pad + (int64_t)blockIdx.y * Ftot;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < Ftot; t += (int64_t)gridDim.x * blockDim.x)
+        P[t] = cmul(P[t], vhat[t]);
+}
+
+// y[row][flat] = pad[row][flat index shifted by n-1]
+__global__ void crop_kernel(ToepGeom g, const double2* __restrict__ pad, double2* __restrict__ y) {
+    const int row = blockIdx.y;
+    const double2* P = pad + (int64_t)row * g.Ftot;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < g.M; t += (int64_t)gridDim.x * blockDim.x)
+        y[(int64_t)row * g.M + t] = P[pad_index(g, t, 1)];
+}
+
+// ------------------------------------------------------------------------------------------
+// CG state
+// ------------------------------------------------------------------------------------------
+struct CgRowScalars {   // one per row
+    double rz;
+    double den;        // |b| or 1
+    int active;
+    int iters;         // iterations in which this row was updated
+};
+
+struct CgArgs {
+    ToepGeom g;
+    const double2* ws;
+    const double* diag;       // may be null
+    double sigmasq;
+    int variant;              // 0 A_mean, 1 A_var
+    double tol;
+    int early_stop;
+    int batched;              // convergence-test placement (cg.py single vs batched)
+    const double2* b;
+    double2* x;
+    double2* r;
+    double2* p;
+    const double2* pad;       // inverse-FFT output, row slot = blockIdx.x
+    const int* rows;          // slot -> row (null: identity)
+    CgRowScalars* sc;
+    int* status;              // [0] = number of active rows (recomputed by host), [1] = any-change flag
+};
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    // wave reduce (64 lanes) then across waves through LDS
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    double t = 0.0;
+    const int nw = blockDim.x >> 6;
+    for (int i = 0; i < nw; ++i) t += red[i];     // same order in every thread: deterministic
+    return t;
+}
+
+// A u for block element t given the cropped Toeplitz product Tu = T(ws*u)[t]
+__device__ __forceinline__ double2 apply_A(const CgArgs& a, double2 wst, double2 Tu, double2 u) {
+    double2 g = cmul(wst, Tu);
+    if (a.variant == 0) return make_double2(g.x + a.sigmasq * u.x, g.y + a.sigmasq * u.y);
+    return make_double2(g.x / a.sigmasq + u.x, g.y / a.sigmasq + u.y);
+}
+
+// r = b - A x0, z = r/diag, p = z, rz = <r,z>, den = |b| (cg.py:94-111 / :164-186).  grid = rows.
+__global__ __launch_bounds__(kCgThreads) void cg_init_kernel(CgArgs a) {
+    __shared__ double red[kCgThreads / 64];
+    const int row = blockIdx.x;
+    const int64_t M = a.g.M;
+    const double2* P = a.pad + (int64_t)row * a.g.Ftot;
+    double rz = 0.0, bb = 0.0;
+    for (int64_t t = threadIdx.x; t < M; t += kCgThreads) {
+        const int64_t o = (int64_t)row * M + t;
+        double2 x0 = a.x[o];
+        double2 Ax = apply_A(a, a.ws[t], P[pad_index(a.g, t, 1)], x0);
+        double2 bv = a.b[o];
+        double2 rv = make_double2(bv.x - Ax.x, bv.y - Ax.y);
+        double2 zv = rv;
+        if (a.diag) {
+            zv.x = rv.x / a.diag[t];
+            zv.y = rv.y / a.diag[t];
+        }
+        a.r[o] = rv;
+        a.p[o] = zv;
+        rz += rv.x * zv.x + rv.y * zv.y;
+        bb += bv.x * bv.x + bv.y * bv.y;
+    }
+    rz = block_sum(rz, red);
+    bb = block_sum(bb, red);
+    if (threadIdx.x == 0) {
+        double bn = sqrt(bb);
+        a.sc[row].rz = rz;
+        a.sc[row].den = bn > 0.0 ? bn : 1.0;
+        a.sc[row].active = 1;
+        a.sc[row].iters = 0;
+    }
+}
+
+// one CG iteration for the row in slot blockIdx.x (cg.py:116-150 / :193-241)
+__global__ __launch_bounds__(kCgThreads) void cg_update_kernel(CgArgs a) {
+    __shared__ double red[kCgThreads / 64];
+    const int slot = blockIdx.x;
+    const int row = a.rows ? a.rows[slot] : slot;
+    if (row < 0) return;
+    CgRowScalars sc = a.sc[row];
+    if (!sc.active) return;
+    const int64_t M = a.g.M;
+    const double2* P = a.pad + (int64_t)slot * a.g.Ftot;
+    const int64_t base = (int64_t)row * M;
+    // pass 1: <p, Ap>
+    double pAp = 0.0;
+    for (int64_t t = threadIdx.x; t < M; t += kCgThreads) {
+        double2 pv = a.p[base + t];
+        double2 Ap = apply_A(a, a.ws[t], P[pad_index(a.g, t, 1)], pv);
+        pAp += pv.x * Ap.x + pv.y * Ap.y;
+    }
+    pAp = block_sum(pAp, red) + kDivEps;
+    const double alpha = sc.rz / pAp;
+    // pass 2: x += alpha p, r -= alpha Ap, |r|^2, <r, r/diag>
+    double rr = 0.0, rz_new = 0.0;
+    for (int64_t t = threadIdx.x; t < M; t += kCgThreads) {
+        double2 pv = a.p[base + t];
+        double2 Ap = apply_A(a, a.ws[t], P[pad_index(a.g, t, 1)], pv);
+        double2 xv = a.x[base + t];
+        double2 rv = a.r[base + t];
+        xv.x += alpha * pv.x;
+        xv.y += alpha * pv.y;
+        rv.x -= alpha * Ap.x;
+        rv.y -= alpha * Ap.y;
+        a.x[base + t] = xv;
+        a.r[base + t] = rv;
+        double q = rv.x * rv.x + rv.y * rv.y;
+        rr += q;
+        rz_new += a.diag ? q / a.diag[t] : q;
+    }
+    rr = block_sum(rr, red);
+    rz_new = block_sum(rz_new, red);
+    const double rnorm = sqrt(rr);
+    const bool conv = a.early_stop && ((rnorm / (sc.den + kDivEps) < a.tol) || (a.batched && rnorm < 1e-12));
+    if (!a.batched && conv) {            // cg.py:132 -- stop before touching p
+        if (threadIdx.x == 0) {
+            a.sc[row].active = 0;
+            a.sc[row].iters = sc.iters + 1;
+            atomicAdd(&a.status[1], 1);
+        }
+        return;
+    }
+    const double beta = rz_new / (sc.rz + kDivEps);
+    for (int64_t t = threadIdx.x; t < M; t += kCgThreads) {
+        double2 rv = a.r[base + t];
+        double2 pv = a.p[base + t];
+        double2 zv = rv;
+        if (a.diag) {
+            zv.x = rv.x / a.diag[t];
+            zv.y = rv.y / a.diag[t];
+        }
+        a.p[base + t] = make_double2(zv.x + beta * pv.x, zv.y + beta * pv.y);
+    }
+    if (threadIdx.x == 0) {
+        a.sc[row].rz = rz_new;
+        a.sc[row].iters = sc.iters + 1;
+        if (conv) {                      // batched: deactivate after the p update, cg.py:229-241
+            a.sc[row].active = 0;
+            atomicAdd(&a.status[1], 1);
+        }
+    }
+}
+
+__global__ void scale_kernel(double2* p, int64_t n, double s) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        p[t].x *= s;
+        p[t].y *= s;
+    }
+}
+
+__global__ void vdot_real_kernel(const double2* __restrict__ a, const double2* __restrict__ b, int64_t n,
+                                 double* __restrict__ partial) {
+    __shared__ double red[kVecThreads / 64];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double2 u = a[i], v = b[i];
+        acc += u.x * v.x + u.y * v.y;
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+}  // namespace efgp
+
+using namespace efgp;
+
+struct efgp_toeplitz_s {
+    int device = 0;
+    DeviceCtx* ctx = nullptr;
+    ToepGeom g;
+    int64_t Ls[3] = {1, 1, 1};
+    double2* vhat = nullptr;
+};
+
+namespace efgp {
+
+static dim3 grid_for(int64_t work, int rows, int threads, int cap = 1024) {
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((work + threads - 1) / threads, cap));
+    return dim3(blocks, rows);
+}
+
+// pad = FFT^-1( FFT(pad) .* vhat ) for `slots` rows
+static int circulant(efgp_toeplitz_s* op, double2* pad, int slots, hipStream_t stream) {
+    hipfftHandle fh;
+    int rc = fft_plan(op->ctx, op->g.d, op->g.F, slots, stream, &fh);
+    if (rc != EFGP_OK) return rc;
+    EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)pad, (hipfftDoubleComplex*)pad, HIPFFT_FORWARD));
+    hipLaunchKernelGGL(spectral_mul_kernel, grid_for(op->g.Ftot, slots, kVecThreads), dim3(kVecThreads), 0, stream,
+                       op->g.Ftot, (const double2*)op->vhat, pad);
+    EFGP_HIP_CHECK(hipGetLastError());
+    EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)pad, (hipfftDoubleComplex*)pad, HIPFFT_BACKWARD));
+    return EFGP_OK;
+}
+
+}  // namespace efgp
+
+extern "C" {
+
+int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const int64_t* Ls, const void* v,
+                         int force_pow2, void* stream_) {
+    EFGP_REQUIRE(op_out && Ls && v, "efgp_toeplitz_create: null argument");
+    EFGP_REQUIRE(dim >= 1 && dim <= 3, "efgp_toeplitz_create: dim must be 1, 2 or 3 (got %d)", dim);
+    for (int a = 0; a < dim; ++a) EFGP_REQUIRE(Ls[a] >= 1, "efgp_toeplitz_create: Ls[%d] < 1", a);
+    DeviceCtx* ctx = device_ctx(device);
+    if (!ctx) return EFGP_EHIP;
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(device);
+    auto* op = new efgp_toeplitz_s();
+    op->device = device;
+    op->ctx = ctx;
+    op->g.d = dim;
+    op->g.M = 1;
+    op->g.Ftot = 1;
+    for (int a = 0; a < 3; ++a) {
+        op->Ls[a] = a < dim ? Ls[a] : 1;
+        op->g.n[a] = a < dim ? (Ls[a] + 1) / 2 : 1;                       // efgpnd.py:1259
+        op->g.F[a] = a < dim ? (force_pow2 ? next_pow2(Ls[a]) : next_smooth_even(Ls[a])) : 1;   // :1269
+        op->g.M *= op->g.n[a];
+        op->g.Ftot *= op->g.F[a];
+    }
+    if (hipMalloc((void**)&op->vhat, (size_t)op->g.Ftot * sizeof(double2)) != hipSuccess) {
+        delete op;
+        set_error("efgp_toeplitz_create: hipMalloc(%lld complex) failed", (long long)op->g.Ftot);
+        return EFGP_ENOMEM;
+    }
+    // vhat = FFT(zero-padded v) / Ftot.  Reuse the pad kernel with n := L, i.e. a geometry whose block is L.
+    ToepGeom gv = op->g;
+    gv.M = 1;
+    for (int a = 0; a < 3; ++a) {
+        gv.n[a] = op->Ls[a];
+        gv.M *= gv.n[a];
+    }
+    hipLaunchKernelGGL(pad_scale_kernel, grid_for(op->g.Ftot, 1, kVecThreads), dim3(kVecThreads), 0, stream, gv,
+                       (const double2*)v, gv.M, (const double2*)nullptr, (const int*)nullptr, (const int*)nullptr,
+                       op->vhat);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        (void)hipFree(op->vhat);
+        delete op;
+        set_error("efgp_toeplitz_create: pad launch failed: %s", hipGetErrorString(e));
+        return EFGP_EHIP;
+    }
+    hipfftHandle fh;
+    int rc = fft_plan(ctx, dim, op->g.F, 1, stream, &fh);
+    if (rc == EFGP_OK && hipfftExecZ2Z(fh, (hipfftDoubleComplex*)op->vhat, (hipfftDoubleComplex*)op->vhat, HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
+        set_error("efgp_toeplitz_create: FFT of the Toeplitz vector failed");
+        rc = EFGP_EHIP;
+    }
+    if (rc != EFGP_OK) {
+        (void)hipFree(op->vhat);
+        delete op;
+        return rc;
+    }
+    // fold the 1/Ftot of the inverse transform into vhat (hipFFT transforms are unnormalised)
+    hipLaunchKernelGGL(scale_kernel, grid_for(op->g.Ftot, 1, kVecThreads), dim3(kVecThreads), 0, stream, op->vhat,
+                       op->g.Ftot, 1.0 / (double)op->g.Ftot);
+    e = hipGetLastError();
+    if (e != hipSuccess) {
+        (void)hipFree(op->vhat);
+        delete op;
+        set_error("efgp_toeplitz_create: scale launch failed: %s", hipGetErrorString(e));
+        return EFGP_EHIP;
+    }
+    *op_out = op;
+    return EFGP_OK;
+}
+
+int efgp_toeplitz_destroy(efgp_toeplitz_t* op) {
+    if (!op) return EFGP_OK;
+    DeviceGuard guard(op->device);
+    (void)hipDeviceSynchronize();
+    if (op->vhat) (void)hipFree(op->vhat);
+    delete op;
+    return EFGP_OK;
+}
+
+int efgp_toeplitz_fft_shape(efgp_toeplitz_t* op, int64_t* shape_out) {
+    EFGP_REQUIRE(op && shape_out, "efgp_toeplitz_fft_shape: null argument");
+    for (int a = 0; a < op->g.d; ++a) shape_out[a] = op->g.F[a];
+    return EFGP_OK;
+}
+
+int efgp_toeplitz_apply(efgp_toeplitz_t* op, const void* x, int nbatch, void* y, void* stream_) {
+    EFGP_REQUIRE(op && x && y, "efgp_toeplitz_apply: null argument");
+    EFGP_REQUIRE(nbatch >= 1, "efgp_toeplitz_apply: nbatch must be >= 1");
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(op->device);
+    // bound the scratch: process rows in chunks of at most ~256 MB of padded grid
+    const int64_t max_rows = std::max<int64_t>(1, (int64_t)(256ll << 20) / (op->g.Ftot * (int64_t)sizeof(double2)));
+    for (int64_t r0 = 0; r0 < nbatch; r0 += max_rows) {
+        const int rows = (int)std::min<int64_t>(max_rows, nbatch - r0);
+        double2* pad = (double2*)scratch(op->ctx, SLOT_TOEP_PAD, (size_t)rows * (size_t)op->g.Ftot * sizeof(double2));
+        if (!pad) return EFGP_ENOMEM;
+        hipLaunchKernelGGL(pad_scale_kernel, grid_for(op->g.Ftot, rows, kVecThreads), dim3(kVecThreads), 0, stream, op->g,
+                           (const double2*)x + r0 * op->g.M, op->g.M, (const double2*)nullptr, (const int*)nullptr,
+                           (const int*)nullptr, pad);
+        EFGP_HIP_CHECK(hipGetLastError());
+        int rc = circulant(op, pad, rows, stream);
+        if (rc != EFGP_OK) return rc;
+        hipLaunchKernelGGL(crop_kernel, grid_for(op->g.M, rows, kVecThreads), dim3(kVecThreads), 0, stream, op->g,
+                           (const double2*)pad, (double2*)y + r0 * op->g.M);
+        EFGP_HIP_CHECK(hipGetLastError());
+    }
+    return EFGP_OK;
+}
+
+int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
+                  const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop,
+                  int batched_semantics, int* iters_out, int* row_iters_out, void* stream_) {
+    EFGP_REQUIRE(op && ws && b && x, "efgp_cg_solve: null argument");
+    EFGP_REQUIRE(nbatch >= 1, "efgp_cg_solve: nbatch must be >= 1");
+    EFGP_REQUIRE(variant == 0 || variant == 1, "efgp_cg_solve: variant must be 0 or 1");
+    EFGP_REQUIRE(batched_semantics || nbatch == 1, "efgp_cg_solve: single-system semantics need nbatch == 1");
+    EFGP_REQUIRE(sigmasq > 0.0 || variant == 0, "efgp_cg_solve: sigmasq must be positive for A_var");
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(op->device);
+    DeviceCtx* ctx = op->ctx;
+    const ToepGeom g = op->g;
+    if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * g.M, 2000000000);
+
+    // rows are processed in groups whose padded grids fit ~512 MB of scratch
+    const int64_t group_cap = std::max<int64_t>(1, (int64_t)(512ll << 20) / (g.Ftot * (int64_t)sizeof(double2)));
+    int global_iters = 0;
+    for (int64_t r0 = 0; r0 < nbatch; r0 += group_cap) {
+        const int rows = (int)std::min<int64_t>(group_cap, nbatch - r0);
+        double2* pad = (double2*)scratch(ctx, SLOT_TOEP_PAD, (size_t)rows * (size_t)g.Ftot * sizeof(double2));
+        double2* vec = (double2*)scratch(ctx, SLOT_CG_VEC, (size_t)2 * rows * (size_t)g.M * sizeof(double2));
+        const size_t sc_bytes = (size_t)rows * sizeof(CgRowScalars) + (size_t)rows * sizeof(int) + 64;
+        char* scb = (char*)scratch(ctx, SLOT_CG_SCALARS, sc_bytes);
+        int* host = pinned_host(ctx, (size_t)rows * sizeof(CgRowScalars) + 64);
+        if (!pad || !vec || !scb || !host) return EFGP_ENOMEM;
+        CgArgs a;
+        a.g = g;
+        a.ws = (const double2*)ws;
+        a.diag = precond_diag;
+        a.sigmasq = sigmasq;
+        a.variant = variant;
+        a.tol = tol;
+        a.early_stop = early_stop;
+        a.batched = batched_semantics;
+        a.b = (const double2*)b + r0 * g.M;
+        a.x = (double2*)x + r0 * g.M;
+        a.r = vec;
+        a.p = vec + (int64_t)rows * g.M;
+        a.pad = pad;
+        a.rows = nullptr;
+        a.sc = (CgRowScalars*)scb;
+        a.status = (int*)(scb + (size_t)rows * sizeof(CgRowScalars));
+        int* d_rows = a.status + 16;
+        EFGP_HIP_CHECK(hipMemsetAsync(a.status, 0, 64, stream));
+
+        // r0 = b - A x0
+        hipLaunchKernelGGL(pad_scale_kernel, grid_for(g.Ftot, rows, kVecThreads), dim3(kVecThreads), 0, stream, g,
+                           (const double2*)a.x, g.M, a.ws, (const int*)nullptr, (const int*)nullptr, pad);
+        EFGP_HIP_CHECK(hipGetLastError());
+        int rc = circulant(op, pad, rows, stream);
+        if (rc != EFGP_OK) return rc;
+        hipLaunchKernelGGL(cg_init_kernel, dim3(rows), dim3(kCgThreads), 0, stream, a);
+        EFGP_HIP_CHECK(hipGetLastError());
+
+        // iteration loop; active rows are compacted on the host whenever the status is polled
+        std::vector<int> active_rows(rows);
+        for (int i = 0; i < rows; ++i) active_rows[i] = i;
+        int n_active = rows;
+        bool compacted = false;
+        int it = 0;
+        int last_active_it = 0;       // number of iterations in which at least one row was active
+        const int poll_every = 8;
+        std::vector<CgRowScalars> hsc(rows);
+        while (it < max_iter && n_active > 0) {
+            const int burst = std::min(poll_every, max_iter - it);
+            // FFT batch = number of slots (bucketed to a power of two to bound the number of plans)
+            int slots = n_active;
+            if (compacted) {
+                int p2 = 1;
+                while (p2 < n_active) p2 <<= 1;
+                slots = std::min(p2, rows);
+            }
+            for (int k = 0; k < burst; ++k) {
+                hipLaunchKernelGGL(pad_scale_kernel, grid_for(g.Ftot, slots, kVecThreads), dim3(kVecThreads), 0, stream, g,
+                                   (const double2*)a.p, g.M, a.ws, a.rows, (const int*)nullptr, pad);
+                EFGP_HIP_CHECK(hipGetLastError());
+                rc = circulant(op, pad, slots, stream);
+                if (rc != EFGP_OK) return rc;
+                hipLaunchKernelGGL(cg_update_kernel, dim3(slots), dim3(kCgThreads), 0, stream, a);
+                EFGP_HIP_CHECK(hipGetLastError());
+            }
+            it += burst;
+            EFGP_HIP_CHECK(hipMemcpyAsync(hsc.data(), a.sc, (size_t)rows * sizeof(CgRowScalars), hipMemcpyDeviceToHost, stream));
+            EFGP_HIP_CHECK(hipStreamSynchronize(stream));
+            int new_active = 0;
+            for (int i = 0; i < rows; ++i) {
+                if (hsc[i].active) active_rows[new_active++] = i;
+                last_active_it = std::max(last_active_it, hsc[i].iters);
+            }
+            if (new_active != n_active || !compacted) {
+                if (new_active > 0 && new_active < rows) {
+                    int p2 = 1;
+                    while (p2 < new_active) p2 <<= 1;
+                    const int nslots = std::min(p2, rows);
+                    std::vector<int> map(nslots, -1);
+                    for (int i = 0; i < new_active; ++i) map[i] = active_rows[i];
+                    std::memcpy(host, map.data(), nslots * sizeof(int));
+                    EFGP_HIP_CHECK(hipMemcpyAsync(d_rows, host, nslots * sizeof(int), hipMemcpyHostToDevice, stream));
+                    EFGP_HIP_CHECK(hipStreamSynchronize(stream));
+                    a.rows = d_rows;
+                    compacted = true;
+                }
+            }
+            n_active = new_active;
+        }
+        // iteration counts (cg.py:152 single; cg.py:193-199,243 batched: +1 for the terminating pass)
+        int group_iters;
+        if (!batched_semantics) {
+            group_iters = hsc.empty() ? 0 : hsc[0].iters;
+            if (it == 0) {   // max_iter == 0 or nothing ran
+                EFGP_HIP_CHECK(hipStreamSynchronize(stream));
+            }
+        } else {
+            group_iters = last_active_it;
+            if (n_active == 0 && last_active_it < max_iter) group_iters = last_active_it + 1;
+        }
+        if (row_iters_out)
+            for (int i = 0; i < rows; ++i) row_iters_out[r0 + i] = hsc[i].iters;
+        global_iters = std::max(global_iters, group_iters);
+    }
+    if (iters_out) *iters_out = global_iters;
+    return EFGP_OK;
+}
+
+int efgp_vdot_real(int device, const void* a, const void* b, int64_t count, double* out_host, void* stream_) {
+    EFGP_REQUIRE(out_host, "efgp_vdot_real: null out");
+    EFGP_REQUIRE(count >= 0, "efgp_vdot_real: negative count");
+    *out_host = 0.0;
+    if (count == 0) return EFGP_OK;
+    EFGP_REQUIRE(a && b, "efgp_vdot_real: null input");
+    DeviceCtx* ctx = device_ctx(device);
+    if (!ctx) return EFGP_EHIP;
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(device);
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((count + kVecThreads - 1) / kVecThreads, 1024));
+    double* partial = (double*)scratch(ctx, SLOT_MISC, (size_t)blocks * sizeof(double));
+    double* host = (double*)pinned_host(ctx, (size_t)blocks * sizeof(double));
+    if (!partial || !host) return EFGP_ENOMEM;
+    hipLaunchKernelGGL(vdot_real_kernel, dim3(blocks), dim3(kVecThreads), 0, stream, (const double2*)a, (const double2*)b,
+                       count, partial);
+    EFGP_HIP_CHECK(hipGetLastError());
+    EFGP_HIP_CHECK(hipMemcpyAsync(host, partial, (size_t)blocks * sizeof(double), hipMemcpyDeviceToHost, stream));
+    EFGP_HIP_CHECK(hipStreamSynchronize(stream));
+    double acc = 0.0;
+    for (int i = 0; i < blocks; ++i) acc += host[i];
+    *out_host = acc;
+    return EFGP_OK;
+}
+
+}  // extern "C"

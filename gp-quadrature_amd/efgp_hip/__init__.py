@@ -1,0 +1,7 @@
+"""ctypes binding of libefgp_hip.so (the HIP/gfx950 back end of the EFGP solve path).
+
+`efgp_hip.lib()` returns the loaded C-ABI library (declared in include/efgp_hip.h) and raises
+RuntimeError when it has not been built; the product path has no CPU fallback.
+"""
+from .lib import lib, library_path, EfgpError, declared_symbols  # noqa: F401
+from .ops import NufftPlan, ToeplitzOp, cg_solve, vdot_real, compute_device, require_gpu  # noqa: F401

@@ -1,0 +1,48 @@
+"""In-tree build of libefgp_hip.so for gfx950 with hipcc.
+
+The library is linked against the HIP runtime and hipFFT that ship inside the installed torch
+wheel (torch/lib), so that it shares ONE HIP runtime with the torch tensors whose device
+pointers it receives.  `-no-hip-rt` keeps hipcc from adding its own -L/opt/rocm/lib.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "csrc")
+SOURCES = ["es_kernel.cpp", "common.cpp", "nufft.hip", "toeplitz_cg.hip"]
+HEADERS = ["es_kernel.hpp", "common.hpp", os.path.join("..", "..", "include", "efgp_hip.h")]
+TARGET = os.path.join(HERE, "libefgp_hip.so")
+
+
+def _torch_lib_dir():
+    import torch
+    return os.path.join(os.path.dirname(torch.__file__), "lib")
+
+
+def needs_build():
+    if not os.path.exists(TARGET):
+        return True
+    t = os.path.getmtime(TARGET)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(p) > t for p in deps if os.path.exists(p))
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return TARGET
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    tl = _torch_lib_dir()
+    cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-munsafe-fp-atomics",
+           "-no-hip-rt", "-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + [
+           "-I/opt/rocm/include", "-L" + tl, "-lhipfft", "-lamdhip64", "-Wl,-rpath," + tl, "-o", TARGET + ".tmp"]
+    if verbose:
+        print("[efgp_hip] " + " ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    os.replace(TARGET + ".tmp", TARGET)
+    return TARGET
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(TARGET)

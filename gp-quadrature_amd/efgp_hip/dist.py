@@ -1,0 +1,79 @@
+"""Sharding of the N observation points over the GPUs of one node (one process per GPU).
+
+The EFGP solve path touches the N points only in NUFFT passes; CG works on M-sized grids.  So the
+points are partitioned into contiguous blocks, every rank runs the spread kernels on its block,
+and the small gridded partial sums (F*y: mtot^d, Toeplitz vector: (4m+1)^d, batched F*Z) plus a
+handful of N-length scalar reductions are summed with ONE all-reduce each (RCCL over xGMI when the
+backend is "nccl"; gloo in the CPU tests).  CG itself is replicated: no communication inside it.
+(The reference has no distributed code at all)
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, world_size, rank):
+    """[lo, hi) of the contiguous block of `n` points owned by `rank` (sizes differ by at most 1)."""
+    base, rem = divmod(int(n), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class PointShards:
+    """All-reduce helper bound to a process group; a no-op when world_size == 1."""
+
+    def __init__(self, group=None, enabled=None):
+        if enabled is None:
+            enabled = dist.is_available() and dist.is_initialized()
+        self.enabled = bool(enabled) and dist.is_available() and dist.is_initialized()
+        self.group = group
+        self.world_size = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+
+    @property
+    def active(self):
+        return self.enabled and self.world_size > 1
+
+    def sum_(self, t):
+        """In-place SUM all-reduce of a real or complex tensor (complex goes as interleaved reals)."""
+        if not self.active:
+            return t
+        buf = torch.view_as_real(t) if t.is_complex() else t
+        if not buf.is_contiguous():
+            tmp = buf.contiguous()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+            buf.copy_(tmp)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def sum_many_(self, tensors):
+        """One fused all-reduce for several small tensors (latency-bound messages)."""
+        if not self.active or not tensors:
+            return tensors
+        flats = [(torch.view_as_real(t) if t.is_complex() else t).reshape(-1) for t in tensors]
+        packed = torch.cat(flats)
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for t, f in zip(tensors, flats):
+            n = f.numel()
+            (torch.view_as_real(t) if t.is_complex() else t).reshape(-1).copy_(packed[off:off + n])
+            off += n
+        return tensors
+
+    def sum_scalars(self, values, device):
+        """SUM-reduce a list of Python floats; returns Python floats."""
+        if not self.active:
+            return [float(v) for v in values]
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return [float(v) for v in t.tolist()]
+
+    def minmax(self, lo, hi):
+        """Global per-dimension min / max of the point coordinates (for the domain length L)."""
+        if not self.active:
+            return lo, hi
+        lo = lo.clone()
+        hi = hi.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        return lo, hi

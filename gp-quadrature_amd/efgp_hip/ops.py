@@ -1,0 +1,194 @@
+"""Tensor-level wrappers over the C ABI: torch tensors carry the device memory and the stream,
+every computation happens in libefgp_hip.so."""
+import ctypes as C
+import os
+
+import torch
+
+from .lib import lib, check
+
+_CD = torch.complex128
+_RD = torch.float64
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("the EFGP HIP path needs an AMD GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback in this package")
+
+
+def compute_device(*tensors, device=None):
+    """Device the kernels run on: an explicit cuda device, else the device of the first cuda tensor,
+    else cuda:LOCAL_RANK (one process per GPU)."""
+    require_gpu()
+    if device is not None:
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            return torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+    for t in tensors:
+        if torch.is_tensor(t) and t.is_cuda:
+            return t.device
+    idx = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    return torch.device("cuda", idx)
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _i64(vals):
+    return (C.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+class NufftPlan:
+    """Type-1 / type-2 transforms for a fixed point set (C ABI: efgp_nufft_*)."""
+
+    def __init__(self, x, h, tol, xcen=None):
+        assert x.is_cuda and x.dtype == _RD and x.ndim == 2 and x.is_contiguous()
+        self.x = x                    # keeps the storage alive; the library does not copy
+        self.dev = x.device
+        self.npts, self.dim = x.shape
+        self.h = float(h)
+        self.tol = float(tol)
+        xc = None
+        if xcen is not None:
+            vals = [float(v) for v in xcen]
+            if any(v != 0.0 for v in vals):
+                xc = (C.c_double * self.dim)(*vals)
+        self._h = C.c_void_p()
+        check(lib().efgp_nufft_create(C.byref(self._h), self.dev.index, self.dim, self.npts, _ptr(x), xc,
+                                      self.h, self.tol), "efgp_nufft_create")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().efgp_nufft_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def type1(self, c, n_modes, modeord=0, isign=-1):
+        """c (N,) or (B,N) real or complex -> (B?, *n_modes) complex128."""
+        batched = c.ndim > 1
+        cc = c.reshape(-1, self.npts)
+        is_c = cc.is_complex()
+        cc = cc.to(device=self.dev, dtype=_CD if is_c else _RD).contiguous()
+        B = cc.shape[0]
+        out = torch.empty((B,) + tuple(int(m) for m in n_modes), dtype=_CD, device=self.dev)
+        with torch.cuda.device(self.dev):
+            check(lib().efgp_nufft_type1(self._h, _ptr(cc), int(is_c), B, _i64(n_modes), isign, int(modeord),
+                                         _ptr(out), _stream(self.dev)), "efgp_nufft_type1")
+        return out if batched else out[0]
+
+    def type1_pair(self, y, n_modes_y, n_modes_one):
+        """One pass over the points: (F* y on n_modes_y, F* 1 on n_modes_one)."""
+        yy = y.to(device=self.dev, dtype=_RD).contiguous()
+        out_y = torch.empty(tuple(int(m) for m in n_modes_y), dtype=_CD, device=self.dev)
+        out_o = torch.empty(tuple(int(m) for m in n_modes_one), dtype=_CD, device=self.dev)
+        with torch.cuda.device(self.dev):
+            check(lib().efgp_nufft_type1_pair(self._h, _ptr(yy), _i64(n_modes_y), _ptr(out_y), _i64(n_modes_one),
+                                              _ptr(out_o), _stream(self.dev)), "efgp_nufft_type1_pair")
+        return out_y, out_o
+
+    def type1_ones(self, n_modes):
+        out_o = torch.empty(tuple(int(m) for m in n_modes), dtype=_CD, device=self.dev)
+        with torch.cuda.device(self.dev):
+            check(lib().efgp_nufft_type1_pair(self._h, None, None, None, _i64(n_modes), _ptr(out_o),
+                                              _stream(self.dev)), "efgp_nufft_type1_pair")
+        return out_o
+
+    def type2(self, f, n_modes, modeord=0, real_only=False, isign=+1, batched=None):
+        """f (prod,) | (*n_modes) | (B, ...) complex -> (N,) | (B,N) complex128 (float64 if real_only)."""
+        M = 1
+        for m in n_modes:
+            M *= int(m)
+        if batched is None:
+            batched = not (f.ndim == 1 or tuple(f.shape) == tuple(int(m) for m in n_modes))
+        ff = f.reshape(-1, M).to(device=self.dev, dtype=_CD).contiguous()
+        B = ff.shape[0]
+        out = torch.empty((B, self.npts), dtype=_RD if real_only else _CD, device=self.dev)
+        with torch.cuda.device(self.dev):
+            check(lib().efgp_nufft_type2(self._h, _ptr(ff), B, _i64(n_modes), isign, int(modeord), _ptr(out),
+                                         int(bool(real_only)), _stream(self.dev)), "efgp_nufft_type2")
+        return out if batched else out[0]
+
+
+class ToeplitzOp:
+    """d-dimensional Toeplitz mat-vec (C ABI: efgp_toeplitz_*)."""
+
+    def __init__(self, v, force_pow2=True):
+        assert v.is_cuda
+        self.dev = v.device
+        self.v = v.to(_CD).contiguous()
+        self.d = self.v.ndim
+        self.Ls = list(self.v.shape)
+        self.ns = [(L + 1) // 2 for L in self.Ls]
+        self.size = 1
+        for n in self.ns:
+            self.size *= n
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.dev):
+            check(lib().efgp_toeplitz_create(C.byref(self._h), self.dev.index, self.d, _i64(self.Ls), _ptr(self.v),
+                                             int(bool(force_pow2)), _stream(self.dev)), "efgp_toeplitz_create")
+        shp = (C.c_int64 * 3)()
+        check(lib().efgp_toeplitz_fft_shape(self._h, shp), "efgp_toeplitz_fft_shape")
+        self.fft_shape = [int(shp[a]) for a in range(self.d)]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().efgp_toeplitz_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def apply(self, u):
+        """u (..., size) complex on the device -> same shape."""
+        uu = u.reshape(-1, self.size).to(device=self.dev, dtype=_CD).contiguous()
+        out = torch.empty_like(uu)
+        with torch.cuda.device(self.dev):
+            check(lib().efgp_toeplitz_apply(self._h, _ptr(uu), uu.shape[0], _ptr(out), _stream(self.dev)),
+                  "efgp_toeplitz_apply")
+        return out.reshape(u.shape)
+
+
+def cg_solve(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=True, diag=None, batched=None):
+    """Fused device CG on ws*T(ws*.) (+sigma^2 | /sigma^2 + 1).  Returns (x, iters, row_iters)."""
+    dev = op.dev
+    if batched is None:
+        batched = b.ndim > 1
+    bb = b.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous()
+    x = x0.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous().clone()
+    wsd = ws.to(device=dev, dtype=_CD).contiguous()
+    dg = diag.to(device=dev, dtype=_RD).contiguous() if diag is not None else None
+    B = bb.shape[0]
+    iters = C.c_int(0)
+    rows = (C.c_int * B)()
+    with torch.cuda.device(dev):
+        check(lib().efgp_cg_solve(op._h, _ptr(wsd), float(sigmasq), int(variant), _ptr(dg) if dg is not None else None,
+                                  _ptr(bb), _ptr(x), B, float(tol), int(max_iter) if max_iter is not None else 0,
+                                  int(bool(early_stop)), int(bool(batched)), C.byref(iters), rows, _stream(dev)),
+              "efgp_cg_solve")
+    return x.reshape(b.shape), int(iters.value), [int(r) for r in rows]
+
+
+def vdot_real(a, b):
+    """Re <a, b> = Re sum conj(a) b for complex device vectors, reduced by the HIP kernel."""
+    dev = a.device
+    aa = a.reshape(-1).to(_CD).contiguous()
+    bb = b.reshape(-1).to(device=dev, dtype=_CD).contiguous()
+    out = C.c_double(0.0)
+    with torch.cuda.device(dev):
+        check(lib().efgp_vdot_real(dev.index, _ptr(aa), _ptr(bb), aa.numel(), C.byref(out), _stream(dev)),
+              "efgp_vdot_real")
+    return float(out.value)

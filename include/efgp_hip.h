@@ -1,0 +1,129 @@
+/* efgp_hip.h -- C ABI of libefgp_hip.so, the MI355X (gfx950) back end of the EFGP solve path.
+ *
+ * The reference (danbider/gp-quadrature) has no FFI of its own: its only compiled code on this
+ * path is reached through `pytorch_finufft.functional.finufft_type1/type2` (efgpnd.py:1496-1499,
+ * 1533-1536, 1546-1549, 1679) and `torch.fft.fftn/ifftn` (efgpnd.py:1284, 1370, 1379, 1661-1663),
+ * and its Krylov loop is interpreted Python (cg.py:86-244).  The entry points below are what a
+ * binding for that path binds instead; each cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative EFGP_E* code on failure;
+ *     efgp_last_error() returns a human-readable message for the last failure on this thread.
+ *   - all data pointers are DEVICE pointers owned by the caller (e.g. torch allocations) unless a
+ *     parameter is documented "host"; the library owns only plans and workspaces and frees them in
+ *     *_destroy / efgp_release_workspaces.
+ *   - complex = interleaved double pairs (complex128); real = double.
+ *   - all work is enqueued on the hipStream_t passed as `stream` (NULL = default stream) and is
+ *     asynchronous w.r.t. the host, except where an `*_out` HOST pointer is written (documented).
+ *   - a plan is used by one host thread at a time (the reference is single-threaded Python).
+ */
+#ifndef EFGP_HIP_H_
+#define EFGP_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EFGP_OK 0
+#define EFGP_EINVAL (-1)    /* bad argument (shape, dimension, null pointer) -> Python ValueError */
+#define EFGP_EHIP (-2)      /* a HIP / hipFFT runtime call failed            -> Python RuntimeError */
+#define EFGP_ENOMEM (-3)
+#define EFGP_EUNSUPPORTED (-4)
+
+typedef struct efgp_nufft_s efgp_nufft_t;
+typedef struct efgp_toeplitz_s efgp_toeplitz_t;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int efgp_version(void);                      /* 1000*major + minor */
+const char* efgp_last_error(void);
+/* frees cached FFT plans and scratch buffers of `device` (-1: all devices) */
+int efgp_release_workspaces(int device);
+
+/* ---- spreading-window parameters (host only; no GPU needed) ------------------------------
+ * Exposed so the window selection can be unit-tested on a CPU-only machine. */
+/* width w chosen for tolerance `tol` at upsampling ratio sigma = nf/n_modes */
+int efgp_window_width(double tol, double sigma);
+/* evaluates the w window values a point at fine-grid position X (grid units) contributes:
+ * first_cell_out = ceil(X - w/2), vals_out[j] = window at cell first+j, both via the same
+ * Horner polynomials the device kernels use.  vals_out holds >= 16 doubles (host). */
+int efgp_window_eval(double tol, double sigma, double X, int64_t* first_cell_out, double* vals_out,
+                     int* w_out, double* beta_out);
+/* fine-grid size the library will use for n_modes modes at tolerance tol (per dimension) */
+int64_t efgp_fine_grid_size(int64_t n_modes, double tol);
+/* out[i] = Fourier-side correction for CMCL mode i (host array of n_modes doubles) */
+int efgp_window_deconv(double tol, int64_t nf, int64_t n_modes, double* out);
+
+/* ---- NUFFT: replaces efgpnd.py NUFFT.__init__ / type1 / type2 -------------------------------
+ * Points enter as the reference stores them, x (N,d) row-major float64; the phase is
+ * phi = 2 pi h (x - xcen) (efgpnd.py:1451).  d in {1,2,3}.  `x` must stay valid for the plan's
+ * lifetime (not copied, as in the reference).  tol = requested relative accuracy (FINUFFT `eps`). */
+int efgp_nufft_create(efgp_nufft_t** plan_out, int device, int dim, int64_t npts, const double* x,
+                      const double* xcen_host /* d doubles or NULL (=0) */, double h, double tol);
+int efgp_nufft_destroy(efgp_nufft_t* plan);
+
+/* type 1 (points -> modes), replaces pff.finufft_type1(phi, vals, out_shape, eps, isign, modeord)
+ * at efgpnd.py:1496-1499:
+ *     out[b, k] = sum_n c[b, n] exp(isign * i * k . phi_n)
+ * c: (nbatch, npts), complex if c_is_complex else real (the reference casts real y / ones / +-1
+ * probes to complex, efgpnd.py:1467-1468; the real entry avoids that traffic).
+ * out: (nbatch, prod n_modes) complex, modes per dimension in CMCL order
+ * -(n/2)..(n-1)/2 when modeord == 0, FFT order 0..,-.. when modeord == 1; last dimension fastest.
+ * n_modes: d host int64. */
+int efgp_nufft_type1(efgp_nufft_t* plan, const void* c, int c_is_complex, int nbatch,
+                     const int64_t* n_modes, int isign, int modeord, void* out, void* stream);
+
+/* Fused fit-time pass over the same points (efgpnd.py:786 and :789-790 / :1395-1421):
+ *     out_y[k]    = sum_n y_n exp(-i k . phi_n),  k in the n_modes_y   box (CMCL order)
+ *     out_ones[k] = sum_n     exp(-i k . phi_n),  k in the n_modes_one box (CMCL order)
+ * one read of x and y.  Either output may be NULL to skip it. */
+int efgp_nufft_type1_pair(efgp_nufft_t* plan, const double* y, const int64_t* n_modes_y, void* out_y,
+                          const int64_t* n_modes_one, void* out_ones, void* stream);
+
+/* type 2 (modes -> points), replaces pff.finufft_type2(phi, fk, eps, isign, modeord) at
+ * efgpnd.py:1533-1536, 1546-1549 and (modeord=1) :1679:
+ *     out[b, n] = sum_k f[b, k] exp(isign * i * k . phi_n)
+ * f: (nbatch, prod n_modes) complex; out: (nbatch, npts) complex, or real (double) holding only
+ * the real part when real_only != 0 (the reference takes .real at efgpnd.py:922 and :1679). */
+int efgp_nufft_type2(efgp_nufft_t* plan, const void* f, int nbatch, const int64_t* n_modes, int isign,
+                     int modeord, void* out, int real_only, void* stream);
+
+/* ---- Toeplitz operator: replaces efgpnd.py ToeplitzND (:1239-1393) --------------------------
+ * v: (L_1,...,L_d) complex, T[j,l] = v[j - l + (n-1)], n_a = (L_a+1)/2.  FFT length per dimension
+ * is next_pow2(L_a) when force_pow2 (efgpnd.py:1269) else the next 2^a3^b5^c size >= L_a. */
+int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const int64_t* Ls,
+                         const void* v, int force_pow2, void* stream);
+int efgp_toeplitz_destroy(efgp_toeplitz_t* op);
+/* y[b] = T x[b]; x, y (nbatch, prod n_a) complex, may alias.  (ToeplitzND.__call__, :1331-1393) */
+int efgp_toeplitz_apply(efgp_toeplitz_t* op, const void* x, int nbatch, void* y, void* stream);
+/* FFT grid shape chosen (d host int64), for inspection (ToeplitzND.fft_shape) */
+int efgp_toeplitz_fft_shape(efgp_toeplitz_t* op, int64_t* shape_out);
+
+/* ---- preconditioned CG on G = D T D: replaces cg.py ConjugateGradients.solve() for the operators
+ * of efgpnd.py:1572-1631 --------------------------------------------------------------------------
+ * variant 0 (A_mean, :1593-1600):  A u = ws * T(ws * u) + sigmasq * u
+ * variant 1 (A_var,  :1602-1609):  A u = ws * T(ws * u) / sigmasq + u
+ * ws: (M) complex (the reference keeps the real weights in complex dtype).
+ * precond_diag: (M) real Jacobi diagonal (z = r / diag, :1619-1631) or NULL for none.
+ * b: (nbatch, M) complex right-hand sides; x: (nbatch, M) complex, holds x0 on entry and the
+ * solution on exit.  batched_semantics = 0 follows cg.py:86-153 (requires nbatch == 1; convergence
+ * tested before the preconditioner), 1 follows cg.py:155-244 (per-row masks, test after the p
+ * update, extra |r| < 1e-12 exit, iteration count includes the terminating pass).
+ * max_iter <= 0 means 2*M (cg.py:59-65).  iters_out (HOST int) receives `iters_completed`;
+ * row_iters_out (HOST, nbatch ints, may be NULL) the per-row iteration counts.  The call
+ * synchronises the stream before returning. */
+int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant,
+                  const double* precond_diag, const void* b, void* x, int nbatch, double tol,
+                  int max_iter, int early_stop, int batched_semantics, int* iters_out,
+                  int* row_iters_out, void* stream);
+
+/* ---- small fused reductions used by the hyper-gradient (efgpnd.py:163, 170, 239) ------------
+ * out_host[0] = Re sum_n conj(a_n) b_n over n < count (complex inputs). Synchronises. */
+int efgp_vdot_real(int device, const void* a, const void* b, int64_t count, double* out_host,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EFGP_HIP_H_ */

@@ -1,0 +1,87 @@
+"""GPU parity: Toeplitz mat-vec and the fused CG (C ABI) vs the oracle restatement of
+ToeplitzND (efgpnd.py:1239-1393) and cg.py:86-244."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = a.detach().cpu()
+    b = b.detach().cpu()
+    return float(torch.linalg.norm((a - b).reshape(-1)) / torch.linalg.norm(b.reshape(-1)))
+
+
+def _setup(d, mtot, N=500, seed=0, h=0.4):
+    from oracle import efgp_oracle as O
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(N, d, generator=g, dtype=torch.float64) * 2 - 1
+    v = O.conv_vector(x, h, (mtot - 1) // 2)
+    return x, v, O.Toeplitz(v)
+
+
+@pytest.mark.parametrize("d,mtot", [(1, 35), (2, 23), (2, 15), (3, 7), (2, 71)])
+def test_toeplitz_apply(d, mtot):
+    from efgp_hip import ToeplitzOp
+    x, v, T = _setup(d, mtot)
+    op = ToeplitzOp(v.cuda())
+    assert op.fft_shape == T.fft_shape and op.ns == T.ns
+    g = torch.Generator().manual_seed(1)
+    u = torch.complex(torch.randn(3, T.size, generator=g, dtype=torch.float64),
+                      torch.randn(3, T.size, generator=g, dtype=torch.float64))
+    assert _rel(op.apply(u.cuda()), T(u)) < 1e-13
+    assert _rel(op.apply(u[0].cuda()), T(u[0])) < 1e-13
+
+
+@pytest.mark.parametrize("d,mtot,precond", [(1, 35, True), (2, 23, True), (2, 23, False), (3, 7, True)])
+def test_cg_single_iterate_parity(d, mtot, precond):
+    """Same iteration count and solution as the oracle CG at a moderate tolerance."""
+    from efgp_hip import ToeplitzOp, cg_solve
+    from oracle import efgp_oracle as O
+    x, v, T = _setup(d, mtot, N=800)
+    M = T.size
+    g = torch.Generator().manual_seed(2)
+    ws = torch.exp(-3.0 * torch.rand(M, generator=g, dtype=torch.float64)).to(torch.complex128)
+    sig2 = 0.3
+    b = torch.complex(torch.randn(M, generator=g, dtype=torch.float64), torch.randn(M, generator=g, dtype=torch.float64))
+    diag = O.jacobi_diag(ws, sig2, float(v.reshape(-1)[v.numel() // 2].real)) if precond else None
+    A = O.make_A_mean(ws, T, sig2)
+    xo, ito = O.cg_single(A, b, torch.zeros_like(b), 1e-8, diag=diag)
+    op = ToeplitzOp(v.cuda())
+    xg, itg, _ = cg_solve(op, ws.cuda(), sig2, 0, b.cuda(), torch.zeros_like(b).cuda(), 1e-8,
+                          diag=diag.cuda() if precond else None, batched=False)
+    # hundreds of iterations with a different FFT: the stopping test may flip one iteration late/early
+    assert abs(itg - ito) <= (0 if ito < 100 else 1 + ito // 200)
+    assert _rel(xg, xo) < 1e-7
+    # warm start from the solution: converges in one step (cg.py:94-95 residual with x0)
+    xg2, it2, _ = cg_solve(op, ws.cuda(), sig2, 0, b.cuda(), xg, 1e-6, diag=diag.cuda() if precond else None, batched=False)
+    xo2, ito2 = O.cg_single(A, b, xo, 1e-6, diag=diag)
+    assert it2 == ito2
+
+
+def test_cg_batched_mask_semantics():
+    """Per-row early stop, +1 terminating pass, A_var variant, no preconditioner (efgpnd.py:1648-1655)."""
+    from efgp_hip import ToeplitzOp, cg_solve
+    from oracle import efgp_oracle as O
+    x, v, T = _setup(2, 15, N=600)
+    M = T.size
+    g = torch.Generator().manual_seed(3)
+    ws = torch.exp(-2.0 * torch.rand(M, generator=g, dtype=torch.float64)).to(torch.complex128)
+    sig2 = 0.2
+    B = 9
+    b = torch.complex(torch.randn(B, M, generator=g, dtype=torch.float64), torch.randn(B, M, generator=g, dtype=torch.float64))
+    b[3] = 0.0                    # zero rhs: denom falls back to 1, converges at once
+    b[5] *= 1e-3
+    A = O.make_A_var(ws, T, sig2)
+    xo, ito = O.cg_batched(A, b, torch.zeros_like(b), 1e-7, max_iter=1000)
+    op = ToeplitzOp(v.cuda())
+    xg, itg, rows = cg_solve(op, ws.cuda(), sig2, 1, b.cuda(), torch.zeros_like(b).cuda(), 1e-7, max_iter=1000)
+    assert itg == ito
+    assert _rel(xg, xo) < 1e-9
+    assert rows[3] == 1
+    # iteration cap reached without convergence: count equals the cap
+    xo3, ito3 = O.cg_batched(A, b, torch.zeros_like(b), 1e-30, max_iter=7)
+    xg3, itg3, _ = cg_solve(op, ws.cuda(), sig2, 1, b.cuda(), torch.zeros_like(b).cuda(), 1e-30, max_iter=7)
+    assert itg3 == ito3 == 7
+    assert _rel(xg3, xo3) < 1e-10
