@@ -131,6 +131,43 @@ void release_ctx(int device) {
     }
 }
 
+// ---- kernel timing ------------------------------------------------------------------------
+struct TimingRec {
+    std::string name;
+    hipEvent_t start, stop;
+};
+static bool g_timing = false;
+static std::vector<TimingRec> g_recs;
+constexpr size_t kMaxTimingRecs = 1 << 16;
+
+bool timing_enabled() { return g_timing; }
+
+KernelTimer::KernelTimer(const char* name, hipStream_t s) : stream(s) {
+    if (!g_timing || g_recs.size() >= kMaxTimingRecs) return;
+    TimingRec r;
+    r.name = name;
+    if (hipEventCreate(&r.start) != hipSuccess) return;
+    if (hipEventCreate(&r.stop) != hipSuccess) {
+        (void)hipEventDestroy(r.start);
+        return;
+    }
+    (void)hipEventRecord(r.start, s);
+    g_recs.push_back(r);
+    slot = (int)g_recs.size() - 1;
+}
+
+KernelTimer::~KernelTimer() {
+    if (slot >= 0) (void)hipEventRecord(g_recs[(size_t)slot].stop, stream);
+}
+
+static void clear_timing() {
+    for (auto& r : g_recs) {
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    g_recs.clear();
+}
+
 }  // namespace efgp
 
 using namespace efgp;
@@ -143,6 +180,31 @@ const char* efgp_last_error(void) { return g_err; }
 
 int efgp_release_workspaces(int device) {
     release_ctx(device);
+    return EFGP_OK;
+}
+
+int efgp_kernel_timing(int enable) {
+    (void)hipDeviceSynchronize();
+    clear_timing();
+    g_timing = enable != 0;
+    return EFGP_OK;
+}
+
+int efgp_kernel_timing_read(const char* name, double* total_ms_out, int64_t* launches_out) {
+    EFGP_REQUIRE(name && total_ms_out && launches_out, "efgp_kernel_timing_read: null argument");
+    EFGP_HIP_CHECK(hipDeviceSynchronize());
+    double tot = 0.0;
+    int64_t cnt = 0;
+    for (auto& r : g_recs) {
+        if (r.name != name) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+            tot += ms;
+            ++cnt;
+        }
+    }
+    *total_ms_out = tot;
+    *launches_out = cnt;
     return EFGP_OK;
 }
 

@@ -78,6 +78,15 @@ int fft_plan(DeviceCtx* ctx, int rank, const int64_t* n, int64_t batch, hipStrea
 int* pinned_host(DeviceCtx* ctx, size_t bytes);
 void release_ctx(int device);
 
+// Optional HIP-event timing of selected kernels (see efgp_kernel_timing in the C ABI).
+bool timing_enabled();
+struct KernelTimer {     // RAII: records start at construction, stop at destruction, on `stream`
+    KernelTimer(const char* name, hipStream_t stream);
+    ~KernelTimer();
+    int slot = -1;
+    hipStream_t stream = nullptr;
+};
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;

@@ -623,6 +623,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     dim3 grid(nwg, nbatch);
     hipError_t e = hipSuccess;
     if (plan->npts > 0) {
+        KernelTimer timer("spread", stream);
         if (plan->dim == 1) e = launch_spread_d<1>(w->p.w, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
         else if (plan->dim == 2) e = launch_spread_d<2>(w->p.w, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
         else e = launch_spread_d<3>(w->p.w, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
@@ -814,6 +815,7 @@ int efgp_nufft_type2(efgp_nufft_t* plan, const void* f, int nbatch, const int64_
     }
     dim3 grid(nwg, nbatch);
     hipError_t e;
+    KernelTimer timer("interp", stream);
     if (plan->dim == 1) e = launch_interp_d<1>(w->p.w, cplx, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
     else if (plan->dim == 2) e = launch_interp_d<2>(w->p.w, cplx, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
     else e = launch_interp_d<3>(w->p.w, cplx, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);

@@ -253,13 +253,28 @@ __global__ void scale_kernel(double2* p, int64_t n, double s) {
     }
 }
 
-__global__ void vdot_real_kernel(const double2* __restrict__ a, const double2* __restrict__ b, int64_t n,
+template <bool AC, bool BC>
+__global__ void vdot_real_kernel(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
                                  double* __restrict__ partial) {
     __shared__ double red[kVecThreads / 64];
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        double2 u = a[i], v = b[i];
-        acc += u.x * v.x + u.y * v.y;
+        double ar, ai = 0.0, br, bi = 0.0;
+        if (AC) {
+            double2 u = reinterpret_cast<const double2*>(a)[i];
+            ar = u.x;
+            ai = u.y;
+        } else {
+            ar = a[i];
+        }
+        if (BC) {
+            double2 v = reinterpret_cast<const double2*>(b)[i];
+            br = v.x;
+            bi = v.y;
+        } else {
+            br = b[i];
+        }
+        acc += ar * br + ai * bi;
     }
     acc = block_sum(acc, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
@@ -482,6 +497,7 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
                 slots = std::min(p2, rows);
             }
             for (int k = 0; k < burst; ++k) {
+                KernelTimer timer("cg_iteration", stream);
                 hipLaunchKernelGGL(pad_scale_kernel, grid_for(g.Ftot, slots, kVecThreads), dim3(kVecThreads), 0, stream, g,
                                    (const double2*)a.p, g.M, a.ws, a.rows, (const int*)nullptr, pad);
                 EFGP_HIP_CHECK(hipGetLastError());
@@ -533,7 +549,8 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
     return EFGP_OK;
 }
 
-int efgp_vdot_real(int device, const void* a, const void* b, int64_t count, double* out_host, void* stream_) {
+int efgp_vdot_real(int device, const void* a, int a_is_complex, const void* b, int b_is_complex, int64_t count,
+                   double* out_host, void* stream_) {
     EFGP_REQUIRE(out_host, "efgp_vdot_real: null out");
     EFGP_REQUIRE(count >= 0, "efgp_vdot_real: negative count");
     *out_host = 0.0;
@@ -543,12 +560,20 @@ int efgp_vdot_real(int device, const void* a, const void* b, int64_t count, doub
     if (!ctx) return EFGP_EHIP;
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(device);
-    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((count + kVecThreads - 1) / kVecThreads, 1024));
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((count + kVecThreads - 1) / kVecThreads, 2048));
     double* partial = (double*)scratch(ctx, SLOT_MISC, (size_t)blocks * sizeof(double));
     double* host = (double*)pinned_host(ctx, (size_t)blocks * sizeof(double));
     if (!partial || !host) return EFGP_ENOMEM;
-    hipLaunchKernelGGL(vdot_real_kernel, dim3(blocks), dim3(kVecThreads), 0, stream, (const double2*)a, (const double2*)b,
-                       count, partial);
+    const double* pa = (const double*)a;
+    const double* pb = (const double*)b;
+    if (a_is_complex && b_is_complex)
+        hipLaunchKernelGGL((vdot_real_kernel<true, true>), dim3(blocks), dim3(kVecThreads), 0, stream, pa, pb, count, partial);
+    else if (a_is_complex)
+        hipLaunchKernelGGL((vdot_real_kernel<true, false>), dim3(blocks), dim3(kVecThreads), 0, stream, pa, pb, count, partial);
+    else if (b_is_complex)
+        hipLaunchKernelGGL((vdot_real_kernel<false, true>), dim3(blocks), dim3(kVecThreads), 0, stream, pa, pb, count, partial);
+    else
+        hipLaunchKernelGGL((vdot_real_kernel<false, false>), dim3(blocks), dim3(kVecThreads), 0, stream, pa, pb, count, partial);
     EFGP_HIP_CHECK(hipGetLastError());
     EFGP_HIP_CHECK(hipMemcpyAsync(host, partial, (size_t)blocks * sizeof(double), hipMemcpyDeviceToHost, stream));
     EFGP_HIP_CHECK(hipStreamSynchronize(stream));

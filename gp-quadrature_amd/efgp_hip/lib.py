@@ -35,6 +35,8 @@ _SIGNATURES = {
     "efgp_version": (_I, []),
     "efgp_last_error": (C.c_char_p, []),
     "efgp_release_workspaces": (_I, [_I]),
+    "efgp_kernel_timing": (_I, [_I]),
+    "efgp_kernel_timing_read": (_I, [C.c_char_p, C.POINTER(_D), _PI64]),
     "efgp_window_width": (_I, [_D, _D]),
     "efgp_window_eval": (_I, [_D, _D, _D, _PI64, C.POINTER(_D), C.POINTER(_I), C.POINTER(_D)]),
     "efgp_fine_grid_size": (_I64, [_I64, _D]),
@@ -49,7 +51,7 @@ _SIGNATURES = {
     "efgp_toeplitz_apply": (_I, [_VP, _VP, _I, _VP, _VP]),
     "efgp_toeplitz_fft_shape": (_I, [_VP, _PI64]),
     "efgp_cg_solve": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _VP]),
-    "efgp_vdot_real": (_I, [_I, _VP, _VP, _I64, C.POINTER(_D), _VP]),
+    "efgp_vdot_real": (_I, [_I, _VP, _I, _VP, _I, _I64, C.POINTER(_D), _VP]),
 }
 
 

@@ -183,12 +183,24 @@ def cg_solve(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=Tru
 
 
 def vdot_real(a, b):
-    """Re <a, b> = Re sum conj(a) b for complex device vectors, reduced by the HIP kernel."""
+    """Re <a, b> = Re sum conj(a) b for real or complex device vectors, reduced by the HIP kernel."""
     dev = a.device
-    aa = a.reshape(-1).to(_CD).contiguous()
-    bb = b.reshape(-1).to(device=dev, dtype=_CD).contiguous()
+    aa = a.reshape(-1).to(_CD if a.is_complex() else _RD).contiguous()
+    bb = b.reshape(-1).to(device=dev, dtype=_CD if b.is_complex() else _RD).contiguous()
     out = C.c_double(0.0)
     with torch.cuda.device(dev):
-        check(lib().efgp_vdot_real(dev.index, _ptr(aa), _ptr(bb), aa.numel(), C.byref(out), _stream(dev)),
-              "efgp_vdot_real")
+        check(lib().efgp_vdot_real(dev.index, _ptr(aa), int(aa.is_complex()), _ptr(bb), int(bb.is_complex()),
+                                   aa.numel(), C.byref(out), _stream(dev)), "efgp_vdot_real")
     return float(out.value)
+
+
+def kernel_timing(enable):
+    check(lib().efgp_kernel_timing(int(bool(enable))), "efgp_kernel_timing")
+
+
+def kernel_timing_read(name):
+    """-> (total milliseconds, launches) of the named kernel since kernel_timing(True)."""
+    ms = C.c_double(0.0)
+    n = C.c_int64(0)
+    check(lib().efgp_kernel_timing_read(name.encode(), C.byref(ms), C.byref(n)), "efgp_kernel_timing_read")
+    return float(ms.value), int(n.value)

@@ -41,6 +41,13 @@ const char* efgp_last_error(void);
 /* frees cached FFT plans and scratch buffers of `device` (-1: all devices) */
 int efgp_release_workspaces(int device);
 
+/* ---- per-kernel timing (HIP events recorded on the launch stream around selected kernels) -----
+ * enable != 0 starts recording (and clears previous records).  Names: "spread", "interp",
+ * "cg_iteration" (one pad+FFT+multiply+FFT+update group).  efgp_kernel_timing_read synchronises the
+ * device and returns the summed duration (ms) and launch count of `name` since enabling. */
+int efgp_kernel_timing(int enable);
+int efgp_kernel_timing_read(const char* name, double* total_ms_out, int64_t* launches_out);
+
 /* ---- spreading-window parameters (host only; no GPU needed) ------------------------------
  * Exposed so the window selection can be unit-tested on a CPU-only machine. */
 /* width w chosen for tolerance `tol` at upsampling ratio sigma = nf/n_modes */
@@ -118,10 +125,12 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
                   int max_iter, int early_stop, int batched_semantics, int* iters_out,
                   int* row_iters_out, void* stream);
 
-/* ---- small fused reductions used by the hyper-gradient (efgpnd.py:163, 170, 239) ------------
- * out_host[0] = Re sum_n conj(a_n) b_n over n < count (complex inputs). Synchronises. */
-int efgp_vdot_real(int device, const void* a, const void* b, int64_t count, double* out_host,
-                   void* stream);
+/* ---- N-length reductions of the hyper-gradient (efgpnd.py:163, 170, 239) ----------------------
+ * out_host[0] = Re sum_n conj(a_n) b_n over n < count; each operand is complex (interleaved) when
+ * its *_is_complex flag is set, else real.  Wavefront-shuffle + LDS reduction, deterministic order.
+ * Synchronises the stream (the result is a HOST double). */
+int efgp_vdot_real(int device, const void* a, int a_is_complex, const void* b, int b_is_complex,
+                   int64_t count, double* out_host, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,113 @@
+"""GPU parity of the whole EFGP path (through efgpnd.EFGPND -> C ABI -> HIP kernels) against golden
+vectors produced by the reference's own code (oracle/gen_golden.py).
+
+Tolerance: north_star asks posterior mean / variance within 1e-5 relative (float64).  Quantities
+that feed the solve (F*y, Toeplitz vector) are checked to the NUFFT tolerance requested here (1e-9)."""
+import numpy as np
+import pytest
+import torch
+
+from _golden import load_case, rel
+
+pytestmark = pytest.mark.gpu
+
+NOMINAL = {"c1_se1d_n5000": ("se", 0.1, 2.0, 0.1, 2.5), "c2_se2d_n100000": ("se", 0.2, 2.0, 0.2, 2.5),
+           "c3_matern52_usatemp": ("matern", 0.1, 1.0, 0.05, 2.5), "c4_se2d_hard_n100000": ("se", 0.05, 3.0, 0.2, 2.5),
+           "c5_matern32_3d_n20000": ("matern", 0.3, 1.5, 0.2, 1.5), "s1_se2d_n100": ("se", 0.5, 2.0, 0.2, 2.5),
+           "s2_matern12_1d_n200": ("matern", 0.3, 1.2, 0.1, 0.5)}
+
+
+def make_model(name, g, x, y, cg_tol, **opts):
+    from efgpnd import EFGPND
+    from kernels.squared_exponential import SquaredExponential
+    from kernels.matern import Matern
+    kind, ls, var, sig2, nu = NOMINAL[name]
+    d = x.shape[1]
+    k = SquaredExponential(dimension=d, init_lengthscale=ls, init_variance=var) if kind == "se" else \
+        Matern(dimension=d, nu=nu, init_lengthscale=ls, init_variance=var)
+    o = {"cg_tolerance": cg_tol, "mean_cg_warm_start": False}
+    o.update(opts)
+    m = EFGPND(x, y, k, sigmasq=sig2, eps=float(g["eps"]), nufft_eps=1e-9, estimate_params=False, opts=o)
+    # effective hyper-parameters equal what the reference read back
+    assert abs(k.get_hyper("lengthscale") - float(g["lengthscale"])) < 1e-15
+    assert abs(float(m.sigmasq.detach()) - float(g["sigmasq"])) < 1e-15
+    return m
+
+
+CASES = ["s1_se2d_n100", "s2_matern12_1d_n200", "c1_se1d_n5000", "c2_se2d_n100000", "c3_matern52_usatemp",
+         "c4_se2d_hard_n100000", "c5_matern32_3d_n20000"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fit_pieces_and_mean(name):
+    g, x, y = load_case(name)
+    m = make_model(name, g, x, y, 1e-12)
+    m.fit()
+    st = m._fit_state
+    assert st["mtot"] == int(g["mtot"])
+    assert abs(st["h"] - float(g["h"])) < 1e-12 * float(g["h"])
+    assert rel(st["ws"], g["ws"]) < 1e-12
+    assert rel(st["Fy"], g["Fy"]) < 5e-8
+    assert rel(st["v"], g["v"]) < 5e-8
+    # Toeplitz apply on the golden probe vector
+    tv = torch.from_numpy(g["toeplitz_in"]).cuda()
+    assert rel(m._toeplitz(tv), g["toeplitz_out"]) < 5e-8
+    # posterior mean at the golden prediction points: 1e-5 relative (north_star)
+    xn = torch.from_numpy(g["x_new"])
+    mean, var = m.predict(xn, return_variance=False)
+    assert mean.device == x.device and mean.dtype == x.dtype
+    assert torch.isnan(var).all()
+    assert rel(mean, g["mean"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["s1_se2d_n100", "s2_matern12_1d_n200", "c1_se1d_n5000", "c2_se2d_n100000",
+                                  "c3_matern52_usatemp", "c4_se2d_hard_n100000", "c5_matern32_3d_n20000"])
+def test_default_tolerance_iterations(name):
+    """CG at the reference's default tolerance 1e-4: same iteration count (+-1 for long solves)."""
+    g, x, y = load_case(name)
+    m = make_model(name, g, x, y, 1e-4)
+    m.fit()
+    it = m.last_fit_stats["mean_cg_iters"]
+    ref_it = int(g["iters_1e4"])
+    assert abs(it - ref_it) <= (0 if ref_it < 60 else 2)
+    # at the loose default tolerance the iterate moves by ~tol*cond when the stop flips by one pass
+    # (SURVEY section 7 "hard parts"); only a coarse agreement is meaningful here
+    assert rel(m._fit_state["ws"] * m._beta, torch.from_numpy(g["ws"]) * torch.from_numpy(g["beta_1e4"])) < 2e-2
+
+
+@pytest.mark.parametrize("name", ["s1_se2d_n100", "s2_matern12_1d_n200", "c1_se1d_n5000", "c2_se2d_n100000",
+                                  "c3_matern52_usatemp"])
+def test_variance_regular(name):
+    g, x, y = load_case(name)
+    m = make_model(name, g, x, y, 1e-12, max_cg_iterations=4000)
+    xn = torch.from_numpy(g["x_new"])[:16]
+    _, var = m.predict(xn, variance_method="regular")
+    assert rel(var, g["var_regular"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_variance_stochastic_with_recorded_probes(name):
+    g, x, y = load_case(name)
+    m = make_model(name, g, x, y, 1e-12, max_cg_iterations=4000)
+    xn = torch.from_numpy(g["x_new"])
+    etas = torch.from_numpy(g["etas"].astype(np.float64))
+    _, var = m.predict(xn, variance_method="stochastic", hutchinson_probes=etas.shape[0], variance_probes=etas)
+    scale = float(np.abs(g["var_stochastic"]).max())
+    assert float(np.abs(var.cpu().numpy() - g["var_stochastic"]).max()) < 1e-5 * scale
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gradient_with_recorded_probes(name):
+    """efgpnd_gradient_batched with the reference's own Rademacher draws (efgpnd.py:179-182,199-202)."""
+    g, x, y = load_case(name)
+    m = make_model(name, g, x, y, 1e-12)
+    Z = g["Z"]
+    V = torch.from_numpy(g["V"].astype(np.float64))
+    raw = m.compute_gradients(trace_samples=V.shape[0], nufft_eps=1e-9, cg_tol=1e-12, probes_Z=Z, probes_V=V)
+    pos = torch.tensor([float(g["lengthscale"]), float(g["variance"]), float(g["sigmasq"])], dtype=torch.float64)
+    grad = raw.detach().cpu() / pos
+    ref = torch.from_numpy(g["grad"])
+    # the gradient is a difference of large terms: compare against the size of the terms
+    scale = float(m.last_gradient_stats["term1"].abs().max())
+    assert float((grad - ref).abs().max()) < 1e-5 * scale
+    assert m._gp_params.raw.grad is not None

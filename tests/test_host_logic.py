@@ -1,0 +1,179 @@
+"""Host-side mirror of the reference interface: kernels, GPParams, get_xis, CG generic path,
+model construction and error behaviour.  No GPU needed."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from _golden import load_case, oracle_kernel
+from oracle import efgp_oracle as O
+
+
+def test_import_surface():
+    import efgpnd
+    for name in ["EFGPND", "efgpnd_gradient_batched", "efgp_nd", "NUFFT", "ToeplitzND",
+                 "compute_convolution_vector_vectorized_dD", "_cmplx", "create_A_mean", "create_A_var", "create_Gv",
+                 "create_jacobi_precond", "setup_operators", "setup_nufft", "get_xis", "diag_sums_nd",
+                 "nufft_var_est_nd", "compute_prediction_variance", "logdet_slq", "ConjugateGradients", "GPParams"]:
+        assert hasattr(efgpnd, name), name
+    from kernels import Kernel, Matern, SquaredExponential, GPParams  # noqa: F401
+    from kernels.squared_exponential import SquaredExponential as SE2  # noqa: F401
+    from kernels.matern import Matern as M2  # noqa: F401
+    from utils.kernels import get_xis, GetTruncationBound  # noqa: F401
+    from cg import ConjugateGradients  # noqa: F401
+
+
+def test_kernel_values_against_oracle():
+    from kernels.squared_exponential import SquaredExponential
+    from kernels.matern import Matern
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        xi = torch.tensor(np.random.default_rng(0).normal(size=(50, 2)))
+        r = torch.linspace(0, 3, 40, dtype=torch.float64)
+        for k, spec in [(SquaredExponential(dimension=2, init_lengthscale=0.3, init_variance=1.7), O.KernelSpec("se", 2, 0.3, 1.7)),
+                        (Matern(dimension=2, nu=0.5, init_lengthscale=0.3, init_variance=1.7), O.KernelSpec("matern", 2, 0.3, 1.7, 0.5)),
+                        (Matern(dimension=2, nu=1.5, init_lengthscale=0.3, init_variance=1.7), O.KernelSpec("matern", 2, 0.3, 1.7, 1.5)),
+                        (Matern(dimension=2, nu=2.5, init_lengthscale=0.3, init_variance=1.7), O.KernelSpec("matern", 2, 0.3, 1.7, 2.5))]:
+            spec.lengthscale, spec.variance = k.get_hyper("lengthscale"), k.get_hyper("variance")
+            assert np.allclose(k.kernel(r).numpy(), spec.k(r.numpy()), rtol=1e-14)
+            assert np.allclose(k.spectral_density(xi).numpy(), spec.S(xi.numpy()), rtol=1e-13)
+            assert np.allclose(k.spectral_grad(xi).numpy(), spec.dS(xi.numpy()), rtol=1e-12)
+            # spectral_grad is the derivative of spectral_density (finite differences)
+            e = 1e-6
+            l0 = k.get_hyper("lengthscale")
+            k._gp_params_ref.raw.data[0] = math.log(l0 + e)
+            S1 = k.spectral_density(xi)
+            k._gp_params_ref.raw.data[0] = math.log(l0 - e)
+            S0 = k.spectral_density(xi)
+            k._gp_params_ref.raw.data[0] = math.log(l0)
+            fd = (S1 - S0) / (2 * e)
+            assert torch.allclose(fd, k.spectral_grad(xi)[:, 0], rtol=1e-5, atol=1e-7)
+    finally:
+        torch.set_default_dtype(prev)
+
+
+def test_hyper_storage_quirks():
+    """log-space storage in the default dtype; set_hyper rounds through float32 (reference kernel.py:137)."""
+    from kernels.squared_exponential import SquaredExponential
+    k = SquaredExponential(dimension=2, init_lengthscale=0.2, init_variance=2.0)
+    assert k.num_hypers == 3 and k.hypers == ["lengthscale", "variance"]
+    assert k.get_hyper("lengthscale") == pytest.approx(0.2, rel=1e-6)
+    assert k.get_hyper("lengthscale") != 0.2            # float32 GPParams outside a float64 model
+    assert dict(k.iter_hypers())["lengthscale"] == 0.2
+    with pytest.raises(ValueError):
+        k.set_hyper("nope", 1.0)
+    with pytest.raises(ValueError):
+        k.get_hyper("nope")
+    with pytest.raises(ValueError):
+        SquaredExponential(dimension=0)
+    with pytest.raises(ValueError):
+        SquaredExponential(dimension=1, init_lengthscale=1e-9)
+    k.lengthscale = 0.14
+    assert k.lengthscale == pytest.approx(0.14, rel=1e-6)
+
+
+@pytest.mark.parametrize("name", ["s1_se2d_n100", "s2_matern12_1d_n200", "c1_se1d_n5000", "c2_se2d_n100000",
+                                  "c3_matern52_usatemp", "c4_se2d_hard_n100000", "c5_matern32_3d_n20000"])
+def test_get_xis_matches_reference(name):
+    """get_xis inside a float64 model reproduces the reference's h and mtot (golden)."""
+    from efgpnd import EFGPND
+    from kernels.squared_exponential import SquaredExponential
+    from kernels.matern import Matern
+    from utils.kernels import get_xis
+    from test_gpu_efgp_golden import NOMINAL
+    g, x, y = load_case(name)
+    kind, ls, var, sig2, nu = NOMINAL[name]
+    d = x.shape[1]
+    k = SquaredExponential(dimension=d, init_lengthscale=ls, init_variance=var) if kind == "se" else \
+        Matern(dimension=d, nu=nu, init_lengthscale=ls, init_variance=var)
+    m = EFGPND(x, y, k, sigmasq=sig2, eps=float(g["eps"]), estimate_params=False)
+    assert k.get_hyper("lengthscale") == pytest.approx(float(g["lengthscale"]), abs=1e-15)
+    assert k.get_hyper("variance") == pytest.approx(float(g["variance"]), abs=1e-15)
+    assert float(m.sigmasq.detach()) == pytest.approx(float(g["sigmasq"]), abs=1e-15)
+    L = float((x.max(0).values - x.min(0).values).max())
+    xis, h, mtot = get_xis(k, float(g["eps"]), L, use_integral=True)
+    assert mtot == int(g["mtot"])
+    assert h == pytest.approx(float(g["h"]), rel=1e-13)
+    assert np.allclose(xis.numpy(), g["xis_1d"], rtol=1e-13, atol=1e-15)
+    # generic tensor path (any object with kernel()/spectral_density()) gives the same grid
+    class Wrapped:
+        dimension = d
+        kernel = staticmethod(k.kernel)
+        spectral_density = staticmethod(k.spectral_density)
+    xis2, h2, mtot2 = get_xis(Wrapped(), float(g["eps"]), L, use_integral=True)
+    assert mtot2 == mtot and h2 == pytest.approx(h, rel=1e-12)
+
+
+def test_get_xis_heuristic_branches():
+    from kernels.squared_exponential import SquaredExponential
+    from kernels.matern import Matern
+    from utils.kernels import get_xis
+    for k in (SquaredExponential(dimension=2, init_lengthscale=0.3, init_variance=1.0),
+              Matern(dimension=1, nu=1.5, init_lengthscale=0.3, init_variance=1.0)):
+        for l2 in (False, True):
+            xis, h, mtot = get_xis(k, 1e-3, 2.0, use_integral=False, l2scaled=l2)
+            assert mtot % 2 == 1 and xis.numel() == mtot and h > 0
+            assert xis[mtot // 2].item() == 0.0
+
+
+def test_model_construction_and_errors():
+    from efgpnd import EFGPND
+    x = torch.rand(50, 2, dtype=torch.float64)
+    y = torch.rand(50, dtype=torch.float64)
+    for name, nu in [("SquaredExponential", None), ("se", None), ("SE", None), ("Matern12", 0.5), ("matern32", 1.5), ("MATERN52", 2.5)]:
+        m = EFGPND(x, y, name, eps=1e-3)
+        if nu is not None:
+            assert m.kernel.nu == nu
+        assert len(list(m.parameters())) == 1 and list(m.parameters())[0].shape == (3,)
+        assert list(m.parameters())[0].dtype == torch.float64
+    with pytest.raises(ValueError):
+        EFGPND(x, y, "Periodic")
+    m = EFGPND(x, y, "se", sigmasq=None, estimate_params=False)
+    assert float(m.sigmasq.detach()) == pytest.approx(0.1)
+    opt = torch.optim.Adam(m.parameters(), lr=0.1)
+    assert m.register_optimizer(opt) is opt and m.register_optimizer(opt) is opt
+    with pytest.raises(ValueError):
+        m.predict(None)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    """No CPU fallback: every hot entry point raises instead of silently computing elsewhere."""
+    from efgpnd import EFGPND, NUFFT, ToeplitzND, compute_convolution_vector_vectorized_dD
+    x = torch.rand(50, 2, dtype=torch.float64)
+    y = torch.rand(50, dtype=torch.float64)
+    m = EFGPND(x, y, "se", sigmasq=0.1, estimate_params=False)
+    with pytest.raises(RuntimeError, match="GPU"):
+        m.predict(x)
+    with pytest.raises(RuntimeError, match="GPU"):
+        m.compute_gradients(trace_samples=2)
+    with pytest.raises(RuntimeError, match="GPU"):
+        NUFFT(x, torch.zeros(2, dtype=torch.float64), 0.3, 1e-6)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ToeplitzND(torch.ones(5, 5, dtype=torch.complex128))
+    with pytest.raises(RuntimeError, match="GPU"):
+        compute_convolution_vector_vectorized_dD(2, x, 0.3)
+
+
+def test_generic_cg_matches_oracle():
+    """The compatibility loop for arbitrary operators follows cg.py:86-244 (checked via the oracle)."""
+    from cg import ConjugateGradients
+    g = torch.Generator().manual_seed(0)
+    n = 40
+    Q = torch.complex(torch.randn(n, n, generator=g, dtype=torch.float64), torch.randn(n, n, generator=g, dtype=torch.float64))
+    A = Q @ Q.conj().T + 0.5 * torch.eye(n, dtype=torch.complex128)
+    b = torch.complex(torch.randn(n, generator=g, dtype=torch.float64), torch.randn(n, generator=g, dtype=torch.float64))
+    diag = A.diagonal().real.clone()
+    cgs = ConjugateGradients(A, b, torch.zeros_like(b), tol=1e-10, M_inv_apply=lambda r: r / diag)
+    xs = cgs.solve()
+    xo, ito = O.cg_single(lambda v: A @ v, b, torch.zeros_like(b), 1e-10, diag=diag)
+    assert cgs.iters_completed == ito and torch.allclose(xs, xo, rtol=1e-12, atol=1e-14)
+    B = torch.stack([b, 2 * b.conj(), torch.zeros_like(b)])
+    cgb = ConjugateGradients(lambda V: V @ A.T, B, torch.zeros_like(B), tol=1e-9, max_iter=500)
+    xb = cgb.solve()
+    xob, itob = O.cg_batched(lambda V: V @ A.T, B, torch.zeros_like(B), 1e-9, max_iter=500)
+    assert cgb.iters_completed == itob and torch.allclose(xb, xob, rtol=1e-12, atol=1e-14)
+    with pytest.raises(ValueError):
+        ConjugateGradients(3.0, b, b)

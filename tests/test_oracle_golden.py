@@ -1,0 +1,73 @@
+"""The CPU oracle (oracle/efgp_oracle.py) against golden vectors produced by the REFERENCE's own code
+(oracle/gen_golden.py).  This is what pins the oracle; runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from _golden import load_case, oracle_kernel, rel
+from oracle import efgp_oracle as O
+
+SMALL = ["s1_se2d_n100", "s2_matern12_1d_n200", "c1_se1d_n5000", "c3_matern52_usatemp"]
+ALL = SMALL + ["c2_se2d_n100000", "c4_se2d_hard_n100000", "c5_matern32_3d_n20000"]
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_grid_and_weights(name):
+    g, x, y = load_case(name)
+    k = oracle_kernel(g)
+    L = float((x.max(0).values - x.min(0).values).max())
+    xis, h, mtot = O.get_xis(k, float(g["eps"]), L)
+    assert mtot == int(g["mtot"])
+    assert abs(h - float(g["h"])) <= 1e-13 * float(g["h"])
+    assert np.allclose(xis, g["xis_1d"], rtol=1e-13, atol=1e-15)
+    ws = O.feature_weights(k, xis, h)
+    assert rel(torch.from_numpy(ws).to(torch.complex128), g["ws"]) < 1e-13
+
+
+@pytest.mark.parametrize("name", SMALL + ["c2_se2d_n100000"])
+def test_fit_pieces(name):
+    g, x, y = load_case(name)
+    f = O.fit(x, y, oracle_kernel(g), float(g["sigmasq"]), float(g["eps"]), cg_tol=1e-4)
+    assert rel(f.Fy, g["Fy"]) < 1e-12
+    assert rel(f.v, g["v"]) < 1e-12
+    assert f.iters == int(g["iters_1e4"])                       # same CG, same iteration count
+    # ill-conditioned systems amplify rounding differences over 100+ iterations; beta itself is only
+    # determined to ~tol*cond, the posterior mean (test_mean_tight) is the meaningful quantity
+    assert rel(f.beta, g["beta_1e4"]) < 5e-4
+    tv = torch.from_numpy(g["toeplitz_in"])
+    assert rel(f.T(tv), g["toeplitz_out"]) < 1e-13
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_mean_tight(name):
+    g, x, y = load_case(name)
+    f = O.fit(x, y, oracle_kernel(g), float(g["sigmasq"]), float(g["eps"]), cg_tol=1e-12)
+    assert f.iters == int(g["iters_1e12"])
+    mean = O.predict_mean(f, torch.from_numpy(g["x_new"]))
+    assert rel(mean, g["mean"]) < 1e-7
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_variances(name):
+    g, x, y = load_case(name)
+    f = O.fit(x, y, oracle_kernel(g), float(g["sigmasq"]), float(g["eps"]), cg_tol=1e-12)
+    xn = torch.from_numpy(g["x_new"])
+    if "var_regular" in g:
+        vr = O.variance_regular(f, xn[:16], cg_tol=1e-12, max_iter=4000)
+        assert rel(vr, g["var_regular"]) < 1e-7
+    etas = torch.from_numpy(g["etas"].astype(np.float64))
+    c, _ = O.lag_sums(f, etas, cg_tol=1e-12, max_iter=4000)
+    assert rel(c, g["lag_sums"]) < 1e-7
+    vs = O.variance_stochastic(f, xn, etas, cg_tol=1e-12, max_iter=4000)
+    assert float(np.abs(vs.numpy() - g["var_stochastic"]).max()) < 1e-7 * float(np.abs(g["var_stochastic"]).max())
+
+
+@pytest.mark.parametrize("name", SMALL + ["c2_se2d_n100000"])
+def test_gradient(name):
+    g, x, y = load_case(name)
+    V = torch.from_numpy(g["V"].astype(np.float64))
+    grad, st = O.gradient(x, y, oracle_kernel(g), float(g["sigmasq"]), float(g["eps"]), g["Z"], V, cg_tol=1e-12)
+    assert st["mean_cg_iters"] == int(g["grad_mean_cg_iters"])
+    assert st["trace_cg_iters"] == int(g["grad_trace_cg_iters"])
+    scale = float(st["term1"].abs().max())
+    assert float((grad - torch.from_numpy(g["grad"])).abs().max()) < 1e-8 * scale
