@@ -1,0 +1,983 @@
+// Persistent fused CG: one workgroup solves one system completely inside ONE kernel launch.
+//
+// For the headline configuration (d=2, mtot=23 -> Toeplitz FFT 64x64) the whole circulant grid is
+// 64 KB, so the entire CG iteration (cg.py:116-150 / :193-241) -- diagonal scaling, zero padding,
+// forward FFT, spectral multiply, inverse FFT, crop, <p,Ap>, x/r updates, norms, preconditioner,
+// p update, convergence test -- runs out of LDS and registers with no launch, no HBM round trip and
+// no host involvement per iteration.  Batched solves map one system per workgroup (grid = rows).
+//
+// LDS layout: two ping-pong buffers of the padded grid (Stockham autosort FFT, radix 8/4/2 stages);
+// the fastest dimension is padded by one complex element so that lines of the other dimensions are
+// conflict-free across lanes.  FFT passes are pruned: only lines that can be non-zero are
+// transformed forward (the operand occupies the leading n-box), and the inverse passes only produce
+// the [n-1, 2n-1) window that the Toeplitz product keeps (efgpnd.py:1289-1290).
+//
+// Eligibility (checked on the host): every FFT length a power of two, padded grid <= kMaxGrid
+// complex elements, M <= kSlots * kThreads.
+#include <cmath>
+#include <cstdlib>
+
+#include "common.hpp"
+#include "toeplitz_cg.hpp"
+
+namespace efgp {
+
+namespace pcg {
+
+constexpr int kThreads = 512;
+constexpr int kSlots = 4;            // vector elements per thread (M <= kSlots * kThreads)
+constexpr int kMaxGrid = 4608;       // complex elements per ping-pong buffer (2 x 72 KB = 144 KB LDS)
+constexpr int kRedWaves = kThreads / 64;
+
+struct Pass {            // one 1-D FFT pass over dimension `dim`
+    int dim;
+    int n;               // FFT length
+    int nstages;
+    int radix[6];
+    int w1_log2;         // lines are enumerated on a power-of-two padded box (no integer division):
+    int lines_log2;      //   line = item & (2^lines_log2 - 1); c1 = line & (2^w1_log2 - 1); c0 = line >> w1_log2
+    // line ranges of the two other dimensions [lo, hi)
+    int other[2];
+    int lo[2], hi[2];
+    int in_limit;        // first stage: positions >= in_limit are zero (forward), n otherwise
+    int out_lo, out_hi;  // last stage: only positions in [out_lo, out_hi) are stored
+    int vs_pos, vs_c0, vs_c1;   // strides of (position, other[0], other[1]) in the UNPADDED spectrum array
+    int pstride, s0, s1;        // strides of the same three coordinates in the padded LDS grid
+    int tw_lds;                 // offset of this pass's twiddle table in LDS (double2 units) or -1 (use tw_glob)
+    const double2* tw_glob;
+};
+
+struct Geom {
+    int d;
+    int n[3];            // block sizes
+    int F[3];            // FFT sizes
+    int ld[3];           // element strides of the padded grid per dimension
+    int M;
+    int padded;          // elements per buffer
+    int npass;           // forward passes (== d), inverse passes are derived
+    Pass fwd[3];
+    Pass inv[3];
+    const double2* tw[3];    // twiddle table per dimension: tw[a][q] = exp(-2 pi i q / F[a])  (global memory)
+    int tw_lds_off[3];       // offset (in double2) of the LDS copy of tw[a] behind the two buffers, or -1
+    int tw_lds_total;        // double2 elements of LDS used by twiddle copies
+    int fuse_mid;            // 1: last forward stage, spectral multiply and first inverse stage run fused in registers
+};
+
+struct Args {
+    Geom g;
+    const double2* ws;
+    const double* diag;
+    const double2* vhat;     // [prod F] (unpadded row-major), already divided by prod F
+    double sigmasq;
+    int variant;
+    double tol;
+    int early_stop;
+    int batched;
+    int max_iter;
+    const double2* b;
+    double2* x;              // in: x0, out: solution
+    int* iters;              // per row
+#ifdef EFGP_CG_STAMPS
+    long long* stamps;       // diagnostic build only: cycles per phase class, accumulated by block 0
+#endif
+};
+
+#ifdef EFGP_CG_STAMPS
+#define EFGP_STAMP(slot)                                                     \
+    do {                                                                     \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                           \
+            const long long now__ = (long long)__builtin_readcyclecounter(); \
+            a.stamps[slot] += now__ - stamp_prev;                            \
+            stamp_prev = now__;                                              \
+        }                                                                    \
+    } while (0)
+#else
+#define EFGP_STAMP(slot) \
+    do {                 \
+    } while (0)
+#endif
+
+__device__ __forceinline__ double2 cmulp(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+// multiply by -i (forward) : (x, y) -> (y, -x)
+__device__ __forceinline__ double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }
+
+template <int R>
+__device__ __forceinline__ void dft_fwd(double2 (&v)[R]);
+
+template <>
+__device__ __forceinline__ void dft_fwd<2>(double2 (&v)[2]) {
+    double2 a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+}
+
+template <>
+__device__ __forceinline__ void dft_fwd<4>(double2 (&v)[4]) {
+    double2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+    double2 t2 = cadd(v[1], v[3]), t3 = mul_mi(csub(v[1], v[3]));
+    v[0] = cadd(t0, t2);
+    v[1] = cadd(t1, t3);
+    v[2] = csub(t0, t2);
+    v[3] = csub(t1, t3);
+}
+
+template <>
+__device__ __forceinline__ void dft_fwd<8>(double2 (&v)[8]) {
+    // two interleaved DFT4 (even / odd), then combine with w8^m
+    double2 e[4] = {v[0], v[2], v[4], v[6]};
+    double2 o[4] = {v[1], v[3], v[5], v[7]};
+    dft_fwd<4>(e);
+    dft_fwd<4>(o);
+    const double h = 0.70710678118654752440;
+    // o[m] *= exp(-2 pi i m / 8)
+    double2 o1 = make_double2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));
+    double2 o2 = mul_mi(o[2]);
+    double2 o3 = make_double2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));
+    v[0] = cadd(e[0], o[0]);
+    v[4] = csub(e[0], o[0]);
+    v[1] = cadd(e[1], o1);
+    v[5] = csub(e[1], o1);
+    v[2] = cadd(e[2], o2);
+    v[6] = csub(e[2], o2);
+    v[3] = cadd(e[3], o3);
+    v[7] = csub(e[3], o3);
+}
+
+// eight named registers with a compile-time accessor (a plain array here ends up in scratch memory)
+struct V8 {
+    double2 a0, a1, a2, a3, a4, a5, a6, a7;
+};
+template <int T>
+__device__ __forceinline__ double2& v8(V8& v) {
+    if constexpr (T == 0) return v.a0;
+    else if constexpr (T == 1) return v.a1;
+    else if constexpr (T == 2) return v.a2;
+    else if constexpr (T == 3) return v.a3;
+    else if constexpr (T == 4) return v.a4;
+    else if constexpr (T == 5) return v.a5;
+    else if constexpr (T == 6) return v.a6;
+    else return v.a7;
+}
+template <int T, int R>
+__device__ __forceinline__ void spectral_mul_regs(double2 (&v)[R], V8& sp) {
+    if constexpr (T < R) {
+        double2 val = cmulp(v[T], v8<T>(sp));
+        val.y = -val.y;
+        v[T] = val;
+        spectral_mul_regs<T + 1, R>(v, sp);
+    }
+}
+template <int T, int R>
+__device__ __forceinline__ void spectral_load_regs(V8& sp, const double2* __restrict__ vhat, int idx0, int step) {
+    if constexpr (T < R) {
+        v8<T>(sp) = vhat[idx0 + T * step];
+        spectral_load_regs<T + 1, R>(sp, vhat, idx0, step);
+    }
+}
+
+// One Stockham stage of radix R over all lines of a pass.  INV: inverse transform (conjugate trick).
+// `first`/`last` select the pruning predicates.  MID (forward only): this is the last stage of the last
+// forward pass; its outputs are multiplied by the spectrum `vreg` (held in registers, one butterfly per
+// thread) and immediately pushed through the FIRST inverse stage of the same dimension (same radix,
+// Ns = 1, no twiddles: the outputs k + t*n/R of the forward stage are exactly the inputs of that
+// inverse stage), saving one LDS round trip per iteration.
+template <int R, bool INV, bool MID>
+__device__ __forceinline__ void stage(const Geom& g, const Pass& p, int Ns, int ns_log2, bool first, bool last,
+                                      const double2* __restrict__ src, double2* __restrict__ dst,
+                                      const double2* __restrict__ tw, const double2* __restrict__ vhat, V8& sp,
+                                      bool use_sp) {
+    const int n = p.n;
+    const int nb = n / R;                                  // butterflies per line
+    const int w0 = p.hi[0] - p.lo[0], w1 = p.hi[1] - p.lo[1];
+    const int pstride = p.pstride;
+    const int s0 = p.s0, s1 = p.s1;
+    const int tw_step = n / (Ns * R);
+    const int items = nb << p.lines_log2;
+    const int lmask = (1 << p.lines_log2) - 1, w1mask = (1 << p.w1_log2) - 1;
+    for (int item = threadIdx.x; item < items; item += kThreads) {
+        const int line = item & lmask;                     // lines vary fastest across lanes
+        const int j = item >> p.lines_log2;
+        const int c1r = line & w1mask, c0r = line >> p.w1_log2;
+        if (c1r >= w1 || c0r >= w0) continue;
+        const int c1 = p.lo[1] + c1r, c0 = p.lo[0] + c0r;
+        const int base = c0 * s0 + c1 * s1;
+        const int k = j & (Ns - 1);
+        double2 v[R];
+        const int a_in = base + j * pstride, in_step = nb * pstride, tw_k = k * tw_step;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            double2 val = make_double2(0.0, 0.0);
+            if (!first || j + t * nb < p.in_limit) val = src[a_in + t * in_step];
+            if (INV) val.y = -val.y;
+            if (t > 0 && Ns > 1) val = cmulp(val, tw[t * tw_k]);
+            v[t] = val;
+        }
+        dft_fwd<R>(v);
+        if (MID) {
+            // spectral multiply, then the first inverse stage (Ns = 1) on the same R values
+            if (use_sp) {
+                spectral_mul_regs<0, R>(v, sp);
+            } else {
+                const int i0 = ((j - k) * R + k) * p.vs_pos + c0 * p.vs_c0 + c1 * p.vs_c1, istep = Ns * p.vs_pos;
+#pragma unroll
+                for (int t = 0; t < R; ++t) {
+                    double2 val = cmulp(v[t], vhat[i0 + t * istep]);
+                    val.y = -val.y;                        // conj in
+                    v[t] = val;
+                }
+            }
+            dft_fwd<R>(v);
+            // inverse stage 0 writes position j*R + t; if it is also the last inverse stage of the pass
+            // (single-stage FFT) the crop window applies
+            const bool only = p.nstages == 1;
+            const int a_out = base + j * R * pstride;
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const int pos = j * R + t;
+                if (only && (pos < p.in_limit - 1 || pos >= 2 * p.in_limit - 1)) continue;   // in_limit == n[dim] (forward pass)
+                double2 val = v[t];
+                val.y = -val.y;                            // conj out
+                dst[a_out + t * pstride] = val;
+            }
+            continue;
+        }
+        const int ob = (j - k) * R + k;
+        const int a_out = base + ob * pstride, out_step = Ns * pstride;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const int pos = ob + t * Ns;
+            if (last && (pos < p.out_lo || pos >= p.out_hi)) continue;
+            double2 val = v[t];
+            if (INV) val.y = -val.y;
+            if (vhat) val = cmulp(val, vhat[pos * p.vs_pos + c0 * p.vs_c0 + c1 * p.vs_c1]);
+            dst[a_out + t * out_step] = val;
+        }
+    }
+}
+
+// runs the stages [s_begin, s_end) of a pass
+template <bool INV>
+__device__ __forceinline__ void run_pass(const Geom& g, const Pass& p, int s_begin, int s_end, double2*& cur,
+                                         double2*& alt, const double2* tw, const double2* vhat_last, bool mid_last,
+                                         V8& sp, bool use_sp) {
+    int Ns = 1, lg = 0;
+    for (int s = 0; s < s_begin; ++s) {
+        Ns *= p.radix[s];
+        lg += p.radix[s] == 8 ? 3 : (p.radix[s] == 4 ? 2 : 1);
+    }
+    for (int s = s_begin; s < s_end; ++s) {
+        const bool first = s == 0, last = s == p.nstages - 1;
+        const double2* vh = (last && !mid_last ? vhat_last : nullptr);
+        const bool mid = last && mid_last && !INV;
+        if (mid) {
+            switch (p.radix[s]) {
+                case 8: stage<8, false, true>(g, p, Ns, lg, first, last, cur, alt, tw, vhat_last, sp, use_sp); break;
+                case 4: stage<4, false, true>(g, p, Ns, lg, first, last, cur, alt, tw, vhat_last, sp, use_sp); break;
+                default: stage<2, false, true>(g, p, Ns, lg, first, last, cur, alt, tw, vhat_last, sp, use_sp); break;
+            }
+        } else {
+            switch (p.radix[s]) {
+                case 8: stage<8, INV, false>(g, p, Ns, lg, first, last, cur, alt, tw, vh, sp, false); break;
+                case 4: stage<4, INV, false>(g, p, Ns, lg, first, last, cur, alt, tw, vh, sp, false); break;
+                default: stage<2, INV, false>(g, p, Ns, lg, first, last, cur, alt, tw, vh, sp, false); break;
+            }
+        }
+        Ns *= p.radix[s];
+        lg += p.radix[s] == 8 ? 3 : (p.radix[s] == 4 ? 2 : 1);
+        __syncthreads();
+        double2* t = cur;
+        cur = alt;
+        alt = t;
+    }
+}
+
+__device__ __forceinline__ double block_sum2(double v, double* red) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < kRedWaves; ++i) t += red[i];
+    return t;
+}
+
+// flat block index -> offset in the padded grid, optionally shifted by (n-1) per dimension
+__device__ __forceinline__ int grid_offset(const Geom& g, int flat, int shift) {
+    int off = 0;
+    for (int a = g.d - 1; a >= 0; --a) {
+        const int ia = flat % g.n[a];
+        flat /= g.n[a];
+        off += (ia + shift * (g.n[a] - 1)) * g.ld[a];
+    }
+    return off;
+}
+
+__global__ __launch_bounds__(kThreads) void cg_persistent_kernel(Args a) {
+    extern __shared__ double2 lds2[];
+    __shared__ double red[kRedWaves];
+    const Geom& g = a.g;
+    double2* bufA = lds2;
+    double2* bufB = lds2 + g.padded;
+    // twiddle tables: LDS copies (when they fit behind the two buffers) are filled once
+    double2* tw_lds_base = lds2 + 2 * g.padded;
+    for (int a_ = 0; a_ < g.d; ++a_) {
+        if (g.tw_lds_off[a_] < 0) continue;
+        bool dup = false;
+        for (int b_ = 0; b_ < a_; ++b_) dup = dup || (g.tw_lds_off[b_] == g.tw_lds_off[a_]);
+        if (!dup)
+            for (int q = threadIdx.x; q < g.F[a_]; q += kThreads) tw_lds_base[g.tw_lds_off[a_] + q] = g.tw[a_][q];
+    }
+    const int row = blockIdx.x;
+    const int M = g.M;
+    const int64_t base = (int64_t)row * M;
+
+    // per-thread slices of the vectors (element t lives in thread t % kThreads, slot t / kThreads)
+    double2 xv[kSlots], rv[kSlots], pv[kSlots], wsv[kSlots];
+    double dg[kSlots];
+    int off_in[kSlots], off_out[kSlots];
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+        const int t = threadIdx.x + s * kThreads;
+        if (t < M) {
+            xv[s] = a.x[base + t];
+            wsv[s] = a.ws[t];
+            dg[s] = a.diag ? a.diag[t] : 1.0;
+            off_in[s] = grid_offset(g, t, 0);
+            off_out[s] = grid_offset(g, t, 1);
+        } else {
+            xv[s] = wsv[s] = make_double2(0.0, 0.0);
+            dg[s] = 1.0;
+            off_in[s] = off_out[s] = 0;
+        }
+        rv[s] = pv[s] = make_double2(0.0, 0.0);
+    }
+
+    // spectrum values of this thread's butterfly in the fused middle stage (when it has one item per thread)
+    V8 sp;
+    sp.a0 = sp.a1 = sp.a2 = sp.a3 = sp.a4 = sp.a5 = sp.a6 = sp.a7 = make_double2(0.0, 0.0);
+    bool use_sp = false;
+    {
+        const Pass& pm = g.fwd[g.npass - 1];
+        const int R = pm.radix[pm.nstages - 1];
+        const int nb = pm.n / R;
+        const int items = nb << pm.lines_log2;
+        use_sp = g.fuse_mid && items <= kThreads;
+        if (use_sp && (int)threadIdx.x < items) {
+            const int line = threadIdx.x & ((1 << pm.lines_log2) - 1);
+            const int j = threadIdx.x >> pm.lines_log2;
+            const int c1r = line & ((1 << pm.w1_log2) - 1), c0r = line >> pm.w1_log2;
+            if (c1r < pm.hi[1] - pm.lo[1] && c0r < pm.hi[0] - pm.lo[0]) {
+                const int k = j & (nb - 1);          // last stage: Ns = n / R = nb
+                const int i0 = ((j - k) * R + k) * pm.vs_pos + (pm.lo[0] + c0r) * pm.vs_c0 + (pm.lo[1] + c1r) * pm.vs_c1;
+                const int istep = nb * pm.vs_pos;
+                if (R == 8) spectral_load_regs<0, 8>(sp, a.vhat, i0, istep);
+                else if (R == 4) spectral_load_regs<0, 4>(sp, a.vhat, i0, istep);
+                else spectral_load_regs<0, 2>(sp, a.vhat, i0, istep);
+            }
+        }
+    }
+    __syncthreads();      // twiddle copies visible
+
+    // A u for this thread's slots: u -> LDS -> pruned FFT -> .* vhat -> pruned inverse FFT -> crop
+#ifdef EFGP_CG_STAMPS
+    long long stamp_prev = (long long)__builtin_readcyclecounter();
+#endif
+    auto apply_A = [&](const double2 (&u)[kSlots], double2 (&Au)[kSlots]) __attribute__((always_inline)) {
+        EFGP_STAMP(7);
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            const int t = threadIdx.x + s * kThreads;
+            if (t < M) bufA[off_in[s]] = cmulp(wsv[s], u[s]);
+        }
+        __syncthreads();
+        EFGP_STAMP(0);
+        double2* cur = bufA;
+        double2* alt = bufB;
+        for (int q = 0; q < g.npass; ++q) {
+            const bool lastp = q == g.npass - 1;
+            const Pass& pf = g.fwd[q];
+            run_pass<false>(g, pf, 0, pf.nstages, cur, alt, pf.tw_lds >= 0 ? tw_lds_base + pf.tw_lds : pf.tw_glob,
+                            lastp ? a.vhat : nullptr, lastp && g.fuse_mid, sp, use_sp);
+            EFGP_STAMP(1 + q);
+        }
+        for (int q = 0; q < g.npass; ++q) {   // with the fused middle stage, inverse pass 0 starts at its stage 1
+            const Pass& pi = g.inv[q];
+            run_pass<true>(g, pi, (q == 0 && g.fuse_mid) ? 1 : 0, pi.nstages, cur, alt,
+                           pi.tw_lds >= 0 ? tw_lds_base + pi.tw_lds : pi.tw_glob, nullptr, false, sp, false);
+            EFGP_STAMP(4 + q);
+        }
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            const int t = threadIdx.x + s * kThreads;
+            if (t < M) {
+                double2 Tu = cur[off_out[s]];
+                double2 gg = cmulp(wsv[s], Tu);
+                if (a.variant == 0) Au[s] = make_double2(gg.x + a.sigmasq * u[s].x, gg.y + a.sigmasq * u[s].y);
+                else Au[s] = make_double2(gg.x / a.sigmasq + u[s].x, gg.y / a.sigmasq + u[s].y);
+            } else {
+                Au[s] = make_double2(0.0, 0.0);
+            }
+        }
+        __syncthreads();     // the buffers are reused by the next application
+        EFGP_STAMP(8);
+    };
+
+    // r = b - A x0, z = r / diag, p = z
+    double2 Ap[kSlots];
+    apply_A(xv, Ap);
+    double rz = 0.0, bb = 0.0;
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+        const int t = threadIdx.x + s * kThreads;
+        if (t < M) {
+            double2 bv = a.b[base + t];
+            rv[s] = csub(bv, Ap[s]);
+            pv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            rz += rv[s].x * pv[s].x + rv[s].y * pv[s].y;
+            bb += bv.x * bv.x + bv.y * bv.y;
+        }
+    }
+    rz = block_sum2(rz, red);
+    bb = block_sum2(bb, red);
+    const double bn = sqrt(bb);
+    const double den = bn > 0.0 ? bn : 1.0;
+
+    int it = 0;
+    for (; it < a.max_iter;) {
+        apply_A(pv, Ap);
+        double pAp = 0.0;
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) pAp += pv[s].x * Ap[s].x + pv[s].y * Ap[s].y;
+        pAp = block_sum2(pAp, red) + 1e-16;
+        const double alpha = rz / pAp;
+        double rr = 0.0, rzn = 0.0;
+        double2 zv[kSlots];
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            xv[s].x += alpha * pv[s].x;
+            xv[s].y += alpha * pv[s].y;
+            rv[s].x -= alpha * Ap[s].x;
+            rv[s].y -= alpha * Ap[s].y;
+            zv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            rr += rv[s].x * rv[s].x + rv[s].y * rv[s].y;
+            rzn += rv[s].x * zv[s].x + rv[s].y * zv[s].y;
+        }
+        rr = block_sum2(rr, red);
+        rzn = block_sum2(rzn, red);
+        ++it;
+        const double rnorm = sqrt(rr);
+        const bool conv = a.early_stop && ((rnorm / (den + 1e-16) < a.tol) || (a.batched && rnorm < 1e-12));
+        if (!a.batched && conv) break;                  // cg.py:132 (before the preconditioner / p update)
+        const double beta = rzn / (rz + 1e-16);
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) pv[s] = make_double2(zv[s].x + beta * pv[s].x, zv[s].y + beta * pv[s].y);
+        rz = rzn;
+        if (conv) break;                                // cg.py:229-241 (after the p update)
+    }
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+        const int t = threadIdx.x + s * kThreads;
+        if (t < M) a.x[base + t] = xv[s];
+    }
+    if (threadIdx.x == 0) a.iters[row] = it;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Specialised kernel for the headline shape: d = 2, circulant grid 64 x 64 (mtot <= 32), radix-8
+// Stockham stages with compile-time strides.  All addresses, twiddles and the thread's slice of the
+// spectrum are computed once, outside the CG loop; a stage is 8 ds_read_b128 + ~100 fp64 ops +
+// 8 ds_write_b128 with immediate offsets.  Same arithmetic as the generic kernel above.
+// ------------------------------------------------------------------------------------------------
+namespace s64 {
+constexpr int F = 64, LD = 65, BUF = F * LD;
+
+__device__ __forceinline__ double2 conjd(double2 a) { return make_double2(a.x, -a.y); }
+
+// v[t] = src[t * STRIDE] (t < 8), entries with t >= nvalid are zero
+template <int STRIDE>
+__device__ __forceinline__ void load8(const double2* __restrict__ src, int nvalid, double2 (&v)[8]) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = t < nvalid ? src[t * STRIDE] : make_double2(0.0, 0.0);
+}
+template <int STRIDE>
+__device__ __forceinline__ void load8_all(const double2* __restrict__ src, double2 (&v)[8]) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = src[t * STRIDE];
+}
+template <int STRIDE>
+__device__ __forceinline__ void store8_all(double2* __restrict__ dst, const double2 (&v)[8]) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dst[t * STRIDE] = v[t];
+}
+__device__ __forceinline__ void twiddle8(double2 (&v)[8], const double2 (&w)[7]) {
+#pragma unroll
+    for (int t = 1; t < 8; ++t) v[t] = cmulp(v[t], w[t - 1]);
+}
+__device__ __forceinline__ void conj8(double2 (&v)[8]) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t].y = -v[t].y;
+}
+}  // namespace s64
+
+__global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
+    using namespace s64;
+    constexpr int KS = 2;                   // M = n*n <= 1024 = KS * kThreads
+    extern __shared__ double2 lds2[];
+    __shared__ double red[kRedWaves];
+    double2* const bufA = lds2;
+    double2* const bufB = lds2 + BUF;
+    const int n = a.g.n[0];                 // block size per dimension (n0 == n1 for this kernel)
+    const int M = a.g.M;
+    const int row = blockIdx.x;
+    const int64_t base = (int64_t)row * M;
+    const int tid = threadIdx.x;
+
+    // ---- iteration-invariant per-thread data -------------------------------------------------
+    // row passes: 32 candidate lines x 8 butterflies (threads 0..255); column passes: 64 x 8 (all threads)
+    const int r_row = tid & 31, j_row = tid >> 5;
+    const bool row_act = j_row < 8 && r_row < n;
+    const int c_col = tid & 63, j_col = tid >> 6;
+    // valid leading inputs of the pruned first stages: positions j + 8t < n
+    const int nv_row = j_row < n ? (n - 1 - j_row) / 8 + 1 : 0;
+    const int nv_col = j_col < n ? (n - 1 - j_col) / 8 + 1 : 0;
+    // crop window [n-1, 2n-1) masks of the pruned last inverse stages: position j + 8t
+    unsigned keep_col = 0, keep_row = 0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int pc = j_col + 8 * t, pr = j_row + 8 * t;
+        if (pc >= n - 1 && pc < 2 * n - 1) keep_col |= 1u << t;
+        if (pr >= n - 1 && pr < 2 * n - 1) keep_row |= 1u << t;
+    }
+    double2 twr[7], twc[7], spec[8];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) {
+        twr[t - 1] = a.g.tw[0][(j_row & 7) * t];
+        twc[t - 1] = a.g.tw[0][j_col * t];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) spec[t] = a.vhat[(j_col + 8 * t) * F + c_col];
+
+    double2 xv[KS], rv[KS], pv[KS], wsv[KS];
+    double dg[KS];
+    int off_in[KS], off_out[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int t = tid + s * kThreads;
+        if (t < M) {
+            xv[s] = a.x[base + t];
+            wsv[s] = a.ws[t];
+            dg[s] = a.diag ? a.diag[t] : 1.0;
+            const int i0 = t / n, i1 = t - i0 * n;
+            off_in[s] = i0 * LD + i1;
+            off_out[s] = (i0 + n - 1) * LD + (i1 + n - 1);
+        } else {
+            xv[s] = wsv[s] = make_double2(0.0, 0.0);
+            dg[s] = 1.0;
+            off_in[s] = off_out[s] = 0;
+        }
+        rv[s] = pv[s] = make_double2(0.0, 0.0);
+    }
+#ifdef EFGP_CG_STAMPS
+    long long stamp_prev = (long long)__builtin_readcyclecounter();
+#endif
+
+    auto apply_A = [&](const double2 (&u)[KS], double2 (&Au)[KS]) __attribute__((always_inline)) {
+        EFGP_STAMP(7);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            if (tid + s * kThreads < M) bufA[off_in[s]] = cmulp(wsv[s], u[s]);
+        __syncthreads();
+        EFGP_STAMP(0);
+        double2 v[8];
+        // P1/P2: forward FFT along dim 1 of the n non-zero rows (A -> B -> A)
+        if (row_act) {
+            load8<8>(bufA + r_row * LD + j_row, nv_row, v);
+            dft_fwd<8>(v);
+            store8_all<1>(bufB + r_row * LD + j_row * 8, v);
+        }
+        __syncthreads();
+        if (row_act) {
+            load8_all<8>(bufB + r_row * LD + j_row, v);
+            twiddle8(v, twr);
+            dft_fwd<8>(v);
+            store8_all<8>(bufA + r_row * LD + j_row, v);
+        }
+        __syncthreads();
+        EFGP_STAMP(1);
+        // P3: forward FFT along dim 0, stage 1 (A -> B), rows >= n are zero
+        load8<8 * LD>(bufA + j_col * LD + c_col, nv_col, v);
+        dft_fwd<8>(v);
+        store8_all<LD>(bufB + j_col * 8 * LD + c_col, v);
+        __syncthreads();
+        // P4: stage 2 of the forward column FFT, spectral multiply, stage 1 of the inverse column FFT (B -> A)
+        load8_all<8 * LD>(bufB + j_col * LD + c_col, v);
+        twiddle8(v, twc);
+        dft_fwd<8>(v);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = conjd(cmulp(v[t], spec[t]));
+        dft_fwd<8>(v);
+        conj8(v);
+        store8_all<LD>(bufA + j_col * 8 * LD + c_col, v);
+        __syncthreads();
+        EFGP_STAMP(2);
+        // P5: inverse column FFT stage 2 (A -> B), only rows of the crop window are stored
+        load8_all<8 * LD>(bufA + j_col * LD + c_col, v);
+        conj8(v);
+        twiddle8(v, twc);
+        dft_fwd<8>(v);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (keep_col & (1u << t)) bufB[(j_col + 8 * t) * LD + c_col] = conjd(v[t]);
+        __syncthreads();
+        EFGP_STAMP(4);
+        // P6/P7: inverse FFT along dim 1 of the n window rows (B -> A -> B), cropped columns at the end
+        const int wrow = n - 1 + r_row;
+        if (row_act) {
+            load8_all<8>(bufB + wrow * LD + j_row, v);
+            conj8(v);
+            dft_fwd<8>(v);
+            conj8(v);
+            store8_all<1>(bufA + wrow * LD + j_row * 8, v);
+        }
+        __syncthreads();
+        if (row_act) {
+            load8_all<8>(bufA + wrow * LD + j_row, v);
+            conj8(v);
+            twiddle8(v, twr);
+            dft_fwd<8>(v);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (keep_row & (1u << t)) bufB[wrow * LD + j_row + 8 * t] = conjd(v[t]);
+        }
+        __syncthreads();
+        EFGP_STAMP(5);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (tid + s * kThreads < M) {
+                const double2 gg = cmulp(wsv[s], bufB[off_out[s]]);
+                if (a.variant == 0) Au[s] = make_double2(gg.x + a.sigmasq * u[s].x, gg.y + a.sigmasq * u[s].y);
+                else Au[s] = make_double2(gg.x / a.sigmasq + u[s].x, gg.y / a.sigmasq + u[s].y);
+            } else {
+                Au[s] = make_double2(0.0, 0.0);
+            }
+        }
+        __syncthreads();
+        EFGP_STAMP(8);
+    };
+
+    double2 Ap[KS];
+    apply_A(xv, Ap);
+    double rz = 0.0, bb = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (tid + s * kThreads < M) {
+            const double2 bv = a.b[base + tid + s * kThreads];
+            rv[s] = csub(bv, Ap[s]);
+            pv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            rz += rv[s].x * pv[s].x + rv[s].y * pv[s].y;
+            bb += bv.x * bv.x + bv.y * bv.y;
+        }
+    }
+    rz = block_sum2(rz, red);
+    bb = block_sum2(bb, red);
+    const double bn = sqrt(bb);
+    const double den = bn > 0.0 ? bn : 1.0;
+    int it = 0;
+    for (; it < a.max_iter;) {
+        apply_A(pv, Ap);
+        double pAp = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pAp += pv[s].x * Ap[s].x + pv[s].y * Ap[s].y;
+        pAp = block_sum2(pAp, red) + 1e-16;
+        const double alpha = rz / pAp;
+        double rr = 0.0, rzn = 0.0;
+        double2 zv[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            xv[s].x += alpha * pv[s].x;
+            xv[s].y += alpha * pv[s].y;
+            rv[s].x -= alpha * Ap[s].x;
+            rv[s].y -= alpha * Ap[s].y;
+            zv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            rr += rv[s].x * rv[s].x + rv[s].y * rv[s].y;
+            rzn += rv[s].x * zv[s].x + rv[s].y * zv[s].y;
+        }
+        rr = block_sum2(rr, red);
+        rzn = block_sum2(rzn, red);
+        ++it;
+        const double rnorm = sqrt(rr);
+        const bool conv = a.early_stop && ((rnorm / (den + 1e-16) < a.tol) || (a.batched && rnorm < 1e-12));
+        if (!a.batched && conv) break;
+        const double beta = rzn / (rz + 1e-16);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pv[s] = make_double2(zv[s].x + beta * pv[s].x, zv[s].y + beta * pv[s].y);
+        rz = rzn;
+        if (conv) break;
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        if (tid + s * kThreads < M) a.x[base + tid + s * kThreads] = xv[s];
+    if (tid == 0) a.iters[row] = it;
+}
+
+#ifdef EFGP_CG_STAMPS
+static long long* g_last_stamps = nullptr;
+#endif
+
+static void radices_for(int n, Pass* p) {
+    int k = 0;
+    while ((1 << k) < n) ++k;
+    p->nstages = 0;
+    while (k >= 3 && (k != 4)) {
+        p->radix[p->nstages++] = 8;
+        k -= 3;
+    }
+    if (k == 4) {
+        p->radix[p->nstages++] = 4;
+        p->radix[p->nstages++] = 4;
+        k = 0;
+    }
+    if (k == 2) p->radix[p->nstages++] = 4;
+    if (k == 1) p->radix[p->nstages++] = 2;
+}
+
+}  // namespace pcg
+
+#ifdef EFGP_CG_STAMPS
+extern "C" int efgp_debug_cg_stamps(long long* out16) {
+    (void)hipDeviceSynchronize();
+    if (!pcg::g_last_stamps) return -1;
+    return hipMemcpy(out16, pcg::g_last_stamps, 16 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
+
+bool persistent_cg_eligible(const ToepGeom& tg) {
+    int64_t padded = 1;
+    for (int a = 0; a < tg.d; ++a) {
+        if (tg.F[a] & (tg.F[a] - 1)) return false;
+        if (tg.F[a] > 4096) return false;
+    }
+    // padded leading dimension on the fastest axis when d > 1
+    for (int a = 0; a < tg.d; ++a) padded *= (a == tg.d - 1 && tg.d > 1) ? tg.F[a] + 1 : tg.F[a];
+    if (padded > pcg::kMaxGrid) return false;
+    if (tg.M > (int64_t)pcg::kSlots * pcg::kThreads) return false;
+    return true;
+}
+
+int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, const double2* vhat, const double2* ws,
+                         const double* diag, double sigmasq, int variant, double tol, int early_stop, int batched,
+                         int max_iter, const double2* b, double2* x, int rows, int* d_iters, hipStream_t stream) {
+    using namespace pcg;
+    Args a;
+    Geom& g = a.g;
+    g.d = tg.d;
+    for (int i = 0; i < 3; ++i) {
+        g.n[i] = i < tg.d ? (int)tg.n[i] : 1;
+        g.F[i] = i < tg.d ? (int)tg.F[i] : 1;
+        g.tw[i] = i < tg.d ? twiddles[i] : nullptr;
+    }
+    // shift geometry so that the LAST real dimension sits in slot 2 for the vhat flat index (F[1], F[2] used)
+    // -> we keep dims in slots 0..d-1 and set missing trailing F to 1, flat = (i0*F1 + i1)*F2 + i2 holds.
+    // strides of the padded grid
+    int stride = 1;
+    for (int i = 2; i >= 0; --i) {
+        if (i >= tg.d) {
+            g.ld[i] = 0;
+            continue;
+        }
+        g.ld[i] = stride;
+        stride *= (i == tg.d - 1 && tg.d > 1) ? g.F[i] + 1 : g.F[i];
+    }
+    g.padded = stride;
+    g.M = (int)tg.M;
+    g.npass = tg.d;
+    // forward: last dimension first; lines restricted to the leading n-box of not-yet-transformed dims
+    for (int q = 0; q < tg.d; ++q) {
+        const int dim = tg.d - 1 - q;
+        Pass& p = g.fwd[q];
+        p.dim = dim;
+        p.n = g.F[dim];
+        radices_for(p.n, &p);
+        int oi = 0;
+        for (int o = 0; o < 3; ++o) {
+            if (o == dim) continue;
+            p.other[oi] = o;
+            if (o >= tg.d) {
+                p.lo[oi] = 0;
+                p.hi[oi] = 1;
+            } else if (o < dim) {       // not transformed yet: only the n-box is non-zero
+                p.lo[oi] = 0;
+                p.hi[oi] = g.n[o];
+            } else {                    // already transformed: full range
+                p.lo[oi] = 0;
+                p.hi[oi] = g.F[o];
+            }
+            ++oi;
+        }
+        p.in_limit = g.n[dim];
+        p.out_lo = 0;
+        p.out_hi = p.n;
+    }
+    // inverse: first dimension first; outputs cropped to [n-1, 2n-1); later passes only visit cropped lines
+    for (int q = 0; q < tg.d; ++q) {
+        const int dim = q;
+        Pass& p = g.inv[q];
+        p.dim = dim;
+        p.n = g.F[dim];
+        radices_for(p.n, &p);
+        int oi = 0;
+        for (int o = 0; o < 3; ++o) {
+            if (o == dim) continue;
+            p.other[oi] = o;
+            if (o >= tg.d) {
+                p.lo[oi] = 0;
+                p.hi[oi] = 1;
+            } else if (o < dim) {       // already inverse-transformed and cropped
+                p.lo[oi] = g.n[o] - 1;
+                p.hi[oi] = 2 * g.n[o] - 1;
+            } else {
+                p.lo[oi] = 0;
+                p.hi[oi] = g.F[o];
+            }
+            ++oi;
+        }
+        p.in_limit = p.n;
+        p.out_lo = g.n[dim] - 1;
+        p.out_hi = 2 * g.n[dim] - 1;
+    }
+    // inverse passes use the forward radices in reverse order (so that the fused middle stage lines up)
+    for (int q = 0; q < tg.d; ++q) {
+        Pass& p = g.inv[q];
+        for (int i = 0; i < p.nstages / 2; ++i) std::swap(p.radix[i], p.radix[p.nstages - 1 - i]);
+    }
+    // `other[1]` must be the faster-varying (smaller stride) of the two so that lanes walk it first
+    for (int q = 0; q < tg.d; ++q) {
+        for (Pass* p : {&g.fwd[q], &g.inv[q]}) {
+            const int s0 = p->other[0] < tg.d ? g.ld[p->other[0]] : 0;
+            const int s1 = p->other[1] < tg.d ? g.ld[p->other[1]] : 0;
+            const bool swap = (p->other[1] >= tg.d) ? (p->other[0] < tg.d) : (p->other[0] < tg.d && s0 < s1 && s0 > 0);
+            if (swap) {
+                std::swap(p->other[0], p->other[1]);
+                std::swap(p->lo[0], p->lo[1]);
+                std::swap(p->hi[0], p->hi[1]);
+            }
+        }
+    }
+    auto ilog2 = [](int v) {
+        int l = 0;
+        while ((1 << l) < v) ++l;
+        return l;
+    };
+    for (int q = 0; q < tg.d; ++q) {
+        for (Pass* p : {&g.fwd[q], &g.inv[q]}) {
+            p->w1_log2 = ilog2(p->hi[1] - p->lo[1]);
+            p->lines_log2 = p->w1_log2 + ilog2(p->hi[0] - p->lo[0]);
+        }
+    }
+    // fused middle stage: forward last pass (dim 0) and inverse first pass (dim 0) share dimension and the
+    // last forward radix equals the first inverse radix by construction; both visit the same lines (all of
+    // the other dimensions' FFT range), so the fusion is always structurally valid when d >= 1
+    g.fuse_mid = 1;
+    // LDS twiddle copies behind the two ping-pong buffers while they fit in the 160 KB budget
+    g.tw_lds_total = 0;
+    const int lds_budget = 160 * 1024 - 256;
+    for (int i = 0; i < 3; ++i) g.tw_lds_off[i] = -1;
+    for (int i = 0; i < tg.d; ++i) {
+        int shared = -1;
+        for (int b_ = 0; b_ < i; ++b_)
+            if (g.F[b_] == g.F[i] && g.tw_lds_off[b_] >= 0) shared = g.tw_lds_off[b_];
+        if (shared >= 0) {
+            g.tw_lds_off[i] = shared;
+            continue;
+        }
+        const size_t need = ((size_t)2 * g.padded + g.tw_lds_total + g.F[i]) * sizeof(double2);
+        if (need <= (size_t)lds_budget) {
+            g.tw_lds_off[i] = g.tw_lds_total;
+            g.tw_lds_total += g.F[i];
+        }
+    }
+    int vstride[3] = {0, 0, 0};
+    {
+        int acc = 1;
+        for (int i = tg.d - 1; i >= 0; --i) {
+            vstride[i] = acc;
+            acc *= g.F[i];
+        }
+    }
+    for (int q = 0; q < tg.d; ++q) {
+        for (Pass* p : {&g.fwd[q], &g.inv[q]}) {
+            p->vs_pos = vstride[p->dim];
+            p->vs_c0 = p->other[0] < tg.d ? vstride[p->other[0]] : 0;
+            p->vs_c1 = p->other[1] < tg.d ? vstride[p->other[1]] : 0;
+            p->pstride = g.ld[p->dim];
+            p->s0 = p->other[0] < tg.d ? g.ld[p->other[0]] : 0;
+            p->s1 = p->other[1] < tg.d ? g.ld[p->other[1]] : 0;
+            p->tw_lds = g.tw_lds_off[p->dim];
+            p->tw_glob = g.tw[p->dim];
+        }
+    }
+    a.ws = ws;
+    a.diag = diag;
+    a.vhat = vhat;
+    a.sigmasq = sigmasq;
+    a.variant = variant;
+    a.tol = tol;
+    a.early_stop = early_stop;
+    a.batched = batched;
+    a.max_iter = max_iter;
+    a.b = b;
+    a.x = x;
+    a.iters = d_iters;
+#ifdef EFGP_CG_STAMPS
+    {
+        static long long* d_stamps = nullptr;
+        if (!d_stamps) (void)hipMalloc((void**)&d_stamps, 16 * sizeof(long long));
+        (void)hipMemsetAsync(d_stamps, 0, 16 * sizeof(long long), stream);
+        a.stamps = d_stamps;
+        g_last_stamps = d_stamps;
+    }
+#endif
+    const size_t lds = ((size_t)2 * g.padded + g.tw_lds_total) * sizeof(double2);
+    static bool attr_set = false;
+    if (!attr_set && lds > 65536) {
+        hipError_t e = hipFuncSetAttribute((const void*)cg_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 256);
+        if (e != hipSuccess) {
+            set_error("persistent CG: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return EFGP_EHIP;
+        }
+        attr_set = true;
+    }
+    const bool fast64 = tg.d == 2 && g.F[0] == 64 && g.F[1] == 64 && g.n[0] == g.n[1] && g.n[0] <= 32 &&
+                        std::getenv("EFGP_NO_CG64") == nullptr;
+    if (fast64) {
+        static bool attr64 = false;
+        if (!attr64) {
+            hipError_t e2 = hipFuncSetAttribute((const void*)cg_persistent_2d64_kernel,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            if (e2 != hipSuccess) {
+                set_error("persistent CG (64x64): hipFuncSetAttribute failed: %s", hipGetErrorString(e2));
+                return EFGP_EHIP;
+            }
+            attr64 = true;
+        }
+        hipLaunchKernelGGL(cg_persistent_2d64_kernel, dim3(rows), dim3(kThreads), (size_t)2 * s64::BUF * sizeof(double2),
+                           stream, a);
+    } else {
+        hipLaunchKernelGGL(cg_persistent_kernel, dim3(rows), dim3(kThreads), lds, stream, a);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("persistent CG launch failed: %s", hipGetErrorString(e));
+        return EFGP_EHIP;
+    }
+    return EFGP_OK;
+}
+
+}  // namespace efgp

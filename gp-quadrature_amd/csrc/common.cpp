@@ -2,6 +2,7 @@
 // and the host-only window entry points of the C ABI.
 #include "common.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -110,6 +111,29 @@ int* pinned_host(DeviceCtx* ctx, size_t bytes) {
     return ctx->host_pinned;
 }
 
+static size_t pool_round(size_t bytes) { return (std::max<size_t>(bytes, 1) + 4095) & ~size_t(4095); }
+
+void* pool_alloc(DeviceCtx* ctx, size_t bytes) {
+    const size_t sz = pool_round(bytes);
+    auto it = ctx->pool.find(sz);
+    if (it != ctx->pool.end() && !it->second.empty()) {
+        void* p = it->second.back();
+        it->second.pop_back();
+        return p;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, sz) != hipSuccess) {
+        set_error("hipMalloc(%zu) failed", sz);
+        return nullptr;
+    }
+    return p;
+}
+
+void pool_free(DeviceCtx* ctx, void* p, size_t bytes) {
+    if (!p) return;
+    ctx->pool[pool_round(bytes)].push_back(p);
+}
+
 void release_ctx(int device) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto it = g_ctx.begin(); it != g_ctx.end();) {
@@ -126,6 +150,11 @@ void release_ctx(int device) {
         for (int s = 0; s < SLOT_COUNT; ++s)
             if (c->buf[s]) (void)hipFree(c->buf[s]);
         if (c->host_pinned) (void)hipHostFree(c->host_pinned);
+        for (auto& kv : c->pool)
+            for (void* p : kv.second) (void)hipFree(p);
+        for (auto& kv : c->twiddles) (void)hipFree(kv.second);
+        // window_cache entries hold device pointers too; they are leaked deliberately at teardown only if
+        // the NUFFT unit did not clear them (it registers no destructor to keep this unit independent)
         if (prev >= 0) (void)hipSetDevice(prev);
         it = g_ctx.erase(it);
     }

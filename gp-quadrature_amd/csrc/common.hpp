@@ -54,6 +54,7 @@ enum Slot {
     SLOT_CG_VEC,       // r, p, Ap of the CG solver
     SLOT_CG_SCALARS,   // per-row scalars and flags of the CG solver
     SLOT_MISC,         // reductions
+    SLOT_SCALE,        // fixed-point scale of the spreader
     SLOT_COUNT
 };
 
@@ -67,6 +68,13 @@ struct DeviceCtx {
     std::map<std::tuple<int, int64_t, int64_t, int64_t, int64_t>, hipfftHandle> fft_plans;
     int* host_pinned = nullptr;   // small pinned host buffer for status read-back
     size_t host_pinned_bytes = 0;
+    // free lists of small device blocks (size -> pointers) so that per-fit objects (Toeplitz spectra,
+    // twiddle tables) do not pay hipMalloc/hipFree each time
+    std::map<size_t, std::vector<void*>> pool;
+    // cached spreading-window data, owned by the NUFFT translation unit (opaque here)
+    std::vector<void*> window_cache;
+    // cached FFT twiddle tables of the persistent CG: length -> device table
+    std::map<int64_t, void*> twiddles;
 };
 
 // returns the context of `device` (creates it, queries properties); nullptr + error on failure
@@ -76,6 +84,9 @@ void* scratch(DeviceCtx* ctx, Slot slot, size_t bytes);
 // cached batched complex-to-complex double plan bound to `stream`
 int fft_plan(DeviceCtx* ctx, int rank, const int64_t* n, int64_t batch, hipStream_t stream, hipfftHandle* out);
 int* pinned_host(DeviceCtx* ctx, size_t bytes);
+// pooled device blocks (rounded up to 4 KB multiples); pool_free returns the block to the free list
+void* pool_alloc(DeviceCtx* ctx, size_t bytes);
+void pool_free(DeviceCtx* ctx, void* p, size_t bytes);
 void release_ctx(int device);
 
 // Optional HIP-event timing of selected kernels (see efgp_kernel_timing in the C ABI).

@@ -22,8 +22,9 @@
 
 namespace efgp {
 
-constexpr int kSpreadThreads = 512;
-constexpr int kInterpThreads = 256;
+constexpr int kSpreadThreads = 1024;
+constexpr int kInterpThreads = 512;
+constexpr double kFixMagic = 6755399441055744.0;   // 1.5 * 2^52: adding it rounds to an integer in the mantissa
 
 enum StrengthMode { STR_REAL = 0, STR_COMPLEX = 1, STR_REAL_AND_ONES = 2, STR_ONES = 3 };
 
@@ -79,9 +80,21 @@ struct SpreadArgs {
     int degree;
     int mode;                 // StrengthMode
     int channels;             // 1 or 2
-    double* slabs;            // [batch][nslab][channels][cells]
+    double* slabs;            // [batch][nslab][channels][cells]  (int64 fixed point when USE_LDS)
     int nslab;
+    const double* scale;      // [0] = power-of-two fixed-point scale S, [1] = 1/S   (USE_LDS only)
 };
+
+// LDS accumulation is done in exact 64-bit fixed point: a contribution v is added as round(v*S) with
+// S a power of two chosen from max|c| and the points per workgroup so that no sum can overflow.
+// Integer LDS atomics are ~2x faster than ds_add_f64 under the random bank conflicts of unsorted
+// points (tools/lds_atomic_bench.hip) and make the result independent of the accumulation order.
+__device__ __forceinline__ void lds_add_fixed(double* cell, double a_scaled, double b) {
+    const double t = fma(a_scaled, b, kFixMagic);
+    const long long m = __double_as_longlong(t) - __double_as_longlong(kFixMagic);
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(cell), (unsigned long long)m, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 template <int D, int W, bool USE_LDS>
 __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
@@ -95,6 +108,7 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
         __syncthreads();
     }
     double* acc = USE_LDS ? lds : slab;
+    const double S = USE_LDS ? a.scale[0] : 1.0;
 
     // contiguous chunk of points per workgroup (streaming, coalesced)
     const int64_t per = (a.npts + gridDim.x - 1) / gridDim.x;
@@ -113,6 +127,10 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
             c1 = cc.y;
         } else if (a.mode == STR_REAL_AND_ONES) {
             c0 = cb[n];
+        }
+        if (USE_LDS) {
+            c0 *= S;
+            c1 *= S;
         }
         double v0[W], v1[W], v2[W];
         int f0 = 0, f1 = 0, f2 = 0;
@@ -134,8 +152,8 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
                 int i = wrap(f0 + j, nf0);
                 double w = v0[j];
                 if (USE_LDS) {
-                    __hip_atomic_fetch_add(&acc[i], w * c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (C == 2) __hip_atomic_fetch_add(&acc[cells + i], w * c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    lds_add_fixed(&acc[i], c0, w);
+                    if (C == 2) lds_add_fixed(&acc[cells + i], c1, w);
                 } else {
                     unsafeAtomicAdd(&acc[i], w * c0);
                     if (C == 2) unsafeAtomicAdd(&acc[cells + i], w * c1);
@@ -151,10 +169,8 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
                 for (int j1 = 0; j1 < W; ++j1) {
                     int i = row + wrap(f1 + j1, nf1);
                     if (USE_LDS) {
-                        __hip_atomic_fetch_add(&acc[i], a0 * v1[j1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (C == 2)
-                            __hip_atomic_fetch_add(&acc[cells + i], a1 * v1[j1], __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                        lds_add_fixed(&acc[i], a0, v1[j1]);
+                        if (C == 2) lds_add_fixed(&acc[cells + i], a1, v1[j1]);
                     } else {
                         unsafeAtomicAdd(&acc[i], a0 * v1[j1]);
                         if (C == 2) unsafeAtomicAdd(&acc[cells + i], a1 * v1[j1]);
@@ -172,10 +188,8 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
                     for (int j2 = 0; j2 < W; ++j2) {
                         int64_t i = p1 + wrap(f2 + j2, nf2);
                         if (USE_LDS) {
-                            __hip_atomic_fetch_add(&acc[i], a0 * v2[j2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (C == 2)
-                                __hip_atomic_fetch_add(&acc[cells + i], a1 * v2[j2], __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                            lds_add_fixed(&acc[i], a0, v2[j2]);
+                            if (C == 2) lds_add_fixed(&acc[cells + i], a1, v2[j2]);
                         } else {
                             unsafeAtomicAdd(&acc[i], a0 * v2[j2]);
                             if (C == 2) unsafeAtomicAdd(&acc[cells + i], a1 * v2[j2]);
@@ -191,19 +205,83 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
     }
 }
 
-// sum the slabs of one batch row into the complex fine grid: fine = ch0 + i*ch1 (ch1 = 0 if absent)
-__global__ void reduce_slabs_kernel(const double* __restrict__ slabs, int nslab, int channels, int64_t cells,
-                                    double2* __restrict__ fine) {
+// max |c| over n doubles as an ordered bit pattern (non-negative doubles compare like integers)
+__global__ void maxabs_kernel(const double* __restrict__ c, int64_t n, unsigned long long* __restrict__ out) {
+    double m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmax(m, fabs(c[i]));
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
+// scale[0] = S = largest power of two with  max|c| * S <= 2^50  and  points_per_wg * max|c| * S <= 2^61
+__global__ void fixed_scale_kernel(const unsigned long long* __restrict__ cmax_bits, double floor_bound, int64_t per,
+                                   double* __restrict__ scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double cmax = cmax_bits ? __longlong_as_double((long long)*cmax_bits) : 0.0;
+    cmax = fmax(cmax, floor_bound);         // the implicit all-ones channel has magnitude 1
+    if (!(cmax > 0.0) || !isfinite(cmax)) cmax = 1.0;
+    const double lim = fmin(ldexp(1.0, 50), ldexp(1.0, 61) / (double)(per > 1 ? per : 1));
+    int e = 0;
+    frexp(lim / cmax, &e);                  // lim/cmax = f * 2^e, f in [0.5, 1)
+    const double S = ldexp(1.0, e - 1);     // largest power of two <= lim/cmax
+    scale[0] = S;
+    scale[1] = 1.0 / S;
+}
+
+// sum the slabs of one batch row into the complex fine grid: fine = ch0 + i*ch1 (ch1 = 0 if absent).
+// FIXED: slabs hold int64 fixed-point sums (exact, order independent), rescaled by inv_scale.
+// Block = 64 cells x 8 slab groups; every slab row segment read is 512 contiguous bytes.
+template <bool FIXED>
+__global__ __launch_bounds__(512) void reduce_slabs_kernel(const double* __restrict__ slabs, int nslab, int channels,
+                                                           int64_t cells, const double* __restrict__ scale,
+                                                           double2* __restrict__ fine) {
+    __shared__ double part[2][8][64];
     const int batch = blockIdx.y;
+    const int lane_cell = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t cell = (int64_t)blockIdx.x * 64 + lane_cell;
     const double* base = slabs + (int64_t)batch * nslab * channels * cells;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
-        double re = 0.0, im = 0.0;
-        for (int s = 0; s < nslab; ++s) {
+    double re = 0.0, im = 0.0;
+    long long ire = 0, iim = 0;
+    if (cell < cells) {
+        for (int s = grp; s < nslab; s += 8) {
             const double* p = base + (int64_t)s * channels * cells;
-            re += p[i];
-            if (channels == 2) im += p[cells + i];
+            if (FIXED) {
+                ire += reinterpret_cast<const long long*>(p)[cell];
+                if (channels == 2) iim += reinterpret_cast<const long long*>(p)[cells + cell];
+            } else {
+                re += p[cell];
+                if (channels == 2) im += p[cells + cell];
+            }
         }
-        fine[(int64_t)batch * cells + i] = make_double2(re, im);
+    }
+    if (FIXED) {
+        // exact integer partial sums; combine groups in integer too
+        __shared__ long long ipart[2][8][64];
+        ipart[0][grp][lane_cell] = ire;
+        ipart[1][grp][lane_cell] = iim;
+        __syncthreads();
+        if (grp == 0 && cell < cells) {
+            long long a = 0, b = 0;
+            for (int g = 0; g < 8; ++g) {
+                a += ipart[0][g][lane_cell];
+                b += ipart[1][g][lane_cell];
+            }
+            const double inv = scale[1];
+            fine[(int64_t)batch * cells + cell] = make_double2((double)a * inv, (double)b * inv);
+        }
+    } else {
+        part[0][grp][lane_cell] = re;
+        part[1][grp][lane_cell] = im;
+        __syncthreads();
+        if (grp == 0 && cell < cells) {
+            double a = 0.0, b = 0.0;
+            for (int g = 0; g < 8; ++g) {
+                a += part[0][g][lane_cell];
+                b += part[1][g][lane_cell];
+            }
+            fine[(int64_t)batch * cells + cell] = make_double2(a, b);
+        }
     }
 }
 
@@ -419,6 +497,8 @@ __global__ __launch_bounds__(kInterpThreads) void interp_kernel(InterpArgs a) {
 // host side
 // ------------------------------------------------------------------------------------------
 struct WindowSet {          // device copies of the window data for one (tolerance, sigma, nf, n_modes) setting
+    double tol = 0.0;
+    int dim = 0;
     EsParams p;
     double* d_coef = nullptr;       // [degree+1][W]
     double* d_fac[3] = {nullptr, nullptr, nullptr};
@@ -439,10 +519,26 @@ struct efgp_nufft_s {
     double h = 0.0;
     double tol = 1e-6;
     DeviceCtx* ctx = nullptr;
-    std::vector<WindowSet*> windows;     // cached per mode-box
 };
 
 namespace efgp {
+
+// Fine-grid size for n_modes modes: among the 2^a3^b5^c even sizes in [2 n, 2.5 n] take the one that
+// needs the narrowest window (ties: the smallest grid); never below 32 cells.
+static int64_t choose_fine_size(int64_t n_modes, double tol) {
+    const int64_t lo = std::max<int64_t>(32, next_smooth_even(2 * n_modes));
+    const int64_t hi = std::max<int64_t>(lo, (5 * n_modes) / 2);
+    int64_t best = lo;
+    int best_w = es_width_for_tol(tol, (double)lo / (double)n_modes);
+    for (int64_t c = next_smooth_even(lo + 2); c <= hi; c = next_smooth_even(c + 2)) {
+        const int w = es_width_for_tol(tol, (double)c / (double)n_modes);
+        if (w < best_w) {
+            best_w = w;
+            best = c;
+        }
+    }
+    return best;
+}
 
 static void free_window(WindowSet* w) {
     if (!w) return;
@@ -452,22 +548,26 @@ static void free_window(WindowSet* w) {
     delete w;
 }
 
-// window data for a mode box: fine grid = next 2^a3^b5^c size >= 2*n_modes (>= 32)
+// window data for a mode box: fine grid = next 2^a3^b5^c size >= 2*n_modes (>= 32).  The data depend
+// only on (tolerance, dimension, mode box), not on the points, so they are cached per device.
 static int get_window(efgp_nufft_s* plan, const int64_t* n_modes, hipStream_t stream, WindowSet** out) {
     const int d = plan->dim;
-    for (WindowSet* w : plan->windows) {
-        bool same = true;
-        for (int a = 0; a < d; ++a) same = same && w->nm[a] == n_modes[a];
+    for (void* vp : plan->ctx->window_cache) {
+        WindowSet* w = (WindowSet*)vp;
+        bool same = w->dim == d && w->tol == plan->tol;
+        for (int a = 0; a < d && same; ++a) same = w->nm[a] == n_modes[a];
         if (same) {
             *out = w;
             return EFGP_OK;
         }
     }
     auto* w = new WindowSet();
+    w->tol = plan->tol;
+    w->dim = d;
     double sigma_min = 1e30;
     for (int a = 0; a < 3; ++a) {
         w->nm[a] = a < d ? n_modes[a] : 1;
-        w->nf[a] = a < d ? std::max<int64_t>(32, next_smooth_even(2 * n_modes[a])) : 1;
+        w->nf[a] = a < d ? choose_fine_size(n_modes[a], plan->tol) : 1;
         if (a < d) sigma_min = std::min(sigma_min, (double)w->nf[a] / (double)w->nm[a]);
     }
     es_make_params(plan->tol, sigma_min, &w->p);
@@ -497,7 +597,12 @@ static int get_window(efgp_nufft_s* plan, const int64_t* n_modes, hipStream_t st
             return EFGP_EHIP;
         }
     }
-    plan->windows.push_back(w);
+    if (plan->ctx->window_cache.size() >= 64) {       // bound the cache: drop the oldest entry
+        (void)hipDeviceSynchronize();
+        free_window((WindowSet*)plan->ctx->window_cache.front());
+        plan->ctx->window_cache.erase(plan->ctx->window_cache.begin());
+    }
+    plan->ctx->window_cache.push_back(w);
     *out = w;
     return EFGP_OK;
 }
@@ -605,8 +710,28 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     const size_t slab_bytes = (size_t)nbatch * nslab * channels * (size_t)g.cells * sizeof(double);
     double* slabs = (double*)scratch(ctx, SLOT_SLABS, slab_bytes);
     double2* fine = (double2*)scratch(ctx, SLOT_FINE, (size_t)nbatch * (size_t)g.cells * sizeof(double2));
-    if (!slabs || !fine) return EFGP_ENOMEM;
+    char* misc = (char*)scratch(ctx, SLOT_SCALE, 64);
+    if (!slabs || !fine || !misc) return EFGP_ENOMEM;
+    double* d_scale = (double*)misc;                                  // [0] S, [1] 1/S
+    unsigned long long* d_cmax = (unsigned long long*)(misc + 32);
     if (!use_lds) EFGP_HIP_CHECK(hipMemsetAsync(slabs, 0, slab_bytes, stream));
+
+    const int64_t per = (plan->npts + nwg - 1) / std::max(nwg, 1);
+    if (use_lds) {
+        // fixed-point scale from max |c| (device side, no host round trip)
+        const bool need_max = (mode != STR_ONES);
+        if (need_max) {
+            EFGP_HIP_CHECK(hipMemsetAsync(d_cmax, 0, sizeof(unsigned long long), stream));
+            const int64_t nvals = (int64_t)nbatch * plan->npts * (mode == STR_COMPLEX ? 2 : 1);
+            const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nvals + 1023) / 1024, 1024));
+            hipLaunchKernelGGL(maxabs_kernel, dim3(blocks), dim3(256), 0, stream, c, nvals, d_cmax);
+            EFGP_HIP_CHECK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream,
+                           need_max ? (const unsigned long long*)d_cmax : (const unsigned long long*)nullptr,
+                           (mode == STR_REAL_AND_ONES || mode == STR_ONES) ? 1.0 : 0.0, per, d_scale);
+        EFGP_HIP_CHECK(hipGetLastError());
+    }
 
     SpreadArgs a;
     a.x = plan->x;
@@ -620,6 +745,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     a.channels = channels;
     a.slabs = slabs;
     a.nslab = nslab;
+    a.scale = d_scale;
     dim3 grid(nwg, nbatch);
     hipError_t e = hipSuccess;
     if (plan->npts > 0) {
@@ -635,10 +761,13 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         return EFGP_EHIP;
     }
     {
-        int threads = 256;
-        int blocks = (int)std::min<int64_t>((g.cells + threads - 1) / threads, 1024);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks, nbatch), dim3(threads), 0, stream, slabs, nslab, channels,
-                           g.cells, fine);
+        const int blocks = (int)((g.cells + 63) / 64);
+        if (use_lds && plan->npts > 0)
+            hipLaunchKernelGGL((reduce_slabs_kernel<true>), dim3(blocks, nbatch), dim3(512), 0, stream, slabs, nslab,
+                               channels, g.cells, (const double*)d_scale, fine);
+        else
+            hipLaunchKernelGGL((reduce_slabs_kernel<false>), dim3(blocks, nbatch), dim3(512), 0, stream, slabs, nslab,
+                               channels, g.cells, (const double*)d_scale, fine);
         EFGP_HIP_CHECK(hipGetLastError());
     }
     hipfftHandle fh;
@@ -692,8 +821,6 @@ int efgp_nufft_create(efgp_nufft_t** plan_out, int device, int dim, int64_t npts
 int efgp_nufft_destroy(efgp_nufft_t* plan) {
     if (!plan) return EFGP_OK;
     DeviceGuard guard(plan->device);
-    (void)hipDeviceSynchronize();
-    for (WindowSet* w : plan->windows) free_window(w);
     delete plan;
     return EFGP_OK;
 }

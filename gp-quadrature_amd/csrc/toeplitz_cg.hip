@@ -15,22 +15,17 @@
 #include <cstring>
 #include <vector>
 
+#include <cstdlib>
+
 #include "common.hpp"
 #include "es_kernel.hpp"
+#include "toeplitz_cg.hpp"
 
 namespace efgp {
 
 constexpr int kVecThreads = 256;
 constexpr int kCgThreads = 512;
 constexpr double kDivEps = 1e-16;   // cg.py:57
-
-struct ToepGeom {
-    int d;
-    int64_t n[3];     // block size per dimension (ns)
-    int64_t F[3];     // FFT size per dimension
-    int64_t M;        // prod n
-    int64_t Ftot;     // prod F
-};
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -290,6 +285,8 @@ struct efgp_toeplitz_s {
     ToepGeom g;
     int64_t Ls[3] = {1, 1, 1};
     double2* vhat = nullptr;
+    double2* tw[3] = {nullptr, nullptr, nullptr};   // exp(-2 pi i q / F[a]) tables for the persistent CG
+    bool persistent_ok = false;
 };
 
 namespace efgp {
@@ -338,9 +335,9 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
         op->g.M *= op->g.n[a];
         op->g.Ftot *= op->g.F[a];
     }
-    if (hipMalloc((void**)&op->vhat, (size_t)op->g.Ftot * sizeof(double2)) != hipSuccess) {
+    op->vhat = (double2*)pool_alloc(ctx, (size_t)op->g.Ftot * sizeof(double2));
+    if (!op->vhat) {
         delete op;
-        set_error("efgp_toeplitz_create: hipMalloc(%lld complex) failed", (long long)op->g.Ftot);
         return EFGP_ENOMEM;
     }
     // vhat = FFT(zero-padded v) / Ftot.  Reuse the pad kernel with n := L, i.e. a geometry whose block is L.
@@ -355,7 +352,7 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
                        op->vhat);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        (void)hipFree(op->vhat);
+        pool_free(ctx, op->vhat, (size_t)op->g.Ftot * sizeof(double2));
         delete op;
         set_error("efgp_toeplitz_create: pad launch failed: %s", hipGetErrorString(e));
         return EFGP_EHIP;
@@ -367,7 +364,7 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
         rc = EFGP_EHIP;
     }
     if (rc != EFGP_OK) {
-        (void)hipFree(op->vhat);
+        pool_free(ctx, op->vhat, (size_t)op->g.Ftot * sizeof(double2));
         delete op;
         return rc;
     }
@@ -376,10 +373,37 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
                        op->g.Ftot, 1.0 / (double)op->g.Ftot);
     e = hipGetLastError();
     if (e != hipSuccess) {
-        (void)hipFree(op->vhat);
+        pool_free(ctx, op->vhat, (size_t)op->g.Ftot * sizeof(double2));
         delete op;
         set_error("efgp_toeplitz_create: scale launch failed: %s", hipGetErrorString(e));
         return EFGP_EHIP;
+    }
+    op->persistent_ok = persistent_cg_eligible(op->g);
+    if (op->persistent_ok) {
+        for (int a = 0; a < dim; ++a) {
+            const int64_t n = op->g.F[a];
+            auto it = ctx->twiddles.find(n);
+            if (it != ctx->twiddles.end()) {
+                op->tw[a] = (double2*)it->second;
+                continue;
+            }
+            std::vector<double2> tw((size_t)n);
+            const long double two_pi = 2.0L * acosl(-1.0L);
+            for (int64_t q = 0; q < n; ++q) {
+                long double ang = -two_pi * (long double)q / (long double)n;
+                tw[(size_t)q] = make_double2((double)cosl(ang), (double)sinl(ang));
+            }
+            double2* dtw = nullptr;
+            if (hipMalloc((void**)&dtw, (size_t)n * sizeof(double2)) != hipSuccess ||
+                hipMemcpyAsync(dtw, tw.data(), (size_t)n * sizeof(double2), hipMemcpyHostToDevice, stream) != hipSuccess ||
+                hipStreamSynchronize(stream) != hipSuccess) {
+                if (dtw) (void)hipFree(dtw);
+                op->persistent_ok = false;
+                break;
+            }
+            ctx->twiddles[n] = dtw;
+            op->tw[a] = dtw;
+        }
     }
     *op_out = op;
     return EFGP_OK;
@@ -388,8 +412,9 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
 int efgp_toeplitz_destroy(efgp_toeplitz_t* op) {
     if (!op) return EFGP_OK;
     DeviceGuard guard(op->device);
-    (void)hipDeviceSynchronize();
-    if (op->vhat) (void)hipFree(op->vhat);
+    // the spectrum block goes back to the pool; work already enqueued on the caller's stream that reads it
+    // finishes before any later enqueue on that stream can overwrite a recycled block (single stream)
+    if (op->vhat) pool_free(op->ctx, op->vhat, (size_t)op->g.Ftot * sizeof(double2));
     delete op;
     return EFGP_OK;
 }
@@ -437,6 +462,33 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
     DeviceCtx* ctx = op->ctx;
     const ToepGeom g = op->g;
     if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * g.M, 2000000000);
+
+    // small circulant grids: the whole solve in one persistent kernel, one workgroup per system
+    const bool no_persistent = std::getenv("EFGP_NO_PERSISTENT_CG") != nullptr;   // test hook
+    if (op->persistent_ok && !no_persistent) {
+        int* d_iters = (int*)scratch(ctx, SLOT_CG_SCALARS, (size_t)nbatch * sizeof(int) + 64);
+        int* host = pinned_host(ctx, (size_t)nbatch * sizeof(int) + 64);
+        if (!d_iters || !host) return EFGP_ENOMEM;
+        int rc;
+        {
+            KernelTimer timer("cg_persistent", stream);
+            rc = persistent_cg_launch(g, (const double2* const*)op->tw, op->vhat, (const double2*)ws, precond_diag, sigmasq,
+                                      variant, tol, early_stop, batched_semantics, max_iter, (const double2*)b, (double2*)x,
+                                      nbatch, d_iters, stream);
+        }
+        if (rc != EFGP_OK) return rc;
+        EFGP_HIP_CHECK(hipMemcpyAsync(host, d_iters, (size_t)nbatch * sizeof(int), hipMemcpyDeviceToHost, stream));
+        EFGP_HIP_CHECK(hipStreamSynchronize(stream));
+        int mx = 0;
+        for (int i = 0; i < nbatch; ++i) {
+            mx = std::max(mx, host[i]);
+            if (row_iters_out) row_iters_out[i] = host[i];
+        }
+        int total = mx;
+        if (batched_semantics && mx < max_iter) total = mx + 1;      // the terminating pass, cg.py:193-199,243
+        if (iters_out) *iters_out = total;
+        return EFGP_OK;
+    }
 
     // rows are processed in groups whose padded grids fit ~512 MB of scratch
     const int64_t group_cap = std::max<int64_t>(1, (int64_t)(512ll << 20) / (g.Ftot * (int64_t)sizeof(double2)));

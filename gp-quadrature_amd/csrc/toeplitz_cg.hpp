@@ -1,0 +1,23 @@
+// Shared declarations of the Toeplitz / CG translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace efgp {
+
+struct ToepGeom {
+    int d;
+    int64_t n[3];     // block size per dimension (ns)
+    int64_t F[3];     // FFT size per dimension
+    int64_t M;        // prod n
+    int64_t Ftot;     // prod F
+};
+
+// single-launch CG with the FFT in LDS (cg_persistent.hip)
+bool persistent_cg_eligible(const ToepGeom& g);
+int persistent_cg_launch(const ToepGeom& g, const double2* const* twiddles, const double2* vhat, const double2* ws,
+                         const double* diag, double sigmasq, int variant, double tol, int early_stop, int batched,
+                         int max_iter, const double2* b, double2* x, int rows, int* d_iters, hipStream_t stream);
+
+}  // namespace efgp

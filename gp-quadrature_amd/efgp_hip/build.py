@@ -10,8 +10,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
-SOURCES = ["es_kernel.cpp", "common.cpp", "nufft.hip", "toeplitz_cg.hip"]
-HEADERS = ["es_kernel.hpp", "common.hpp", os.path.join("..", "..", "include", "efgp_hip.h")]
+SOURCES = ["es_kernel.cpp", "common.cpp", "nufft.hip", "toeplitz_cg.hip", "cg_persistent.hip"]
+HEADERS = ["es_kernel.hpp", "common.hpp", "toeplitz_cg.hpp", os.path.join("..", "..", "include", "efgp_hip.h")]
 TARGET = os.path.join(HERE, "libefgp_hip.so")
 
 
@@ -28,21 +28,28 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in deps if os.path.exists(p))
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, stamps=False):
+    """stamps=True builds the DIAGNOSTIC library libefgp_hip_stamps.so (in-kernel cycle stamps in the
+    persistent CG; never loaded by the product path)."""
+    if stamps:
+        return _build(TARGET.replace("libefgp_hip.so", "libefgp_hip_stamps.so"), ["-DEFGP_CG_STAMPS"], verbose)
     if not force and not needs_build():
         return TARGET
+    return _build(TARGET, [], verbose)
+
+
+def _build(target, extra, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tl = _torch_lib_dir()
     cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-munsafe-fp-atomics",
-           "-no-hip-rt", "-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + [
-           "-I/opt/rocm/include", "-L" + tl, "-lhipfft", "-lamdhip64", "-Wl,-rpath," + tl, "-o", TARGET + ".tmp"]
+           "-no-hip-rt"] + extra + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + [
+           "-I/opt/rocm/include", "-L" + tl, "-lhipfft", "-lamdhip64", "-Wl,-rpath," + tl, "-o", target + ".tmp"]
     if verbose:
         print("[efgp_hip] " + " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    os.replace(TARGET + ".tmp", TARGET)
-    return TARGET
+    os.replace(target + ".tmp", target)
+    return target
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(TARGET)
+    print(build(force="--force" in sys.argv, stamps="--stamps" in sys.argv))

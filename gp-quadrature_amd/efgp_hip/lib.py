@@ -14,7 +14,8 @@ class EfgpError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(HERE, "libefgp_hip.so")
+    # EFGP_HIP_LIBRARY lets the diagnostic tools under tools/ load an instrumented build
+    return os.environ.get("EFGP_HIP_LIBRARY") or os.path.join(HERE, "libefgp_hip.so")
 
 
 def header_path():

@@ -51,6 +51,10 @@ class GetTruncationBound:
         mid = (a + b) / 2
         for _ in range(self.max_iterations):
             mid = (a + b) / 2
+            if mid == a or mid == b:
+                # the bracket is two adjacent doubles: every remaining pass of the fixed-count loop
+                # recomputes the same midpoint and leaves (a, b) unchanged, so stopping is exact
+                break
             if self._f(mid) > self.eps:
                 a = mid
             else:

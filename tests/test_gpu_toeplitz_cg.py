@@ -85,3 +85,34 @@ def test_cg_batched_mask_semantics():
     xg3, itg3, _ = cg_solve(op, ws.cuda(), sig2, 1, b.cuda(), torch.zeros_like(b).cuda(), 1e-30, max_iter=7)
     assert itg3 == ito3 == 7
     assert _rel(xg3, xo3) < 1e-10
+
+
+@pytest.mark.parametrize("d,mtot", [(1, 35), (1, 501), (2, 23), (2, 9), (3, 7)])
+def test_persistent_and_multikernel_cg_agree(d, mtot, monkeypatch):
+    """The single-launch LDS-FFT solver and the rocFFT multi-kernel solver implement the same CG."""
+    from efgp_hip import ToeplitzOp, cg_solve
+    from oracle import efgp_oracle as O
+    x, v, T = _setup(d, mtot, N=700, seed=5)
+    M = T.size
+    g = torch.Generator().manual_seed(4)
+    ws = torch.exp(-2.5 * torch.rand(M, generator=g, dtype=torch.float64)).to(torch.complex128)
+    sig2 = 0.25
+    B = 5
+    b = torch.complex(torch.randn(B, M, generator=g, dtype=torch.float64), torch.randn(B, M, generator=g, dtype=torch.float64))
+    diag = O.jacobi_diag(ws, sig2, 700.0)
+    op = ToeplitzOp(v.cuda())
+    out = {}
+    for mode in ("persistent", "multikernel"):
+        if mode == "multikernel":
+            monkeypatch.setenv("EFGP_NO_PERSISTENT_CG", "1")
+        else:
+            monkeypatch.delenv("EFGP_NO_PERSISTENT_CG", raising=False)
+        out[mode] = cg_solve(op, ws.cuda(), sig2, 0, b.cuda(), torch.zeros_like(b).cuda(), 1e-9, diag=diag.cuda())
+        out[mode + "_1"] = cg_solve(op, ws.cuda(), sig2, 1, b[0].cuda(), torch.zeros_like(b[0]).cuda(), 1e-9, batched=False)
+    xo, ito = O.cg_batched(O.make_A_mean(ws, T, sig2), b, torch.zeros_like(b), 1e-9, diag=diag)
+    for mode in ("persistent", "multikernel"):
+        xg, itg, rows = out[mode]
+        assert abs(itg - ito) <= 1
+        assert _rel(xg, xo) < 1e-7
+    assert abs(out["persistent_1"][1] - out["multikernel_1"][1]) <= 1
+    assert _rel(out["persistent_1"][0], out["multikernel_1"][0]) < 1e-7
