@@ -295,8 +295,30 @@ __device__ __forceinline__ void run_pass(const Geom& g, const Pass& p, int s_beg
     }
 }
 
+// wave-level sum with DPP moves (VALU only; the LDS pipe stays free for the FFT stages).  gfx9 row_shr /
+// row_bcast controls; the value ends up in lane 63 and is broadcast through an SGPR.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+#define EFGP_DPP_ADD(v, ctrl, rmask) v += dpp_move<ctrl, rmask>(v)
+__device__ __forceinline__ double wave_sum(double v) {
+    EFGP_DPP_ADD(v, 0x111, 0xF);   // row_shr:1
+    EFGP_DPP_ADD(v, 0x112, 0xF);   // row_shr:2
+    EFGP_DPP_ADD(v, 0x114, 0xF);   // row_shr:4
+    EFGP_DPP_ADD(v, 0x118, 0xF);   // row_shr:8   -> lane 15 of every 16-lane row holds the row sum
+    EFGP_DPP_ADD(v, 0x142, 0xA);   // row_bcast:15 into rows 1 and 3
+    EFGP_DPP_ADD(v, 0x143, 0xC);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double block_sum2(double v, double* red) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    v = wave_sum(v);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) red[wid] = v;
@@ -305,6 +327,27 @@ __device__ __forceinline__ double block_sum2(double v, double* red) {
 #pragma unroll
     for (int i = 0; i < kRedWaves; ++i) t += red[i];
     return t;
+}
+
+// two sums with one pair of barriers
+__device__ __forceinline__ void block_sum_pair(double& u, double& v, double* red) {
+    u = wave_sum(u);
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+        red[wid] = u;
+        red[kRedWaves + wid] = v;
+    }
+    __syncthreads();
+    double t = 0.0, w = 0.0;
+#pragma unroll
+    for (int i = 0; i < kRedWaves; ++i) {
+        t += red[i];
+        w += red[kRedWaves + i];
+    }
+    u = t;
+    v = w;
 }
 
 // flat block index -> offset in the padded grid, optionally shifted by (n-1) per dimension
@@ -320,7 +363,7 @@ __device__ __forceinline__ int grid_offset(const Geom& g, int flat, int shift) {
 
 __global__ __launch_bounds__(kThreads) void cg_persistent_kernel(Args a) {
     extern __shared__ double2 lds2[];
-    __shared__ double red[kRedWaves];
+    __shared__ double red[2 * kRedWaves];
     const Geom& g = a.g;
     double2* bufA = lds2;
     double2* bufB = lds2 + g.padded;
@@ -443,8 +486,7 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_kernel(Args a) {
             bb += bv.x * bv.x + bv.y * bv.y;
         }
     }
-    rz = block_sum2(rz, red);
-    bb = block_sum2(bb, red);
+    block_sum_pair(rz, bb, red);
     const double bn = sqrt(bb);
     const double den = bn > 0.0 ? bn : 1.0;
 
@@ -468,8 +510,7 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_kernel(Args a) {
             rr += rv[s].x * rv[s].x + rv[s].y * rv[s].y;
             rzn += rv[s].x * zv[s].x + rv[s].y * zv[s].y;
         }
-        rr = block_sum2(rr, red);
-        rzn = block_sum2(rzn, red);
+        block_sum_pair(rr, rzn, red);
         ++it;
         const double rnorm = sqrt(rr);
         const bool conv = a.early_stop && ((rnorm / (den + 1e-16) < a.tol) || (a.batched && rnorm < 1e-12));
@@ -529,7 +570,7 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
     using namespace s64;
     constexpr int KS = 2;                   // M = n*n <= 1024 = KS * kThreads
     extern __shared__ double2 lds2[];
-    __shared__ double red[kRedWaves];
+    __shared__ double red[2 * kRedWaves];
     double2* const bufA = lds2;
     double2* const bufB = lds2 + BUF;
     const int n = a.g.n[0];                 // block size per dimension (n0 == n1 for this kernel)
@@ -684,8 +725,7 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
             bb += bv.x * bv.x + bv.y * bv.y;
         }
     }
-    rz = block_sum2(rz, red);
-    bb = block_sum2(bb, red);
+    block_sum_pair(rz, bb, red);
     const double bn = sqrt(bb);
     const double den = bn > 0.0 ? bn : 1.0;
     int it = 0;
@@ -708,8 +748,7 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
             rr += rv[s].x * rv[s].x + rv[s].y * rv[s].y;
             rzn += rv[s].x * zv[s].x + rv[s].y * zv[s].y;
         }
-        rr = block_sum2(rr, red);
-        rzn = block_sum2(rzn, red);
+        block_sum_pair(rr, rzn, red);
         ++it;
         const double rnorm = sqrt(rr);
         const bool conv = a.early_stop && ((rnorm / (den + 1e-16) < a.tol) || (a.batched && rnorm < 1e-12));

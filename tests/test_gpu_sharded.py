@@ -1,0 +1,94 @@
+"""GPU test of the point-sharded product path: two ranks (one process each, both on the single test GPU,
+gloo process group carrying the cuda tensors) each hold half of the observations; the all-reduced fit must
+equal the unsharded fit.  On a multi-GPU node the same code runs with backend "nccl" (RCCL)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _data():
+    g = torch.Generator().manual_seed(11)
+    N = 30001
+    x = torch.rand(N, 2, generator=g, dtype=torch.float64) * 2 - 1
+    y = torch.sin(3 * x[:, 0]) * torch.cos(2 * x[:, 1]) + 0.2 * torch.randn(N, generator=g, dtype=torch.float64)
+    xn = torch.rand(257, 2, generator=g, dtype=torch.float64) * 2 - 1
+    return x, y, xn
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "gp-quadrature_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from efgpnd import EFGPND
+        from efgp_hip.dist import shard_bounds
+        from kernels.squared_exponential import SquaredExponential
+        x, y, xn = _data()
+        lo, hi = shard_bounds(x.shape[0], world, rank)
+        k = SquaredExponential(dimension=2, init_lengthscale=0.25, init_variance=1.3)
+        m = EFGPND(x[lo:hi].cuda(), y[lo:hi].cuda(), k, sigmasq=0.1, eps=1e-4, nufft_eps=1e-9, estimate_params=False,
+                   opts={"cg_tolerance": 1e-10, "shard_points": True})
+        mean, _ = m.predict(xn.cuda(), return_variance=False)
+        V = torch.ones(2, m.last_fit_stats["feature_count"], dtype=torch.float64)
+        V[1, ::2] = -1
+        Z = torch.ones(2, hi - lo, dtype=torch.float64)
+        Z[0, ::3] = -1
+        grad = m.compute_gradients(trace_samples=2, cg_tol=1e-10, probes_Z=Z, probes_V=V)
+        q.put((rank, mean.cpu(), grad.detach().cpu(), m.last_fit_stats["mean_cg_iters"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_shards_equal_unsharded():
+    sys.path.insert(0, os.path.join(ROOT, "gp-quadrature_amd"))
+    from efgpnd import EFGPND
+    from efgp_hip.dist import shard_bounds
+    from kernels.squared_exponential import SquaredExponential
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x, y, xn = _data()
+    k = SquaredExponential(dimension=2, init_lengthscale=0.25, init_variance=1.3)
+    m = EFGPND(x.cuda(), y.cuda(), k, sigmasq=0.1, eps=1e-4, nufft_eps=1e-9, estimate_params=False,
+               opts={"cg_tolerance": 1e-10})
+    mean, _ = m.predict(xn.cuda(), return_variance=False)
+    V = torch.ones(2, m.last_fit_stats["feature_count"], dtype=torch.float64)
+    V[1, ::2] = -1
+    Zs = []
+    for r in range(world):
+        lo, hi = shard_bounds(x.shape[0], world, r)
+        z = torch.ones(2, hi - lo, dtype=torch.float64)
+        z[0, ::3] = -1
+        Zs.append(z)
+    grad = m.compute_gradients(trace_samples=2, cg_tol=1e-10, probes_Z=torch.cat(Zs, dim=1), probes_V=V).detach().cpu()
+    for rank, smean, sgrad, its in res:
+        assert float((smean - mean.cpu()).abs().max() / mean.cpu().abs().max()) < 1e-9
+        scale = float(m.last_gradient_stats["term1"].abs().max()) * float(m._gp_params.pos.detach().max())
+        assert float((sgrad - grad).abs().max()) < 1e-7 * scale
+        assert abs(its - m.last_fit_stats["mean_cg_iters"]) <= 1
