@@ -14,6 +14,7 @@
 // the 160 KB LDS of a CU the points are streamed UNSORTED and accumulated with LDS atomics; larger
 // grids fall back to global (L2) atomics.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -205,13 +206,27 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
     }
 }
 
-// max |c| over n doubles as an ordered bit pattern (non-negative doubles compare like integers)
-__global__ void maxabs_kernel(const double* __restrict__ c, int64_t n, unsigned long long* __restrict__ out) {
+// max |c| over n doubles as an ordered bit pattern (non-negative doubles compare like integers).
+// One atomic per workgroup (block-level reduction first): thousands of same-address atomics serialise.
+__global__ __launch_bounds__(1024) void maxabs_kernel(const double* __restrict__ c, int64_t n,
+                                                       unsigned long long* __restrict__ out) {
+    __shared__ double part[16];
     double m = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        m = fmax(m, fabs(c[i]));
+    const int64_t n2 = n >> 1;
+    const double2* c2 = reinterpret_cast<const double2*>(c);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+        const double2 v = c2[i];
+        m = fmax(m, fmax(fabs(v.x), fabs(v.y)));
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) m = fmax(m, fabs(c[n - 1]));
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t = fmax(t, part[i]);
+        if (t > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(t));
+    }
 }
 
 // scale[0] = S = largest power of two with  max|c| * S <= 2^50  and  points_per_wg * max|c| * S <= 2^61
@@ -282,6 +297,256 @@ __global__ __launch_bounds__(512) void reduce_slabs_kernel(const double* __restr
             }
             fine[(int64_t)batch * cells + cell] = make_double2(a, b);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Tiled spreading for fine grids that do not fit LDS.
+//   The fine grid is cut into tiles of T[a] cells per dimension; a point belongs to the tile of its first
+//   covered cell.  Points are counting-sorted by tile ONCE PER PLAN (x is fixed; LDS-ranked scatter, one
+//   global atomic per (workgroup, tile)); `xs` holds the coordinates in tile order, `order` the original
+//   indices (strengths are gathered through it).  A workgroup then takes a contiguous chunk of sorted
+//   points, and for every tile segment inside it accumulates a (T+W-1)^d LDS tile with the same fixed-point
+//   atomics as the LDS-resident spreader and adds the tile to the int64 global grid.
+// ------------------------------------------------------------------------------------------
+struct TileGeom {
+    int d;
+    int nf[3];
+    int T[3];        // tile size in cells
+    int nt[3];       // tiles per dimension
+    int ext[3];      // T + W - 1: cells an LDS tile spans per dimension (1 for unused dims)
+    int nbins;
+    int W;
+    double scale[3];
+    double xcen[3];
+};
+
+template <int D>
+__device__ __forceinline__ int tile_of_point(const TileGeom& t, const double* __restrict__ x, int64_t n) {
+    int bin = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+        const double X = fold(t.scale[a] * (x[n * D + a] - t.xcen[a]), (double)t.nf[a]);
+        int f = (int)ceil(X - 0.5 * t.W);
+        if (f < 0) f += t.nf[a];
+        bin = bin * t.nt[a] + f / t.T[a];
+    }
+    return bin;
+}
+
+// per-workgroup LDS histogram -> global histogram
+template <int D>
+__global__ __launch_bounds__(1024) void bin_hist_kernel(TileGeom t, const double* __restrict__ x, int64_t npts,
+                                                         int* __restrict__ hist) {
+    extern __shared__ int lhist[];
+    for (int i = threadIdx.x; i < t.nbins; i += blockDim.x) lhist[i] = 0;
+    __syncthreads();
+    const int64_t per = (npts + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < npts ? lo + per : npts;
+    for (int64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) atomicAdd(&lhist[tile_of_point<D>(t, x, n)], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < t.nbins; i += blockDim.x)
+        if (lhist[i]) atomicAdd(&hist[i], lhist[i]);
+}
+
+// exclusive scan of the histogram (one workgroup); start[nbins] = total; cursor = copy of start
+__global__ __launch_bounds__(1024) void bin_scan_kernel(const int* __restrict__ hist, int nbins, int* __restrict__ start,
+                                                         int* __restrict__ cursor) {
+    __shared__ int part[1024];
+    const int per = (nbins + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(lo + per, nbins);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += hist[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const int v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        start[nbins] = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) {
+        start[i] = run;
+        cursor[i] = run;
+        run += hist[i];
+    }
+}
+
+// scatter the points of this workgroup's chunk to their tile ranges
+template <int D>
+__global__ __launch_bounds__(1024) void bin_scatter_kernel(TileGeom t, const double* __restrict__ x, int64_t npts,
+                                                            int* __restrict__ cursor, double* __restrict__ xs,
+                                                            int* __restrict__ order) {
+    extern __shared__ int lmem[];
+    int* lcount = lmem;                 // points of this chunk per tile
+    int* lbase = lmem + t.nbins;        // global offset reserved for them
+    for (int i = threadIdx.x; i < t.nbins; i += blockDim.x) lcount[i] = 0;
+    __syncthreads();
+    const int64_t per = (npts + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < npts ? lo + per : npts;
+    // pass 1: local ranks (kept in registers; a thread handles up to kMaxPer points of the chunk)
+    constexpr int kMaxPer = 32;
+    int bins[kMaxPer], ranks[kMaxPer];
+    int cnt = 0;
+    for (int64_t n = lo + threadIdx.x; n < hi && cnt < kMaxPer; n += blockDim.x, ++cnt) {
+        bins[cnt] = tile_of_point<D>(t, x, n);
+        ranks[cnt] = atomicAdd(&lcount[bins[cnt]], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < t.nbins; i += blockDim.x) lbase[i] = lcount[i] ? atomicAdd(&cursor[i], lcount[i]) : 0;
+    __syncthreads();
+    cnt = 0;
+    for (int64_t n = lo + threadIdx.x; n < hi && cnt < kMaxPer; n += blockDim.x, ++cnt) {
+        const int64_t dst = (int64_t)lbase[bins[cnt]] + ranks[cnt];
+#pragma unroll
+        for (int a = 0; a < D; ++a) xs[dst * D + a] = x[n * D + a];
+        order[dst] = (int)n;
+    }
+}
+
+struct TileSpreadArgs {
+    TileGeom t;
+    const double* xs;         // tile-sorted coordinates
+    const int* order;         // sorted position -> original index
+    const int* start;         // [nbins + 1]
+    const double* c;
+    int64_t c_stride;
+    int64_t npts;
+    int64_t chunk;            // sorted points per workgroup
+    const double* coef;
+    int degree;
+    int mode;
+    int channels;
+    long long* gacc;          // [batch][channels][cells] int64 fixed-point global grid (pre-zeroed)
+    int64_t cells;
+    const double* scale;
+};
+
+template <int D, int W>
+__global__ __launch_bounds__(kSpreadThreads) void spread_tile_kernel(TileSpreadArgs a) {
+    extern __shared__ double lds[];
+    __shared__ int s_bin;
+    const TileGeom& t = a.t;
+    const int batch = blockIdx.y;
+    const int C = a.channels;
+    const int e0 = t.ext[0], e1 = t.ext[1], e2 = t.ext[2];
+    const int tcells = e0 * e1 * e2;
+    const int64_t lo = (int64_t)blockIdx.x * a.chunk;
+    const int64_t hi = lo + a.chunk < a.npts ? lo + a.chunk : a.npts;
+    if (lo >= hi) return;
+    const double S = a.scale[0];
+    const double* cb = a.c ? a.c + (int64_t)batch * a.c_stride : nullptr;
+    long long* gacc = a.gacc + (int64_t)batch * C * a.cells;
+    // first tile that contains sorted position `lo` (binary search by one lane)
+    if (threadIdx.x == 0) {
+        int l = 0, r = t.nbins;            // invariant: start[l] <= lo < start[r]
+        while (r - l > 1) {
+            const int m = (l + r) >> 1;
+            if ((int64_t)a.start[m] <= lo) l = m;
+            else r = m;
+        }
+        s_bin = l;
+    }
+    __syncthreads();
+    int bin = s_bin;
+    int64_t cur = lo;
+    while (cur < hi) {
+        while ((int64_t)a.start[bin + 1] <= cur) ++bin;            // skip empty tiles
+        const int64_t seg_hi = (int64_t)a.start[bin + 1] < hi ? (int64_t)a.start[bin + 1] : hi;
+        // tile origin
+        int rem = bin, o[3] = {0, 0, 0};
+        for (int q = D - 1; q >= 0; --q) {
+            o[q] = (rem % t.nt[q]) * t.T[q];
+            rem /= t.nt[q];
+        }
+        for (int i = threadIdx.x; i < C * tcells; i += kSpreadThreads) lds[i] = 0.0;
+        __syncthreads();
+        for (int64_t n = cur + threadIdx.x; n < seg_hi; n += kSpreadThreads) {
+            double c0 = 1.0, c1 = 1.0;
+            if (a.mode != STR_ONES) {
+                const int64_t src = a.order[n];
+                if (a.mode == STR_COMPLEX) {
+                    const double2 cc = reinterpret_cast<const double2*>(cb)[src];
+                    c0 = cc.x;
+                    c1 = cc.y;
+                } else {
+                    c0 = cb[src];
+                }
+            }
+            c0 *= S;
+            c1 *= S;
+            double v0[W], v1[W], v2[W];
+            int f0 = 0, f1 = 0, f2 = 0;
+            {
+                double X = fold(t.scale[0] * (a.xs[n * D + 0] - t.xcen[0]), (double)t.nf[0]);
+                window_values<W>(a.coef, a.degree, X, t.nf[0], f0, v0);
+                f0 -= o[0];
+            }
+            if (D > 1) {
+                double X = fold(t.scale[1] * (a.xs[n * D + 1] - t.xcen[1]), (double)t.nf[1]);
+                window_values<W>(a.coef, a.degree, X, t.nf[1], f1, v1);
+                f1 -= o[1];
+            }
+            if (D > 2) {
+                double X = fold(t.scale[2] * (a.xs[n * D + 2] - t.xcen[2]), (double)t.nf[2]);
+                window_values<W>(a.coef, a.degree, X, t.nf[2], f2, v2);
+                f2 -= o[2];
+            }
+            if (D == 1) {
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    lds_add_fixed(&lds[f0 + j], c0, v0[j]);
+                    if (C == 2) lds_add_fixed(&lds[tcells + f0 + j], c1, v0[j]);
+                }
+            } else if (D == 2) {
+#pragma unroll
+                for (int j0 = 0; j0 < W; ++j0) {
+                    const int row = (f0 + j0) * e1 + f1;
+                    const double a0 = v0[j0] * c0, a1 = v0[j0] * c1;
+#pragma unroll
+                    for (int j1 = 0; j1 < W; ++j1) {
+                        lds_add_fixed(&lds[row + j1], a0, v1[j1]);
+                        if (C == 2) lds_add_fixed(&lds[tcells + row + j1], a1, v1[j1]);
+                    }
+                }
+            } else {
+                for (int j0 = 0; j0 < W; ++j0) {
+                    for (int j1 = 0; j1 < W; ++j1) {
+                        const int row = ((f0 + j0) * e1 + (f1 + j1)) * e2 + f2;
+                        const double w01 = v0[j0] * v1[j1];
+                        const double a0 = w01 * c0, a1 = w01 * c1;
+#pragma unroll
+                        for (int j2 = 0; j2 < W; ++j2) {
+                            lds_add_fixed(&lds[row + j2], a0, v2[j2]);
+                            if (C == 2) lds_add_fixed(&lds[tcells + row + j2], a1, v2[j2]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // add the tile (with wrap-around) to the global int64 grid
+        for (int i = threadIdx.x; i < tcells; i += kSpreadThreads) {
+            int l2 = i % e2, l1 = (i / e2) % e1, l0 = i / (e2 * e1);
+            int g0 = o[0] + l0, g1 = o[1] + l1, g2 = o[2] + l2;
+            if (g0 >= t.nf[0]) g0 -= t.nf[0];
+            if (D > 1 && g1 >= t.nf[1]) g1 -= t.nf[1];
+            if (D > 2 && g2 >= t.nf[2]) g2 -= t.nf[2];
+            const int64_t gi = D == 1 ? g0 : (D == 2 ? (int64_t)g0 * t.nf[1] + g1 : ((int64_t)g0 * t.nf[1] + g1) * t.nf[2] + g2);
+            const long long m0 = reinterpret_cast<const long long*>(lds)[i];
+            if (m0) atomicAdd(reinterpret_cast<unsigned long long*>(&gacc[gi]), (unsigned long long)m0);
+            if (C == 2) {
+                const long long m1 = reinterpret_cast<const long long*>(lds)[tcells + i];
+                if (m1) atomicAdd(reinterpret_cast<unsigned long long*>(&gacc[a.cells + gi]), (unsigned long long)m1);
+            }
+        }
+        __syncthreads();
+        cur = seg_hi;
     }
 }
 
@@ -506,6 +771,15 @@ struct WindowSet {          // device copies of the window data for one (toleran
     int64_t nf[3] = {0, 0, 0};
 };
 
+struct BinSet {             // points counting-sorted by fine-grid tile (see spread_tile_kernel)
+    TileGeom t;
+    int channels = 0;
+    double* xs = nullptr;
+    int* order = nullptr;
+    int* start = nullptr;       // nbins + 1
+    size_t xs_bytes = 0, order_bytes = 0, start_bytes = 0;
+};
+
 }  // namespace efgp
 
 using namespace efgp;
@@ -519,6 +793,7 @@ struct efgp_nufft_s {
     double h = 0.0;
     double tol = 1e-6;
     DeviceCtx* ctx = nullptr;
+    std::vector<efgp::BinSet*> bins;     // tile-sorted copies of the points, per (fine grid, W, tile) geometry
 };
 
 namespace efgp {
@@ -689,6 +964,115 @@ static hipError_t launch_interp_d(int W, bool cplx, bool use_lds, dim3 grid, siz
     return hipErrorInvalidValue;
 }
 
+// ---- tiled path: geometry, binning, launch -------------------------------------------------------
+static bool make_tile_geom(const efgp_nufft_s* plan, const WindowSet* w, int channels, size_t lds_budget, TileGeom* out) {
+    TileGeom t;
+    const int d = plan->dim, W = w->p.w;
+    t.d = d;
+    t.W = W;
+    // largest cubic-ish tile whose (T+W-1)^d * channels * 8 B fits the LDS budget
+    const double cells_max = (double)lds_budget / (8.0 * channels);
+    int ext = (int)std::floor(std::pow(cells_max, 1.0 / d));
+    while (ext > W && std::pow((double)ext, d) > cells_max) --ext;
+    const int Tmax = ext - (W - 1);
+    if (Tmax < 2) return false;
+    t.nbins = 1;
+    for (int a = 0; a < 3; ++a) {
+        if (a < d) {
+            t.nf[a] = (int)w->nf[a];
+            t.nt[a] = (t.nf[a] + Tmax - 1) / Tmax;
+            t.T[a] = (t.nf[a] + t.nt[a] - 1) / t.nt[a];
+            t.ext[a] = t.T[a] + W - 1;
+            t.scale[a] = plan->h * (double)w->nf[a];
+            t.xcen[a] = plan->xcen[a];
+            t.nbins *= t.nt[a];
+        } else {
+            t.nf[a] = 1;
+            t.nt[a] = 1;
+            t.T[a] = 1;
+            t.ext[a] = 1;
+            t.scale[a] = 0.0;
+            t.xcen[a] = 0.0;
+        }
+    }
+    if (t.nbins > 8192) return false;           // LDS histograms of the binning kernels
+    *out = t;
+    return true;
+}
+
+static void free_binset(DeviceCtx* ctx, BinSet* b) {
+    if (!b) return;
+    pool_free(ctx, b->xs, b->xs_bytes);
+    pool_free(ctx, b->order, b->order_bytes);
+    pool_free(ctx, b->start, b->start_bytes);
+    delete b;
+}
+
+static int get_bins(efgp_nufft_s* plan, const TileGeom& t, int channels, hipStream_t stream, BinSet** out) {
+    for (BinSet* b : plan->bins) {
+        bool same = b->t.W == t.W && b->t.nbins == t.nbins;
+        for (int a = 0; a < plan->dim && same; ++a) same = b->t.nf[a] == t.nf[a] && b->t.T[a] == t.T[a];
+        if (same) {
+            *out = b;
+            return EFGP_OK;
+        }
+    }
+    DeviceCtx* ctx = plan->ctx;
+    auto* b = new BinSet();
+    b->t = t;
+    b->channels = channels;
+    b->xs_bytes = (size_t)plan->npts * plan->dim * sizeof(double);
+    b->order_bytes = (size_t)plan->npts * sizeof(int);
+    b->start_bytes = (size_t)(t.nbins + 1) * sizeof(int);
+    b->xs = (double*)pool_alloc(ctx, b->xs_bytes);
+    b->order = (int*)pool_alloc(ctx, b->order_bytes);
+    b->start = (int*)pool_alloc(ctx, b->start_bytes);
+    int* tmp = (int*)scratch(ctx, SLOT_MISC, (size_t)2 * (t.nbins + 1) * sizeof(int));     // hist, cursor
+    if (!b->xs || !b->order || !b->start || !tmp) {
+        free_binset(ctx, b);
+        return EFGP_ENOMEM;
+    }
+    int* hist = tmp;
+    int* cursor = tmp + t.nbins + 1;
+    EFGP_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)(t.nbins + 1) * sizeof(int), stream));
+    // chunks of <= 32 * 1024 points per workgroup (bin_scatter_kernel keeps 32 ranks per thread)
+    const int nwg = (int)std::max<int64_t>(1, (plan->npts + 32 * 1024 - 1) / (32 * 1024));
+    const size_t lds_h = (size_t)t.nbins * sizeof(int), lds_s = (size_t)2 * t.nbins * sizeof(int);
+#define EFGP_BIN_LAUNCH(D_)                                                                                              \
+    hipLaunchKernelGGL((bin_hist_kernel<D_>), dim3(nwg), dim3(1024), lds_h, stream, t, plan->x, plan->npts, hist);        \
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, stream, (const int*)hist, t.nbins, b->start, cursor);     \
+    hipLaunchKernelGGL((bin_scatter_kernel<D_>), dim3(nwg), dim3(1024), lds_s, stream, t, plan->x, plan->npts, cursor,    \
+                       b->xs, b->order);
+    if (plan->dim == 1) { EFGP_BIN_LAUNCH(1) }
+    else if (plan->dim == 2) { EFGP_BIN_LAUNCH(2) }
+    else { EFGP_BIN_LAUNCH(3) }
+#undef EFGP_BIN_LAUNCH
+    EFGP_HIP_CHECK(hipGetLastError());
+    plan->bins.push_back(b);
+    *out = b;
+    return EFGP_OK;
+}
+
+template <int D>
+static hipError_t launch_tile_d(int W, dim3 grid, size_t lds_bytes, hipStream_t s, const TileSpreadArgs& a) {
+    switch (W) {
+#define EFGP_CASE(w_)                                                                                               \
+    case w_: {                                                                                                      \
+        auto k = spread_tile_kernel<D, w_>;                                                                         \
+        if (lds_bytes > 65536) {                                                                                    \
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            if (e != hipSuccess) return e;                                                                          \
+        }                                                                                                           \
+        hipLaunchKernelGGL(k, grid, dim3(kSpreadThreads), lds_bytes, s, a);                                         \
+        return hipGetLastError();                                                                                   \
+    }
+        EFGP_CASE(2) EFGP_CASE(3) EFGP_CASE(4) EFGP_CASE(5) EFGP_CASE(6) EFGP_CASE(7) EFGP_CASE(8) EFGP_CASE(9)
+        EFGP_CASE(10) EFGP_CASE(11) EFGP_CASE(12) EFGP_CASE(13) EFGP_CASE(14) EFGP_CASE(15) EFGP_CASE(16)
+#undef EFGP_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
 // spread + reduce + FFT; leaves the transformed fine grids in SLOT_FINE
 static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int mode, int nbatch, int isign,
                           hipStream_t stream, double2** fine_out) {
@@ -697,6 +1081,78 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     const int channels = (mode == STR_COMPLEX || mode == STR_REAL_AND_ONES) ? 2 : 1;
     const size_t lds_bytes = (size_t)channels * (size_t)g.cells * sizeof(double);
     const bool use_lds = lds_bytes <= (size_t)ctx->max_lds && plan->npts > 0;
+    // grids beyond LDS: tile-sorted points + LDS tiles (large N), else global atomics (small N)
+    TileGeom tg;
+    const bool use_tiles = !use_lds && plan->npts >= 32768 && std::getenv("EFGP_NO_TILES") == nullptr &&
+                           make_tile_geom(plan, w, channels, (size_t)ctx->max_lds - 4096, &tg);
+    if (use_tiles) {
+        BinSet* bins = nullptr;
+        int rc = get_bins(plan, tg, channels, stream, &bins);
+        if (rc != EFGP_OK) return rc;
+        const size_t acc_bytes = (size_t)nbatch * channels * (size_t)g.cells * sizeof(long long);
+        long long* gacc = (long long*)scratch(ctx, SLOT_SLABS, acc_bytes);
+        double2* fine = (double2*)scratch(ctx, SLOT_FINE, (size_t)nbatch * (size_t)g.cells * sizeof(double2));
+        char* misc = (char*)scratch(ctx, SLOT_SCALE, 64);
+        if (!gacc || !fine || !misc) return EFGP_ENOMEM;
+        double* d_scale = (double*)misc;
+        unsigned long long* d_cmax = (unsigned long long*)(misc + 32);
+        EFGP_HIP_CHECK(hipMemsetAsync(gacc, 0, acc_bytes, stream));
+        const bool need_max = (mode != STR_ONES);
+        if (need_max) {
+            EFGP_HIP_CHECK(hipMemsetAsync(d_cmax, 0, sizeof(unsigned long long), stream));
+            const int64_t nvals = (int64_t)nbatch * plan->npts * (mode == STR_COMPLEX ? 2 : 1);
+            const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nvals + 8191) / 8192, 256));
+            hipLaunchKernelGGL(maxabs_kernel, dim3(blocks), dim3(1024), 0, stream, c, nvals, d_cmax);
+            EFGP_HIP_CHECK(hipGetLastError());
+        }
+        // the global int64 grid sums over ALL points: bound the scale with N instead of points per workgroup
+        hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream,
+                           need_max ? (const unsigned long long*)d_cmax : (const unsigned long long*)nullptr,
+                           (mode == STR_REAL_AND_ONES || mode == STR_ONES) ? 1.0 : 0.0, plan->npts, d_scale);
+        EFGP_HIP_CHECK(hipGetLastError());
+        TileSpreadArgs ta;
+        ta.t = tg;
+        ta.xs = bins->xs;
+        ta.order = bins->order;
+        ta.start = bins->start;
+        ta.c = c;
+        ta.c_stride = (mode == STR_COMPLEX) ? 2 * plan->npts : plan->npts;
+        ta.npts = plan->npts;
+        // enough chunks to fill the chip, but long enough to amortise the tile flushes
+        int64_t chunk = std::max<int64_t>(4096, (plan->npts + 4 * ctx->num_cu - 1) / (4 * (int64_t)ctx->num_cu));
+        ta.chunk = chunk;
+        ta.coef = w->d_coef;
+        ta.degree = w->p.degree;
+        ta.mode = mode;
+        ta.channels = channels;
+        ta.gacc = gacc;
+        ta.cells = g.cells;
+        ta.scale = d_scale;
+        const size_t tile_lds = (size_t)channels * tg.ext[0] * tg.ext[1] * tg.ext[2] * sizeof(double);
+        dim3 grid((unsigned)((plan->npts + chunk - 1) / chunk), nbatch);
+        hipError_t e;
+        {
+            KernelTimer timer("spread", stream);
+            if (plan->dim == 1) e = launch_tile_d<1>(w->p.w, grid, tile_lds, stream, ta);
+            else if (plan->dim == 2) e = launch_tile_d<2>(w->p.w, grid, tile_lds, stream, ta);
+            else e = launch_tile_d<3>(w->p.w, grid, tile_lds, stream, ta);
+        }
+        if (e != hipSuccess) {
+            set_error("tiled spread kernel launch failed: %s", hipGetErrorString(e));
+            return EFGP_EHIP;
+        }
+        const int blocks = (int)((g.cells + 63) / 64);
+        hipLaunchKernelGGL((reduce_slabs_kernel<true>), dim3(blocks, nbatch), dim3(512), 0, stream, (const double*)gacc, 1,
+                           channels, g.cells, (const double*)d_scale, fine);
+        EFGP_HIP_CHECK(hipGetLastError());
+        hipfftHandle fh;
+        rc = fft_plan(ctx, plan->dim, g.nf, nbatch, stream, &fh);
+        if (rc != EFGP_OK) return rc;
+        EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)fine, (hipfftDoubleComplex*)fine,
+                                     isign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
+        *fine_out = fine;
+        return EFGP_OK;
+    }
     int nwg = 1;
     if (use_lds) {
         int per_cu = std::max(1, std::min(2, (int)((size_t)ctx->max_lds / std::max<size_t>(lds_bytes, 1))));
@@ -723,8 +1179,8 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         if (need_max) {
             EFGP_HIP_CHECK(hipMemsetAsync(d_cmax, 0, sizeof(unsigned long long), stream));
             const int64_t nvals = (int64_t)nbatch * plan->npts * (mode == STR_COMPLEX ? 2 : 1);
-            const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nvals + 1023) / 1024, 1024));
-            hipLaunchKernelGGL(maxabs_kernel, dim3(blocks), dim3(256), 0, stream, c, nvals, d_cmax);
+            const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nvals + 8191) / 8192, 256));
+            hipLaunchKernelGGL(maxabs_kernel, dim3(blocks), dim3(1024), 0, stream, c, nvals, d_cmax);
             EFGP_HIP_CHECK(hipGetLastError());
         }
         hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream,
@@ -821,6 +1277,7 @@ int efgp_nufft_create(efgp_nufft_t** plan_out, int device, int dim, int64_t npts
 int efgp_nufft_destroy(efgp_nufft_t* plan) {
     if (!plan) return EFGP_OK;
     DeviceGuard guard(plan->device);
+    for (BinSet* b : plan->bins) free_binset(plan->ctx, b);
     delete plan;
     return EFGP_OK;
 }

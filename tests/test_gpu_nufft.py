@@ -112,3 +112,38 @@ def test_type1_edge_cases():
     c = torch.tensor([1.0, -2.0, 0.5], dtype=torch.float64)
     plan = NufftPlan(x.cuda(), 0.013, 1e-9)
     assert _rel(plan.type1(c.cuda(), (33, 33)), O.nudft_type1(x, 0.013, c, (33, 33))) < 1e-7
+
+
+@pytest.mark.parametrize("d,nm,tol,N", [(2, 141, 1e-7, 40000), (3, 21, 1e-6, 36000), (3, 37, 1e-4, 50000), (2, 24, 1e-12, 40000)])
+def test_type1_tiled_large_grid(d, nm, tol, N):
+    """Fine grids beyond LDS with many points: tile-sorted LDS spreader (fixed point), incl. the fused pair."""
+    from efgp_hip import NufftPlan
+    from oracle import efgp_oracle as O
+    x = _points(N, d, 40 + d, -1.0, 1.0)
+    h = 0.45
+    g = torch.Generator().manual_seed(9)
+    c = torch.complex(torch.randn(2, N, generator=g, dtype=torch.float64), torch.randn(2, N, generator=g, dtype=torch.float64))
+    plan = NufftPlan(x.cuda(), h, tol)
+    out = plan.type1(c.cuda(), (nm,) * d)
+    ref = O.nudft_type1(x, h, c, (nm,) * d)
+    assert _rel(out, ref) < 5 * tol + 1e-13
+    # bitwise reproducible (integer accumulation): a second call gives identical bits
+    out2 = plan.type1(c.cuda(), (nm,) * d)
+    assert torch.equal(out, out2)
+    y = torch.randn(N, generator=g, dtype=torch.float64)
+    small = (nm + 1) // 2 if ((nm + 1) // 2) % 2 == 1 else (nm + 1) // 2 - 1
+    Fy, v = plan.type1_pair(y.cuda(), (small,) * d, (nm,) * d)
+    assert _rel(Fy, O.nudft_type1(x, h, y, (small,) * d)) < 5 * tol + 1e-13
+    assert _rel(v, O.nudft_type1(x, h, torch.ones(N, dtype=torch.float64), (nm,) * d)) < 5 * tol + 1e-13
+
+
+def test_type1_lds_path_is_bitwise_reproducible():
+    from efgp_hip import NufftPlan
+    N = 50000
+    x = _points(N, 2, 77)
+    g = torch.Generator().manual_seed(10)
+    y = torch.randn(N, generator=g, dtype=torch.float64)
+    plan = NufftPlan(x.cuda(), 0.346, 1e-7)
+    a = plan.type1_pair(y.cuda(), (23, 23), (45, 45))
+    b = plan.type1_pair(y.cuda(), (23, 23), (45, 45))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
