@@ -173,6 +173,16 @@ def main():
     torch.cuda.synchronize(dev)
     cg_rhs_iter_per_s = B * itb / (time.perf_counter() - t3)
 
+    # one hyper-gradient step (the reference's training-loop unit, test_timing_profiling.py:94-111), T = 5 probes
+    for _ in range(2):
+        model.compute_gradients(trace_samples=5, cg_tol=1e-3)
+    barrier()
+    t4 = time.perf_counter()
+    for _ in range(10):
+        model.compute_gradients(trace_samples=5, cg_tol=1e-3)
+    barrier()
+    grad_step_ms = 1e3 * (time.perf_counter() - t4) / 10
+
     if rank == 0:
         m = (mtot - 1) // 2
         out_bytes = 16 * (mtot ** DIM + (4 * m + 1) ** DIM)
@@ -204,6 +214,7 @@ def main():
             "cg_us_per_iter": 1e6 / cg_iter_per_s,
             "cg_rhs_iter_per_s_batch64": cg_rhs_iter_per_s,
             "points_per_s": N * world * fits_per_s,
+            "gradient_step_ms_T5": grad_step_ms,
             "roofline": {"bound": "hbm", "kernel": "spread_kernel (fused F*y + Toeplitz-vector pass, LDS-resident fine grid)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,

@@ -27,7 +27,61 @@ constexpr int kSpreadThreads = 1024;
 constexpr int kInterpThreads = 512;
 constexpr double kFixMagic = 6755399441055744.0;   // 1.5 * 2^52: adding it rounds to an integer in the mantissa
 
-enum StrengthMode { STR_REAL = 0, STR_COMPLEX = 1, STR_REAL_AND_ONES = 2, STR_ONES = 3 };
+enum StrengthMode {
+    STR_REAL = 0,            // one real row per fine grid
+    STR_COMPLEX = 1,         // one complex row (re, im channels)
+    STR_REAL_AND_ONES = 2,   // (y, 1): the fit-time pair
+    STR_ONES = 3,
+    STR_REAL_PAIR = 4,       // two real rows (2g, 2g+1) share one complex fine grid
+    STR_RNG = 5,             // one Rademacher row generated in the kernel
+    STR_RNG_PAIR = 6         // two Rademacher rows
+};
+
+// counter-based Rademacher probe: sign(seed, row, point index) -- splitmix64 finaliser
+__host__ __device__ __forceinline__ unsigned long long efgp_mix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ double efgp_rademacher(unsigned long long seed, long long row, long long n) {
+    const unsigned long long r = efgp_mix64(seed ^ efgp_mix64((unsigned long long)row * 0xD1342543DE82EF95ull +
+                                                             (unsigned long long)n));
+    return (r >> 63) ? 1.0 : -1.0;
+}
+
+struct StrengthSrc {
+    const double* c;          // base pointer of all rows (layout by mode)
+    int64_t npts;             // row length
+    int mode;
+    unsigned long long seed;
+    int64_t index_offset;     // added to the point index for the RNG (global index of this shard's first point)
+};
+
+// strengths (c0, c1) of point `n` (original index) for fine grid `g`
+__device__ __forceinline__ void fetch_strength(const StrengthSrc& s, int g, int64_t n, double& c0, double& c1) {
+    c0 = 1.0;
+    c1 = 1.0;
+    switch (s.mode) {
+        case STR_REAL: c0 = s.c[(int64_t)g * s.npts + n]; break;
+        case STR_COMPLEX: {
+            const double2 cc = reinterpret_cast<const double2*>(s.c)[(int64_t)g * s.npts + n];
+            c0 = cc.x;
+            c1 = cc.y;
+        } break;
+        case STR_REAL_AND_ONES: c0 = s.c[n]; break;
+        case STR_REAL_PAIR:
+            c0 = s.c[(int64_t)(2 * g) * s.npts + n];
+            c1 = s.c[(int64_t)(2 * g + 1) * s.npts + n];
+            break;
+        case STR_RNG: c0 = efgp_rademacher(s.seed, g, n + s.index_offset); break;
+        case STR_RNG_PAIR:
+            c0 = efgp_rademacher(s.seed, 2 * g, n + s.index_offset);
+            c1 = efgp_rademacher(s.seed, 2 * g + 1, n + s.index_offset);
+            break;
+        default: break;
+    }
+}
 
 struct GridGeom {
     int64_t nf[3];      // fine-grid size per dimension (unused dims = 1)
@@ -73,13 +127,11 @@ __device__ __forceinline__ int wrap(int i, int nf) { return i >= nf ? i - nf : i
 // ------------------------------------------------------------------------------------------
 struct SpreadArgs {
     const double* x;
-    const double* c;          // strengths (layout by mode); batch stride c_stride doubles
-    int64_t c_stride;
+    StrengthSrc src;
     int64_t npts;
     GridGeom g;
     const double* coef;       // [degree+1][W]
     int degree;
-    int mode;                 // StrengthMode
     int channels;             // 1 or 2
     double* slabs;            // [batch][nslab][channels][cells]  (int64 fixed point when USE_LDS)
     int nslab;
@@ -115,20 +167,11 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
     const int64_t per = (a.npts + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < a.npts ? lo + per : a.npts;
-    const double* cb = a.c ? a.c + (int64_t)batch * a.c_stride : nullptr;
     const int nf0 = (int)a.g.nf[0], nf1 = (int)a.g.nf[1], nf2 = (int)a.g.nf[2];
 
     for (int64_t n = lo + threadIdx.x; n < hi; n += kSpreadThreads) {
-        double c0 = 1.0, c1 = 1.0;
-        if (a.mode == STR_REAL) {
-            c0 = cb[n];
-        } else if (a.mode == STR_COMPLEX) {
-            const double2 cc = reinterpret_cast<const double2*>(cb)[n];
-            c0 = cc.x;
-            c1 = cc.y;
-        } else if (a.mode == STR_REAL_AND_ONES) {
-            c0 = cb[n];
-        }
+        double c0, c1;
+        fetch_strength(a.src, batch, n, c0, c1);
         if (USE_LDS) {
             c0 *= S;
             c1 *= S;
@@ -204,6 +247,13 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
         __syncthreads();
         for (int64_t i = threadIdx.x; i < C * cells; i += kSpreadThreads) slab[i] = lds[i];
     }
+}
+
+// out[b][n] = the +-1 probe the spread kernels generate for (seed, row b, point n + index_offset)
+__global__ void rademacher_fill_kernel(unsigned long long seed, int64_t npts, int64_t index_offset, double* __restrict__ out) {
+    const int row = blockIdx.y;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < npts; n += (int64_t)gridDim.x * blockDim.x)
+        out[(int64_t)row * npts + n] = efgp_rademacher(seed, row, n + index_offset);
 }
 
 // max |c| over n doubles as an ordered bit pattern (non-negative doubles compare like integers).
@@ -414,13 +464,11 @@ struct TileSpreadArgs {
     const double* xs;         // tile-sorted coordinates
     const int* order;         // sorted position -> original index
     const int* start;         // [nbins + 1]
-    const double* c;
-    int64_t c_stride;
+    StrengthSrc src;
     int64_t npts;
     int64_t chunk;            // sorted points per workgroup
     const double* coef;
     int degree;
-    int mode;
     int channels;
     long long* gacc;          // [batch][channels][cells] int64 fixed-point global grid (pre-zeroed)
     int64_t cells;
@@ -440,7 +488,6 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_tile_kernel(TileSpreadA
     const int64_t hi = lo + a.chunk < a.npts ? lo + a.chunk : a.npts;
     if (lo >= hi) return;
     const double S = a.scale[0];
-    const double* cb = a.c ? a.c + (int64_t)batch * a.c_stride : nullptr;
     long long* gacc = a.gacc + (int64_t)batch * C * a.cells;
     // first tile that contains sorted position `lo` (binary search by one lane)
     if (threadIdx.x == 0) {
@@ -467,17 +514,8 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_tile_kernel(TileSpreadA
         for (int i = threadIdx.x; i < C * tcells; i += kSpreadThreads) lds[i] = 0.0;
         __syncthreads();
         for (int64_t n = cur + threadIdx.x; n < seg_hi; n += kSpreadThreads) {
-            double c0 = 1.0, c1 = 1.0;
-            if (a.mode != STR_ONES) {
-                const int64_t src = a.order[n];
-                if (a.mode == STR_COMPLEX) {
-                    const double2 cc = reinterpret_cast<const double2*>(cb)[src];
-                    c0 = cc.x;
-                    c1 = cc.y;
-                } else {
-                    c0 = cb[src];
-                }
-            }
+            double c0, c1;
+            fetch_strength(a.src, batch, a.src.mode == STR_ONES ? 0 : (int64_t)a.order[n], c0, c1);
             c0 *= S;
             c1 *= S;
             double v0[W], v1[W], v2[W];
@@ -569,6 +607,7 @@ __device__ __forceinline__ int64_t mode_of_slot(int64_t slot, int64_t nm, int mo
 
 // type 1: out[b][slot] = fac * FFT(fine)[k mod nf]; optional Hermitian split for the (y, ones) pair
 //   part = 0: plain;  part = 1: (H[k] + conj(H[-k]))/2;  part = 2: (H[k] - conj(H[-k]))/(2i)
+//   part = 3: fine grid g holds real rows (2g, 2g+1): both parts are written, to out rows 2g and 2g+1
 __global__ void deconvolve_kernel(const double2* __restrict__ fine, int64_t cells, ModeGeom m, int part,
                                   double2* __restrict__ out) {
     const int batch = blockIdx.y;
@@ -596,8 +635,14 @@ __global__ void deconvolve_kernel(const double2* __restrict__ fine, int64_t cell
             r = make_double2(H.x * f, H.y * f);
         } else {
             double2 G = F[idxn];        // H[-k]
-            if (part == 1) r = make_double2(0.5 * (H.x + G.x) * f, 0.5 * (H.y - G.y) * f);
-            else r = make_double2(0.5 * (H.y + G.y) * f, 0.5 * (G.x - H.x) * f);
+            const double2 r1 = make_double2(0.5 * (H.x + G.x) * f, 0.5 * (H.y - G.y) * f);
+            const double2 r2 = make_double2(0.5 * (H.y + G.y) * f, 0.5 * (G.x - H.x) * f);
+            if (part == 3) {
+                out[(int64_t)(2 * batch) * m.total + t] = r1;
+                out[(int64_t)(2 * batch + 1) * m.total + t] = r2;
+                continue;
+            }
+            r = part == 1 ? r1 : r2;
         }
         out[(int64_t)batch * m.total + t] = r;
     }
@@ -1075,10 +1120,21 @@ static hipError_t launch_tile_d(int W, dim3 grid, size_t lds_bytes, hipStream_t 
 
 // spread + reduce + FFT; leaves the transformed fine grids in SLOT_FINE
 static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int mode, int nbatch, int isign,
-                          hipStream_t stream, double2** fine_out) {
+                          hipStream_t stream, double2** fine_out, unsigned long long seed = 0, int64_t index_offset = 0) {
     DeviceCtx* ctx = plan->ctx;
     const GridGeom g = make_geom(plan, w);
-    const int channels = (mode == STR_COMPLEX || mode == STR_REAL_AND_ONES) ? 2 : 1;
+    const int channels = (mode == STR_COMPLEX || mode == STR_REAL_AND_ONES || mode == STR_REAL_PAIR || mode == STR_RNG_PAIR) ? 2 : 1;
+    // strengths read from memory need a max|c| pass for the fixed-point scale; generated / implicit ones are +-1
+    const bool need_max = (mode == STR_REAL || mode == STR_COMPLEX || mode == STR_REAL_AND_ONES || mode == STR_REAL_PAIR);
+    const double floor_bound = (mode == STR_REAL_AND_ONES || mode == STR_ONES || mode == STR_RNG || mode == STR_RNG_PAIR) ? 1.0 : 0.0;
+    const int64_t nvals = (mode == STR_REAL_AND_ONES) ? plan->npts
+                          : (int64_t)nbatch * plan->npts * ((mode == STR_COMPLEX || mode == STR_REAL_PAIR) ? 2 : 1);
+    StrengthSrc src;
+    src.c = c;
+    src.npts = plan->npts;
+    src.mode = mode;
+    src.seed = seed;
+    src.index_offset = index_offset;
     const size_t lds_bytes = (size_t)channels * (size_t)g.cells * sizeof(double);
     const bool use_lds = lds_bytes <= (size_t)ctx->max_lds && plan->npts > 0;
     // grids beyond LDS: tile-sorted points + LDS tiles (large N), else global atomics (small N)
@@ -1097,10 +1153,8 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         double* d_scale = (double*)misc;
         unsigned long long* d_cmax = (unsigned long long*)(misc + 32);
         EFGP_HIP_CHECK(hipMemsetAsync(gacc, 0, acc_bytes, stream));
-        const bool need_max = (mode != STR_ONES);
         if (need_max) {
             EFGP_HIP_CHECK(hipMemsetAsync(d_cmax, 0, sizeof(unsigned long long), stream));
-            const int64_t nvals = (int64_t)nbatch * plan->npts * (mode == STR_COMPLEX ? 2 : 1);
             const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nvals + 8191) / 8192, 256));
             hipLaunchKernelGGL(maxabs_kernel, dim3(blocks), dim3(1024), 0, stream, c, nvals, d_cmax);
             EFGP_HIP_CHECK(hipGetLastError());
@@ -1108,22 +1162,20 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         // the global int64 grid sums over ALL points: bound the scale with N instead of points per workgroup
         hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream,
                            need_max ? (const unsigned long long*)d_cmax : (const unsigned long long*)nullptr,
-                           (mode == STR_REAL_AND_ONES || mode == STR_ONES) ? 1.0 : 0.0, plan->npts, d_scale);
+                           floor_bound, plan->npts, d_scale);
         EFGP_HIP_CHECK(hipGetLastError());
         TileSpreadArgs ta;
         ta.t = tg;
         ta.xs = bins->xs;
         ta.order = bins->order;
         ta.start = bins->start;
-        ta.c = c;
-        ta.c_stride = (mode == STR_COMPLEX) ? 2 * plan->npts : plan->npts;
+        ta.src = src;
         ta.npts = plan->npts;
         // enough chunks to fill the chip, but long enough to amortise the tile flushes
         int64_t chunk = std::max<int64_t>(4096, (plan->npts + 4 * ctx->num_cu - 1) / (4 * (int64_t)ctx->num_cu));
         ta.chunk = chunk;
         ta.coef = w->d_coef;
         ta.degree = w->p.degree;
-        ta.mode = mode;
         ta.channels = channels;
         ta.gacc = gacc;
         ta.cells = g.cells;
@@ -1175,29 +1227,25 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     const int64_t per = (plan->npts + nwg - 1) / std::max(nwg, 1);
     if (use_lds) {
         // fixed-point scale from max |c| (device side, no host round trip)
-        const bool need_max = (mode != STR_ONES);
         if (need_max) {
             EFGP_HIP_CHECK(hipMemsetAsync(d_cmax, 0, sizeof(unsigned long long), stream));
-            const int64_t nvals = (int64_t)nbatch * plan->npts * (mode == STR_COMPLEX ? 2 : 1);
             const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nvals + 8191) / 8192, 256));
             hipLaunchKernelGGL(maxabs_kernel, dim3(blocks), dim3(1024), 0, stream, c, nvals, d_cmax);
             EFGP_HIP_CHECK(hipGetLastError());
         }
         hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream,
                            need_max ? (const unsigned long long*)d_cmax : (const unsigned long long*)nullptr,
-                           (mode == STR_REAL_AND_ONES || mode == STR_ONES) ? 1.0 : 0.0, per, d_scale);
+                           floor_bound, per, d_scale);
         EFGP_HIP_CHECK(hipGetLastError());
     }
 
     SpreadArgs a;
     a.x = plan->x;
-    a.c = c;
-    a.c_stride = (mode == STR_COMPLEX) ? 2 * plan->npts : plan->npts;
+    a.src = src;
     a.npts = plan->npts;
     a.g = g;
     a.coef = w->d_coef;
     a.degree = w->p.degree;
-    a.mode = mode;
     a.channels = channels;
     a.slabs = slabs;
     a.nslab = nslab;
@@ -1282,6 +1330,40 @@ int efgp_nufft_destroy(efgp_nufft_t* plan) {
     return EFGP_OK;
 }
 
+// shared by the strengths-from-memory and the generated-probe entry points: real rows are processed two
+// per fine grid (re/im channels, separated after the FFT by Hermitian symmetry), an odd last row alone
+static int type1_real_rows(efgp_nufft_s* plan, WindowSet* w, const double* c, bool rng, unsigned long long seed,
+                           int64_t index_offset, int nbatch, const int64_t* n_modes, int isign, int modeord, void* out,
+                           hipStream_t stream) {
+    int64_t total = 1;
+    for (int a = 0; a < plan->dim; ++a) total *= n_modes[a];
+    const int npair = nbatch / 2;
+    double2* fine = nullptr;
+    if (npair > 0) {
+        int rc = spread_and_fft(plan, w, c, rng ? STR_RNG_PAIR : STR_REAL_PAIR, npair, isign, stream, &fine, seed, index_offset);
+        if (rc != EFGP_OK) return rc;
+        // for isign = +1 the roles of k and -k swap in the Hermitian split; conjugating H handles both signs:
+        // the split below assumes the forward (isign = -1) transform, which is what the reference uses for type 1
+        rc = run_deconvolve(plan, w, fine, n_modes, modeord, 3, npair, out, stream);
+        if (rc != EFGP_OK) return rc;
+    }
+    if (nbatch & 1) {
+        const int last = nbatch - 1;
+        // single real row: offset the source / the RNG row so that it addresses row `last`
+        int rc;
+        if (rng) {
+            // STR_RNG uses the fine-grid index as row: shift the seed domain by generating row `last` explicitly
+            rc = spread_and_fft(plan, w, nullptr, STR_RNG, 1, isign, stream, &fine, seed ^ efgp_mix64(0xA5A5A5A5ull + (unsigned long long)last), index_offset);
+        } else {
+            rc = spread_and_fft(plan, w, c + (int64_t)last * plan->npts, STR_REAL, 1, isign, stream, &fine);
+        }
+        if (rc != EFGP_OK) return rc;
+        rc = run_deconvolve(plan, w, fine, n_modes, modeord, 0, 1, (double2*)out + (int64_t)last * total, stream);
+        if (rc != EFGP_OK) return rc;
+    }
+    return EFGP_OK;
+}
+
 int efgp_nufft_type1(efgp_nufft_t* plan, const void* c, int c_is_complex, int nbatch, const int64_t* n_modes,
                      int isign, int modeord, void* out, void* stream_) {
     EFGP_REQUIRE(plan && n_modes && out, "efgp_nufft_type1: null argument");
@@ -1294,10 +1376,56 @@ int efgp_nufft_type1(efgp_nufft_t* plan, const void* c, int c_is_complex, int nb
     WindowSet* w = nullptr;
     int rc = get_window(plan, n_modes, stream, &w);
     if (rc != EFGP_OK) return rc;
+    if (!c_is_complex && isign == -1 && plan->npts > 0)
+        return type1_real_rows(plan, w, (const double*)c, false, 0, 0, nbatch, n_modes, isign, modeord, out, stream);
     double2* fine = nullptr;
     rc = spread_and_fft(plan, w, (const double*)c, c_is_complex ? STR_COMPLEX : STR_REAL, nbatch, isign, stream, &fine);
     if (rc != EFGP_OK) return rc;
     return run_deconvolve(plan, w, fine, n_modes, modeord, 0, nbatch, out, stream);
+}
+
+int efgp_nufft_type1_rademacher(efgp_nufft_t* plan, uint64_t seed, int64_t index_offset, int nbatch,
+                                const int64_t* n_modes, int modeord, void* out, void* stream_) {
+    EFGP_REQUIRE(plan && n_modes && out, "efgp_nufft_type1_rademacher: null argument");
+    EFGP_REQUIRE(nbatch >= 1, "efgp_nufft_type1_rademacher: nbatch must be >= 1");
+    for (int a = 0; a < plan->dim; ++a) EFGP_REQUIRE(n_modes[a] >= 1, "efgp_nufft_type1_rademacher: n_modes[%d] < 1", a);
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(plan->device);
+    WindowSet* w = nullptr;
+    int rc = get_window(plan, n_modes, stream, &w);
+    if (rc != EFGP_OK) return rc;
+    if (plan->npts == 0) {
+        int64_t total = 1;
+        for (int a = 0; a < plan->dim; ++a) total *= n_modes[a];
+        EFGP_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)nbatch * total * sizeof(double2), stream));
+        return EFGP_OK;
+    }
+    return type1_real_rows(plan, w, nullptr, true, (unsigned long long)seed, index_offset, nbatch, n_modes, -1, modeord, out,
+                           stream);
+}
+
+int efgp_rademacher_fill(int device, uint64_t seed, int64_t index_offset, int nbatch, int64_t npts, double* out,
+                         void* stream_) {
+    EFGP_REQUIRE(out || npts == 0, "efgp_rademacher_fill: null out");
+    EFGP_REQUIRE(nbatch >= 1 && npts >= 0, "efgp_rademacher_fill: bad sizes");
+    if (npts == 0) return EFGP_OK;
+    if (!device_ctx(device)) return EFGP_EHIP;
+    DeviceGuard guard(device);
+    hipStream_t stream = (hipStream_t)stream_;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((npts + 255) / 256, 4096));
+    // rows of an odd last batch element are generated with the same seed derivation as type1_real_rows
+    const int npair_rows = (nbatch / 2) * 2;
+    if (npair_rows > 0)
+        hipLaunchKernelGGL(rademacher_fill_kernel, dim3(blocks, npair_rows), dim3(256), 0, stream, (unsigned long long)seed, npts,
+                           index_offset, out);
+    if (nbatch & 1) {
+        const int last = nbatch - 1;
+        hipLaunchKernelGGL(rademacher_fill_kernel, dim3(blocks, 1), dim3(256), 0, stream,
+                           (unsigned long long)seed ^ efgp_mix64(0xA5A5A5A5ull + (unsigned long long)last), npts, index_offset,
+                           out + (int64_t)last * npts);
+    }
+    EFGP_HIP_CHECK(hipGetLastError());
+    return EFGP_OK;
 }
 
 int efgp_nufft_type1_pair(efgp_nufft_t* plan, const double* y, const int64_t* n_modes_y, void* out_y,

@@ -68,6 +68,14 @@ class PointShards:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return [float(v) for v in t.tolist()]
 
+    def exclusive_offset(self, n_local, device):
+        """Global index of this rank's first point (ranks hold consecutive blocks of the observations)."""
+        if not self.active:
+            return 0
+        counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(self.world_size)]
+        dist.all_gather(counts, torch.tensor([int(n_local)], dtype=torch.int64, device=device), group=self.group)
+        return int(sum(int(c.item()) for c in counts[:self.rank]))
+
     def minmax(self, lo, hi):
         """Global per-dimension min / max of the point coordinates (for the domain length L)."""
         if not self.active:

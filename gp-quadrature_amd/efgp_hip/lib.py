@@ -45,6 +45,8 @@ _SIGNATURES = {
     "efgp_nufft_create": (_I, [C.POINTER(_VP), _I, _I, _I64, _VP, C.POINTER(_D), _D, _D]),
     "efgp_nufft_destroy": (_I, [_VP]),
     "efgp_nufft_type1": (_I, [_VP, _VP, _I, _I, _PI64, _I, _I, _VP, _VP]),
+    "efgp_nufft_type1_rademacher": (_I, [_VP, C.c_uint64, _I64, _I, _PI64, _I, _VP, _VP]),
+    "efgp_rademacher_fill": (_I, [_I, C.c_uint64, _I64, _I, _I64, _VP, _VP]),
     "efgp_nufft_type1_pair": (_I, [_VP, _VP, _PI64, _VP, _PI64, _VP, _VP]),
     "efgp_nufft_type2": (_I, [_VP, _VP, _I, _PI64, _I, _I, _VP, _I, _VP]),
     "efgp_toeplitz_create": (_I, [C.POINTER(_VP), _I, _I, _PI64, _VP, _I, _VP]),

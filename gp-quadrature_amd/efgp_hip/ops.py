@@ -87,6 +87,15 @@ class NufftPlan:
                                          _ptr(out), _stream(self.dev)), "efgp_nufft_type1")
         return out if batched else out[0]
 
+    def type1_rademacher(self, seed, nbatch, n_modes, index_offset=0, modeord=0):
+        """F* Z for Z[b,n] = +-1 generated in the kernel from (seed, b, n + index_offset) -> (B, *n_modes)."""
+        out = torch.empty((int(nbatch),) + tuple(int(m) for m in n_modes), dtype=_CD, device=self.dev)
+        with torch.cuda.device(self.dev):
+            check(lib().efgp_nufft_type1_rademacher(self._h, int(seed) & (2 ** 64 - 1), int(index_offset), int(nbatch),
+                                                    _i64(n_modes), int(modeord), _ptr(out), _stream(self.dev)),
+                  "efgp_nufft_type1_rademacher")
+        return out
+
     def type1_pair(self, y, n_modes_y, n_modes_one):
         """One pass over the points: (F* y on n_modes_y, F* 1 on n_modes_one)."""
         yy = y.to(device=self.dev, dtype=_RD).contiguous()
@@ -192,6 +201,15 @@ def vdot_real(a, b):
         check(lib().efgp_vdot_real(dev.index, _ptr(aa), int(aa.is_complex()), _ptr(bb), int(bb.is_complex()),
                                    aa.numel(), C.byref(out), _stream(dev)), "efgp_vdot_real")
     return float(out.value)
+
+
+def rademacher_fill(dev, seed, nbatch, npts, index_offset=0):
+    """The +-1 probes `NufftPlan.type1_rademacher` uses, materialised as a (nbatch, npts) float64 tensor."""
+    out = torch.empty((int(nbatch), int(npts)), dtype=_RD, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().efgp_rademacher_fill(dev.index, int(seed) & (2 ** 64 - 1), int(index_offset), int(nbatch), int(npts),
+                                         _ptr(out), _stream(dev)), "efgp_rademacher_fill")
+    return out
 
 
 def kernel_timing(enable):

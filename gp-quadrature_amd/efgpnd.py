@@ -300,7 +300,7 @@ def efgpnd_gradient_batched(
         use_trace_cg_preconditioner: bool = True,
         log_marginal_probes=100, log_marginal_steps=25,
         probes_Z: Optional[torch.Tensor] = None, probes_V: Optional[torch.Tensor] = None,
-        shards: Optional[PointShards] = None):
+        shards: Optional[PointShards] = None, trace_mode: str = "adjoint", probe_seed: Optional[int] = None):
     """d(negative log marginal likelihood)/d(kernel hypers..., sigma^2) = (term1 - term2)/2 with
     Hutchinson trace estimates (data-space probes Z for non-variance kernel hypers, feature-space
     probes V for the noise) and CG solves.  ``x0, x1`` are ignored as in the reference (:72-73).
@@ -308,8 +308,22 @@ def efgpnd_gradient_batched(
     Extra keyword arguments (not in the reference): ``probes_Z`` (T,N) / ``probes_V`` (T,M) inject the
     +-1 probes (the reference draws them from torch's generator at :179-182 and :199-202), and
     ``shards`` sums the gridded partials / N-length scalars over point shards.
-    Stage timers (seconds) are written to ``stats_out['stage_sec']`` with the reference's stage names.
+    Stage timers (seconds) are written to ``stats_out['stage_sec']`` with the reference's stage names (host
+    clock; with ``do_profiling=True`` the device is synchronised at every stage boundary so they are exact).
+
+    ``trace_mode``:
+      * ``"adjoint"`` (default) evaluates every N-length inner product of the reference in feature space
+        through the adjoint identity  sum_n z_n (F g)_n = <F* z, g>  and  |F g|^2 = <g, T g>:
+        sum_n Z (rhs - F(ws beta))/sigma^2 = Re<F*Z, D'F*Z - ws beta>/sigma^2,  y.z = Re<F*y, g>,  |z|^2 = Re<g, T g>
+        (g = ws beta, z = F g).  Same estimator, same probes, but NO type-2 pass over the N points (the
+        reference spends 1 + 2T of them, :149, :189, :234) and, without injected probes, the +-1 draws are
+        generated inside the spread kernel (``probe_seed``) so Z never exists in memory.  Agrees with the
+        literal sequence to the NUFFT tolerance.
+      * ``"reference"`` follows the reference's operation sequence literally (type-2 passes included).
     """
+    if trace_mode not in ("adjoint", "reference"):
+        raise ValueError(f"trace_mode must be 'adjoint' or 'reference', got {trace_mode!r}")
+    adjoint = trace_mode == "adjoint"
     num_hypers = kernel.num_hypers
     if cg_tol is None:
         cg_tol = eps
@@ -319,7 +333,7 @@ def efgpnd_gradient_batched(
     tic = [time.perf_counter()]
 
     def lap(name):
-        if do_profiling or stats_out is not None:
+        if do_profiling:                      # device-accurate stage times only when asked: a sync per stage is not free
             torch.cuda.synchronize(dev)
         now = time.perf_counter()
         stages[name] = stages.get(name, 0.0) + (now - tic[0])
@@ -364,18 +378,25 @@ def efgpnd_gradient_batched(
     beta, mean_iters, _ = cg_solve(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping,
                                    diag=diag if use_mean_cg_preconditioner else None, batched=False)
     beta_raw = beta.clone()
-    beta_s = ws * beta
-    z = plan.type2(beta_s, grid.shape)                       # F (D beta), complex (N,)
-    alpha = (yd - z) / sig
+    beta_s = ws * beta                                        # g = D beta
+    Tg = top.apply(beta_s)
+    if not adjoint:
+        z = plan.type2(beta_s, grid.shape)                   # F g, complex (N,)
+        alpha = (yd - z) / sig
     lap("4_solve_cg")
 
     # 5) term 2 -------------------------------------------------------------------------------
-    fadj_alpha = (Fy - top.apply(beta_s)) / sig               # = F* alpha without another pass over N
+    fadj_alpha = (Fy - Tg) / sig                               # = F* alpha without another pass over N
     term2_kernel = torch.stack([vdot_m(fadj_alpha, Dp[:, i] * fadj_alpha) for i in range(kernel_hyper_count)]) \
         if kernel_hyper_count else torch.zeros(0, dtype=torch.float64, device=dev)
-    a_norm_loc = vdot_real(alpha, alpha)
-    y_alpha_loc = vdot_real(yd, alpha)
-    a_norm, y_alpha = shards.sum_scalars([a_norm_loc, y_alpha_loc], dev)
+    if adjoint:
+        yy = shards.sum_scalars([vdot_real(yd, yd)], dev)[0]
+        y_z = float(vdot_m(Fy, beta_s))                        # Re sum_n y_n z_n
+        z_z = float(vdot_m(beta_s, Tg))                        # |F g|^2 = <g, T g>
+        a_norm = (yy - 2.0 * y_z + z_z) / (sig * sig)
+        y_alpha = (yy - y_z) / sig
+    else:
+        a_norm, y_alpha = shards.sum_scalars([vdot_real(alpha, alpha), vdot_real(yd, alpha)], dev)
     if variance_idx is not None:
         variance_scalar = float(kernel.get_hyper("variance"))
         term2_kernel[variance_idx] = (y_alpha - sig * a_norm) / variance_scalar
@@ -385,19 +406,27 @@ def efgpnd_gradient_batched(
     # 6) Monte-Carlo trace probes ---------------------------------------------------------------
     T = int(trace_samples)
     K = len(trace_idx)
+    Z = None
+    rhs_k = None
     if K > 0:
         if probes_Z is not None:
             Z = probes_Z.detach().to(device=dev, dtype=torch.float64).contiguous()
+            FZ = plan.type1(Z, grid.shape).reshape(T, M)                            # real rows, two per pass
+        elif adjoint:
+            if probe_seed is None:
+                probe_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            offset = shards.exclusive_offset(N_local, dev)
+            FZ = plan.type1_rademacher(probe_seed, T, grid.shape, index_offset=offset).reshape(T, M)
         else:
             Z = torch.empty((T, N_local), device=dev, dtype=torch.float64).bernoulli_(0.5).mul_(2).sub_(1)
-        FZ = plan.type1(Z, grid.shape).reshape(T, M)
+            FZ = plan.type1(Z, grid.shape).reshape(T, M)
         shards.sum_(FZ)
         DFZ = torch.stack([Dp[:, i] * FZ for i in trace_idx], dim=0).reshape(K * T, M)
-        rhs_k = plan.type2(DFZ, grid.shape, batched=True)                       # (K*T, N) complex
+        if not adjoint:
+            rhs_k = plan.type2(DFZ, grid.shape, batched=True)                       # (K*T, N) complex
         B_k = ws * top.apply(DFZ)
     else:
-        Z = None
-        rhs_k = None
+        DFZ = torch.empty((0, M), dtype=torch.complex128, device=dev)
         B_k = torch.empty((0, M), dtype=torch.complex128, device=dev)
     if probes_V is not None:
         V = probes_V.detach().to(device=dev, dtype=torch.float64).contiguous()
@@ -418,10 +447,15 @@ def efgpnd_gradient_batched(
     term1 = torch.empty(num_hypers, dtype=torch.float64, device=dev)
     Beta_k, Beta_n = Beta_all[:K * T], Beta_all[K * T:]
     if K > 0:
-        fwdB = plan.type2(ws * Beta_k, grid.shape, batched=True)
-        Alpha = (rhs_k - fwdB) / sig                                                # (K*T, N)
-        sums = [vdot_real(Z, Alpha[s * T:(s + 1) * T]) for s in range(K)]         # sum_t sum_n Z*Alpha
-        sums = shards.sum_scalars(sums, dev)
+        if adjoint:
+            # sum_n Z (F(D'F*Z) - F(ws beta))/sigma^2 = Re <F*Z, D'F*Z - ws beta> / sigma^2   (F*Z is already global)
+            diff = (DFZ - ws * Beta_k).reshape(K, T, M)
+            sums = [float((FZ.conj() * diff[slot]).sum().real) / sig for slot in range(K)]
+        else:
+            fwdB = plan.type2(ws * Beta_k, grid.shape, batched=True)
+            Alpha = (rhs_k - fwdB) / sig                                            # (K*T, N)
+            sums = [vdot_real(Z, Alpha[s_ * T:(s_ + 1) * T]) for s_ in range(K)]    # sum_t sum_n Z*Alpha
+            sums = shards.sum_scalars(sums, dev)
         for slot, ki in enumerate(trace_idx):
             term1[ki] = sums[slot] / T
     t1_noise = N / sig - float(((Vc.conj() * Beta_n).sum(dim=1).real / sig).mean())

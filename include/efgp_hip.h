@@ -81,6 +81,17 @@ int efgp_nufft_destroy(efgp_nufft_t* plan);
 int efgp_nufft_type1(efgp_nufft_t* plan, const void* c, int c_is_complex, int nbatch,
                      const int64_t* n_modes, int isign, int modeord, void* out, void* stream);
 
+/* type 1 of Rademacher probes generated inside the spread kernel (the +-1 probes the reference draws at
+ * efgpnd.py:179-182 never have to exist in memory):
+ *     out[b, k] = sum_n Z[b, n] exp(-i k . phi_n),   Z[b, n] = +-1 from a counter-based hash of
+ *     (seed, b, n + index_offset)   (index_offset = global index of this shard's first point).
+ * efgp_rademacher_fill writes the very same Z[b, n] to memory (nbatch x npts doubles) for callers that need
+ * the probes themselves (tests, the reference-order code path). */
+int efgp_nufft_type1_rademacher(efgp_nufft_t* plan, uint64_t seed, int64_t index_offset, int nbatch,
+                                const int64_t* n_modes, int modeord, void* out, void* stream);
+int efgp_rademacher_fill(int device, uint64_t seed, int64_t index_offset, int nbatch, int64_t npts, double* out,
+                         void* stream);
+
 /* Fused fit-time pass over the same points (efgpnd.py:786 and :789-790 / :1395-1421):
  *     out_y[k]    = sum_n y_n exp(-i k . phi_n),  k in the n_modes_y   box (CMCL order)
  *     out_ones[k] = sum_n     exp(-i k . phi_n),  k in the n_modes_one box (CMCL order)

@@ -100,14 +100,17 @@ def test_variance_stochastic_with_recorded_probes(name):
     assert float(np.abs(var.cpu().numpy() - g["var_stochastic"]).max()) < 1e-5 * scale
 
 
+@pytest.mark.parametrize("mode", ["adjoint", "reference"])
 @pytest.mark.parametrize("name", CASES)
-def test_gradient_with_recorded_probes(name):
-    """efgpnd_gradient_batched with the reference's own Rademacher draws (efgpnd.py:179-182,199-202)."""
+def test_gradient_with_recorded_probes(name, mode):
+    """efgpnd_gradient_batched with the reference's own Rademacher draws (efgpnd.py:179-182,199-202):
+    the literal operation sequence ("reference") and the adjoint-identity evaluation (default) both match."""
     g, x, y = load_case(name)
     m = make_model(name, g, x, y, 1e-12)
     Z = g["Z"]
     V = torch.from_numpy(g["V"].astype(np.float64))
-    raw = m.compute_gradients(trace_samples=V.shape[0], nufft_eps=1e-9, cg_tol=1e-12, probes_Z=Z, probes_V=V)
+    raw = m.compute_gradients(trace_samples=V.shape[0], nufft_eps=1e-9, cg_tol=1e-12, probes_Z=Z, probes_V=V,
+                              trace_mode=mode)
     pos = torch.tensor([float(g["lengthscale"]), float(g["variance"]), float(g["sigmasq"])], dtype=torch.float64)
     grad = raw.detach().cpu() / pos
     ref = torch.from_numpy(g["grad"])
@@ -115,3 +118,21 @@ def test_gradient_with_recorded_probes(name):
     scale = float(m.last_gradient_stats["term1"].abs().max())
     assert float((grad - ref).abs().max()) < 1e-5 * scale
     assert m._gp_params.raw.grad is not None
+
+
+def test_gradient_in_kernel_probes_match_materialised_probes():
+    """Probes generated inside the spread kernel (default path) == the same probes written to memory."""
+    from efgp_hip import rademacher_fill
+    name = "c2_se2d_n100000"
+    g, x, y = load_case(name)
+    m = make_model(name, g, x, y, 1e-10)
+    T = 3
+    V = torch.from_numpy(g["V"].astype(np.float64))[:1].repeat(T, 1)
+    g1 = m.compute_gradients(trace_samples=T, nufft_eps=1e-9, cg_tol=1e-10, probes_V=V, probe_seed=12345)
+    Z = rademacher_fill(torch.device("cuda", 0), 12345, T, x.shape[0])
+    assert set(torch.unique(Z).tolist()) == {-1.0, 1.0}
+    assert abs(float(Z.mean())) < 0.01 and abs(float((Z[0] * Z[1]).mean())) < 0.02
+    m._last_gradient_beta = None
+    g2 = m.compute_gradients(trace_samples=T, nufft_eps=1e-9, cg_tol=1e-10, probes_V=V, probes_Z=Z, trace_mode="reference")
+    scale = float(m.last_gradient_stats["term1"].abs().max()) * float(m._gp_params.pos.detach().max())
+    assert float((g1 - g2).abs().max()) < 1e-6 * scale

@@ -147,3 +147,17 @@ def test_type1_lds_path_is_bitwise_reproducible():
     a = plan.type1_pair(y.cuda(), (23, 23), (45, 45))
     b = plan.type1_pair(y.cuda(), (23, 23), (45, 45))
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("d,nm,N,B", [(2, 23, 5000, 5), (2, 141, 40000, 2), (1, 35, 3000, 3), (3, 9, 2000, 1)])
+def test_type1_rademacher_equals_type1_of_filled_probes(d, nm, N, B):
+    from efgp_hip import NufftPlan, rademacher_fill
+    from oracle import efgp_oracle as O
+    x = _points(N, d, 60 + d)
+    plan = NufftPlan(x.cuda(), 0.37, 1e-9)
+    out = plan.type1_rademacher(987654321, B, (nm,) * d, index_offset=17)
+    Z = rademacher_fill(torch.device("cuda", 0), 987654321, B, N, index_offset=17)
+    assert torch.all(Z.abs() == 1.0)
+    assert _rel(out, O.nudft_type1(x, 0.37, Z.cpu(), (nm,) * d)) < 5e-9
+    # real rows from memory take the same paired path and give the same bits
+    assert torch.equal(plan.type1(Z, (nm,) * d), out) or _rel(plan.type1(Z, (nm,) * d), out) < 1e-13
