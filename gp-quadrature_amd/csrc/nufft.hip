@@ -24,7 +24,8 @@
 namespace efgp {
 
 constexpr int kSpreadThreads = 1024;
-constexpr int kInterpThreads = 512;
+constexpr int kInterpThreads = 1024;        // LDS-resident fine grid
+constexpr int kInterpThreadsGlobal = 256;   // fine grid read through L2
 constexpr double kFixMagic = 6755399441055744.0;   // 1.5 * 2^52: adding it rounds to an integer in the mantissa
 
 enum StrengthMode {
@@ -93,9 +94,16 @@ struct GridGeom {
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------
+// The Horner coefficients are read through the CONSTANT address space: the table is never written while a
+// kernel runs, and telling the compiler so lets it use scalar loads (s_load) for these wave-uniform values.
+// With a plain global pointer the interpolation kernels (which also store to global memory) fell back to
+// vector global loads inside the Horner loop -- a chain of ~2*degree dependent L2 round trips per point.
+typedef const __attribute__((address_space(4))) double* const_coef_ptr;
+
 template <int W>
-__device__ __forceinline__ void window_values(const double* __restrict__ coef, int degree, double X, int64_t nf,
+__device__ __forceinline__ void window_values(const double* __restrict__ coef_generic, int degree, double X, int64_t nf,
                                               int& first, double (&val)[W]) {
+    const_coef_ptr coef = (const_coef_ptr)coef_generic;
     // first covered cell and the Horner variable (see EsParams::coef)
     double i0 = ceil(X - 0.5 * W);
     double s = 2.0 * (i0 - X + 0.5 * W) - 1.0;
@@ -148,6 +156,16 @@ __device__ __forceinline__ void lds_add_fixed(double* cell, double a_scaled, dou
     __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(cell), (unsigned long long)m, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// "raw" variant: adds the bit pattern of (v*S + 1.5*2^52) itself.  bits(magic) = 0x4338 << 48 has zero low 48
+// bits, so after n additions the low 48 bits of the cell hold (sum of the rounded integers) mod 2^48, which is
+// the exact sum whenever it is below 2^47 in magnitude (guaranteed by the choice of S); the flush
+// sign-extends bit 47.  Saves the 64-bit subtraction (two VALU instructions) per atomic.
+__device__ __forceinline__ void lds_add_raw(double* cell, double a_scaled, double b) {
+    const double t = fma(a_scaled, b, kFixMagic);
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(cell), (unsigned long long)__double_as_longlong(t),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ long long sext48(long long v) { return (v << 16) >> 16; }
 
 template <int D, int W, bool USE_LDS>
 __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
@@ -249,6 +267,158 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
     }
 }
 
+// LDS-resident spreader with the LAST dimension padded by W-1 halo cells: the innermost stencil loop then
+// needs no wrap arithmetic and its atomics use immediate offsets from one address per stencil row (PMC on the
+// plain kernel: 1365 VALU instructions per point, most of them address / wrap / fixed-point bookkeeping).
+// RAW48: see lds_add_raw.  The halo columns are folded back when the tile is flushed to the slab.
+template <int D, int W, bool RAW48>
+__global__ __launch_bounds__(kSpreadThreads) void spread_pad_kernel(SpreadArgs a) {
+    extern __shared__ double lds[];
+    const int batch = blockIdx.y;
+    const int64_t cells = a.g.cells;
+    const int C = a.channels;
+    const int nf0 = (int)a.g.nf[0], nf1 = (int)a.g.nf[1], nf2 = (int)a.g.nf[2];
+    const int nl = D == 1 ? nf0 : (D == 2 ? nf1 : nf2);            // size of the last (padded) dimension
+    const int pl = nl + W - 1;                                     // padded row length
+    const int rows = (int)(cells / nl);
+    const int plane = rows * pl;                                    // padded cells per channel
+    double* slab = a.slabs + ((int64_t)batch * a.nslab + blockIdx.x) * C * cells;
+    for (int i = threadIdx.x; i < C * plane; i += kSpreadThreads) lds[i] = 0.0;
+    __syncthreads();
+    const double S = a.scale[0];
+    const int64_t per = (a.npts + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per;
+    const int64_t hi = lo + per < a.npts ? lo + per : a.npts;
+    // Bank-balanced lane assignment.  All lanes walk the same stencil offsets, so an atomic wave-instruction
+    // meets no LDS bank conflict inside a 32-lane group when the lanes' first cells differ mod 32 (8-byte
+    // cells over 64 four-byte banks).  Each chunk of 1024 points is counting-sorted by that class in LDS;
+    // lane L of group G takes the G-th point of class L, surplus points of over-full classes fill the lanes
+    // of under-full ones (one pass, every lane busy).  PMC before: 67 % of LDS-active cycles were conflicts.
+    __shared__ int cls_cnt[32];
+    __shared__ int cls_free[33];
+    __shared__ int left_cnt;
+    __shared__ unsigned short cls_list[32][32];
+    __shared__ unsigned short left_list[kSpreadThreads];
+    constexpr bool kBalance = D >= 2;          // 1-D has only W atomics per point: the bookkeeping does not pay
+    for (int64_t cbase = lo; cbase < hi; cbase += kSpreadThreads) {
+      int src = -1;
+      if (!kBalance) {
+        if (cbase + threadIdx.x < hi) src = threadIdx.x;
+      } else {
+        if (threadIdx.x < 32) cls_cnt[threadIdx.x] = 0;
+        if (threadIdx.x == 0) left_cnt = 0;
+        __syncthreads();
+        {
+            const int64_t nn = cbase + threadIdx.x;
+            if (nn < hi) {
+                int lin = 0;
+#pragma unroll
+                for (int q = 0; q < D; ++q) {
+                    const int nfq = (int)a.g.nf[q];
+                    const double Xq = fold(a.g.scale[q] * (a.x[nn * D + q] - a.g.xcen[q]), (double)nfq);
+                    int fq = (int)ceil(Xq - 0.5 * W);
+                    if (fq < 0) fq += nfq;
+                    lin = lin * (q == D - 1 ? pl : nfq) + fq;
+                }
+                const int key = lin & 31;
+                const int r = atomicAdd(&cls_cnt[key], 1);
+                if (r < 32) cls_list[key][r] = (unsigned short)threadIdx.x;
+                else left_list[atomicAdd(&left_cnt, 1)] = (unsigned short)threadIdx.x;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int run = 0;
+            for (int q = 0; q < 32; ++q) {
+                cls_free[q] = run;
+                run += 32 - min(cls_cnt[q], 32);
+            }
+            cls_free[32] = run;
+        }
+        __syncthreads();
+        {
+            const int L = threadIdx.x & 31, G = threadIdx.x >> 5;
+            const int have = min(cls_cnt[L], 32);
+            if (G < have) {
+                src = cls_list[L][G];
+            } else {
+                const int fi = cls_free[L] + (G - have);
+                if (fi < left_cnt) src = left_list[fi];
+            }
+        }
+        __syncthreads();                       // lists are rebuilt by the next chunk
+      }
+        if (src < 0) continue;
+        const int64_t n = cbase + src;
+        double c0, c1;
+        fetch_strength(a.src, batch, n, c0, c1);
+        c0 *= S;
+        c1 *= S;
+        double v0[W], v1[W], v2[W];
+        int f0 = 0, f1 = 0, f2 = 0;
+        {
+            double X = fold(a.g.scale[0] * (a.x[n * D + 0] - a.g.xcen[0]), (double)nf0);
+            window_values<W>(a.coef, a.degree, X, nf0, f0, v0);
+        }
+        if (D > 1) {
+            double X = fold(a.g.scale[1] * (a.x[n * D + 1] - a.g.xcen[1]), (double)nf1);
+            window_values<W>(a.coef, a.degree, X, nf1, f1, v1);
+        }
+        if (D > 2) {
+            double X = fold(a.g.scale[2] * (a.x[n * D + 2] - a.g.xcen[2]), (double)nf2);
+            window_values<W>(a.coef, a.degree, X, nf2, f2, v2);
+        }
+        if (D == 1) {
+            double* p = lds + f0;
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                if (RAW48) lds_add_raw(p + j, c0, v0[j]); else lds_add_fixed(p + j, c0, v0[j]);
+                if (C == 2) { if (RAW48) lds_add_raw(p + plane + j, c1, v0[j]); else lds_add_fixed(p + plane + j, c1, v0[j]); }
+            }
+        } else if (D == 2) {
+#pragma unroll
+            for (int j0 = 0; j0 < W; ++j0) {
+                double* p = lds + wrap(f0 + j0, nf0) * pl + f1;
+                double* q = p + plane;
+                const double a0 = v0[j0] * c0, a1 = v0[j0] * c1;
+#pragma unroll
+                for (int j1 = 0; j1 < W; ++j1) {
+                    if (RAW48) lds_add_raw(p + j1, a0, v1[j1]); else lds_add_fixed(p + j1, a0, v1[j1]);
+                    if (C == 2) { if (RAW48) lds_add_raw(q + j1, a1, v1[j1]); else lds_add_fixed(q + j1, a1, v1[j1]); }
+                }
+            }
+        } else {
+            for (int j0 = 0; j0 < W; ++j0) {
+                const int r0 = wrap(f0 + j0, nf0) * nf1;
+                for (int j1 = 0; j1 < W; ++j1) {
+                    double* p = lds + (r0 + wrap(f1 + j1, nf1)) * pl + f2;
+                    double* q = p + plane;
+                    const double w01 = v0[j0] * v1[j1];
+                    const double a0 = w01 * c0, a1 = w01 * c1;
+#pragma unroll
+                    for (int j2 = 0; j2 < W; ++j2) {
+                        if (RAW48) lds_add_raw(p + j2, a0, v2[j2]); else lds_add_fixed(p + j2, a0, v2[j2]);
+                        if (C == 2) { if (RAW48) lds_add_raw(q + j2, a1, v2[j2]); else lds_add_fixed(q + j2, a1, v2[j2]); }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // flush: fold the halo columns, undo the raw encoding, write the int64 slab
+    const long long* li = reinterpret_cast<const long long*>(lds);
+    long long* so = reinterpret_cast<long long*>(slab);
+    for (int64_t i = threadIdx.x; i < C * cells; i += kSpreadThreads) {
+        const int ch = (int)(i / cells);
+        const int64_t cell = i - (int64_t)ch * cells;
+        const int r = (int)(cell / nl), col = (int)(cell - (int64_t)r * nl);
+        const long long* row = li + (int64_t)ch * plane + (int64_t)r * pl;
+        long long v = RAW48 ? sext48(row[col]) : row[col];
+        if (col < W - 1) v += RAW48 ? sext48(row[nl + col]) : row[nl + col];
+        so[i] = v;
+    }
+}
+
 // out[b][n] = the +-1 probe the spread kernels generate for (seed, row b, point n + index_offset)
 __global__ void rademacher_fill_kernel(unsigned long long seed, int64_t npts, int64_t index_offset, double* __restrict__ out) {
     const int row = blockIdx.y;
@@ -279,14 +449,15 @@ __global__ __launch_bounds__(1024) void maxabs_kernel(const double* __restrict__
     }
 }
 
-// scale[0] = S = largest power of two with  max|c| * S <= 2^50  and  points_per_wg * max|c| * S <= 2^61
+// scale[0] = S = largest power of two with  max|c| * S <= 2^min(50,sum_bits)  and  points_per_wg * max|c| * S <= 2^sum_bits
 __global__ void fixed_scale_kernel(const unsigned long long* __restrict__ cmax_bits, double floor_bound, int64_t per,
-                                   double* __restrict__ scale) {
+                                   double* __restrict__ scale, int sum_bits) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double cmax = cmax_bits ? __longlong_as_double((long long)*cmax_bits) : 0.0;
     cmax = fmax(cmax, floor_bound);         // the implicit all-ones channel has magnitude 1
     if (!(cmax > 0.0) || !isfinite(cmax)) cmax = 1.0;
-    const double lim = fmin(ldexp(1.0, 50), ldexp(1.0, 61) / (double)(per > 1 ? per : 1));
+    // every value below 2^50 (or 2^(sum_bits)) and every per-workgroup sum below 2^sum_bits
+    const double lim = fmin(ldexp(1.0, sum_bits < 50 ? sum_bits : 50), ldexp(1.0, sum_bits) / (double)(per > 1 ? per : 1));
     int e = 0;
     frexp(lim / cmax, &e);                  // lim/cmax = f * 2^e, f in [0.5, 1)
     const double S = ldexp(1.0, e - 1);     // largest power of two <= lim/cmax
@@ -701,7 +872,8 @@ struct InterpArgs {
 };
 
 template <int D, int W, bool CPLX, bool USE_LDS>
-__global__ __launch_bounds__(kInterpThreads) void interp_kernel(InterpArgs a) {
+__global__ __launch_bounds__(USE_LDS ? kInterpThreads : kInterpThreadsGlobal) void interp_kernel(InterpArgs a) {
+    constexpr int kThr = USE_LDS ? kInterpThreads : kInterpThreadsGlobal;
     extern __shared__ double lds[];
     const int batch = blockIdx.y;
     const int64_t cells = a.g.cells;
@@ -709,9 +881,9 @@ __global__ __launch_bounds__(kInterpThreads) void interp_kernel(InterpArgs a) {
     if (USE_LDS) {
         if (CPLX) {
             double2* l2 = reinterpret_cast<double2*>(lds);
-            for (int64_t i = threadIdx.x; i < cells; i += kInterpThreads) l2[i] = F[i];
+            for (int64_t i = threadIdx.x; i < cells; i += kThr) l2[i] = F[i];
         } else {
-            for (int64_t i = threadIdx.x; i < cells; i += kInterpThreads) lds[i] = F[i].x;
+            for (int64_t i = threadIdx.x; i < cells; i += kThr) lds[i] = F[i].x;
         }
         __syncthreads();
     }
@@ -737,8 +909,8 @@ __global__ __launch_bounds__(kInterpThreads) void interp_kernel(InterpArgs a) {
             }
         }
     };
-    for (int64_t n = (int64_t)blockIdx.x * kInterpThreads + threadIdx.x; n < a.npts;
-         n += (int64_t)gridDim.x * kInterpThreads) {
+    for (int64_t n = (int64_t)blockIdx.x * kThr + threadIdx.x; n < a.npts;
+         n += (int64_t)gridDim.x * kThr) {
         double v0[W], v1[W], v2[W];
         int f0 = 0, f1 = 0, f2 = 0;
         {
@@ -800,6 +972,83 @@ __global__ __launch_bounds__(kInterpThreads) void interp_kernel(InterpArgs a) {
         }
         if (CPLX) reinterpret_cast<double2*>(a.out)[(int64_t)batch * a.npts + n] = make_double2(sre, sim);
         else reinterpret_cast<double*>(a.out)[(int64_t)batch * a.npts + n] = sre;
+    }
+}
+
+// Real-output interpolation with a HALO-PADDED LDS copy of the real fine grid: W-1 wrap-around rows /
+// columns are duplicated behind the grid, so a point's W^d cells are `base + constant offsets` -- no wrap
+// arithmetic and all W loads of a row are issued back to back before they are consumed.
+template <int D, int W>
+__global__ __launch_bounds__(kInterpThreads) void interp_real_halo_kernel(InterpArgs a) {
+    extern __shared__ double lds[];
+    const int batch = blockIdx.y;
+    const double2* F = a.fine + (int64_t)batch * a.g.cells;
+    const int nf0 = (int)a.g.nf[0], nf1 = (int)a.g.nf[1], nf2 = (int)a.g.nf[2];
+    const int p0 = nf0 + W - 1, p1 = D > 1 ? nf1 + W - 1 : 1, p2 = D > 2 ? nf2 + W - 1 : 1;
+    const int total = p0 * p1 * p2;
+    for (int i = threadIdx.x; i < total; i += kInterpThreads) {
+        int i2 = i % p2, i1 = (i / p2) % p1, i0 = i / (p2 * p1);
+        if (i0 >= nf0) i0 -= nf0;
+        if (D > 1 && i1 >= nf1) i1 -= nf1;
+        if (D > 2 && i2 >= nf2) i2 -= nf2;
+        const int64_t gi = D == 1 ? i0 : (D == 2 ? (int64_t)i0 * nf1 + i1 : ((int64_t)i0 * nf1 + i1) * nf2 + i2);
+        lds[i] = F[gi].x;
+    }
+    __syncthreads();
+    double* out = reinterpret_cast<double*>(a.out) + (int64_t)batch * a.npts;
+    for (int64_t n = (int64_t)blockIdx.x * kInterpThreads + threadIdx.x; n < a.npts;
+         n += (int64_t)gridDim.x * kInterpThreads) {
+        double v0[W], v1[W], v2[W];
+        int f0 = 0, f1 = 0, f2 = 0;
+        {
+            double X = fold(a.g.scale[0] * (a.x[n * D + 0] - a.g.xcen[0]), (double)nf0);
+            window_values<W>(a.coef, a.degree, X, nf0, f0, v0);
+        }
+        if (D > 1) {
+            double X = fold(a.g.scale[1] * (a.x[n * D + 1] - a.g.xcen[1]), (double)nf1);
+            window_values<W>(a.coef, a.degree, X, nf1, f1, v1);
+        }
+        if (D > 2) {
+            double X = fold(a.g.scale[2] * (a.x[n * D + 2] - a.g.xcen[2]), (double)nf2);
+            window_values<W>(a.coef, a.degree, X, nf2, f2, v2);
+        }
+        double acc = 0.0;
+        if (D == 1) {
+            const double* p = lds + f0;
+            double c[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) c[j] = p[j];
+#pragma unroll
+            for (int j = 0; j < W; ++j) acc = fma(v0[j], c[j], acc);
+        } else if (D == 2) {
+            const double* p = lds + f0 * p1 + f1;
+#pragma unroll
+            for (int j0 = 0; j0 < W; ++j0) {
+                double c[W];
+#pragma unroll
+                for (int j1 = 0; j1 < W; ++j1) c[j1] = p[j0 * p1 + j1];
+                double r = 0.0;
+#pragma unroll
+                for (int j1 = 0; j1 < W; ++j1) r = fma(v1[j1], c[j1], r);
+                acc = fma(v0[j0], r, acc);
+            }
+        } else {
+            for (int j0 = 0; j0 < W; ++j0) {
+                double r0 = 0.0;
+                for (int j1 = 0; j1 < W; ++j1) {
+                    const double* p = lds + ((f0 + j0) * p1 + (f1 + j1)) * p2 + f2;
+                    double c[W];
+#pragma unroll
+                    for (int j2 = 0; j2 < W; ++j2) c[j2] = p[j2];
+                    double r = 0.0;
+#pragma unroll
+                    for (int j2 = 0; j2 < W; ++j2) r = fma(v2[j2], c[j2], r);
+                    r0 = fma(v1[j1], r, r0);
+                }
+                acc = fma(v0[j0], r0, acc);
+            }
+        }
+        out[n] = acc;
     }
 }
 
@@ -968,6 +1217,31 @@ static hipError_t launch_spread_dw(bool use_lds, dim3 grid, size_t lds_bytes, hi
     return hipGetLastError();
 }
 
+template <int D, int W, bool RAW48>
+static hipError_t launch_spread_pad_dwr(dim3 grid, size_t lds_bytes, hipStream_t s, const SpreadArgs& a) {
+    auto k = spread_pad_kernel<D, W, RAW48>;
+    if (lds_bytes > 65536) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(kSpreadThreads), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_spread_pad_d(int W, bool raw48, dim3 grid, size_t lds_bytes, hipStream_t s, const SpreadArgs& a) {
+    switch (W) {
+#define EFGP_CASE(w_)                                                                          \
+    case w_:                                                                                   \
+        return raw48 ? launch_spread_pad_dwr<D, w_, true>(grid, lds_bytes, s, a)               \
+                     : launch_spread_pad_dwr<D, w_, false>(grid, lds_bytes, s, a);
+        EFGP_CASE(2) EFGP_CASE(3) EFGP_CASE(4) EFGP_CASE(5) EFGP_CASE(6) EFGP_CASE(7) EFGP_CASE(8) EFGP_CASE(9)
+        EFGP_CASE(10) EFGP_CASE(11) EFGP_CASE(12) EFGP_CASE(13) EFGP_CASE(14) EFGP_CASE(15) EFGP_CASE(16)
+#undef EFGP_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
 template <int D>
 static hipError_t launch_spread_d(int W, bool use_lds, dim3 grid, size_t lds_bytes, hipStream_t s, const SpreadArgs& a) {
     switch (W) {
@@ -989,9 +1263,29 @@ static hipError_t launch_interp_dwc(bool use_lds, dim3 grid, size_t lds_bytes, h
         }
         hipLaunchKernelGGL(k, grid, dim3(kInterpThreads), lds_bytes, s, a);
     } else {
-        hipLaunchKernelGGL((interp_kernel<D, W, CPLX, false>), grid, dim3(kInterpThreads), 0, s, a);
+        hipLaunchKernelGGL((interp_kernel<D, W, CPLX, false>), grid, dim3(kInterpThreadsGlobal), 0, s, a);
     }
     return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_interp_halo_d(int W, dim3 grid, size_t lds_bytes, hipStream_t s, const InterpArgs& a) {
+    switch (W) {
+#define EFGP_CASE(w_)                                                                                               \
+    case w_: {                                                                                                      \
+        auto k = interp_real_halo_kernel<D, w_>;                                                                    \
+        if (lds_bytes > 65536) {                                                                                    \
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            if (e != hipSuccess) return e;                                                                          \
+        }                                                                                                           \
+        hipLaunchKernelGGL(k, grid, dim3(kInterpThreads), lds_bytes, s, a);                                         \
+        return hipGetLastError();                                                                                   \
+    }
+        EFGP_CASE(2) EFGP_CASE(3) EFGP_CASE(4) EFGP_CASE(5) EFGP_CASE(6) EFGP_CASE(7) EFGP_CASE(8) EFGP_CASE(9)
+        EFGP_CASE(10) EFGP_CASE(11) EFGP_CASE(12) EFGP_CASE(13) EFGP_CASE(14) EFGP_CASE(15) EFGP_CASE(16)
+#undef EFGP_CASE
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int D>
@@ -1162,7 +1456,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         // the global int64 grid sums over ALL points: bound the scale with N instead of points per workgroup
         hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream,
                            need_max ? (const unsigned long long*)d_cmax : (const unsigned long long*)nullptr,
-                           floor_bound, plan->npts, d_scale);
+                           floor_bound, plan->npts, d_scale, 61);
         EFGP_HIP_CHECK(hipGetLastError());
         TileSpreadArgs ta;
         ta.t = tg;
@@ -1225,6 +1519,12 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     if (!use_lds) EFGP_HIP_CHECK(hipMemsetAsync(slabs, 0, slab_bytes, stream));
 
     const int64_t per = (plan->npts + nwg - 1) / std::max(nwg, 1);
+    // padded-row variant when the padded grid still fits LDS; 48-bit raw accumulation when its rounding
+    // floor (points per workgroup * 2^-47 relative to max|c|) stays two orders below the requested tolerance
+    const int64_t nlast = g.nf[plan->dim - 1];
+    const size_t pad_bytes = (size_t)channels * (size_t)(g.cells / nlast) * (size_t)(nlast + w->p.w - 1) * sizeof(double);
+    const bool use_pad = use_lds && pad_bytes + 4608 <= (size_t)ctx->max_lds && std::getenv("EFGP_NO_PAD") == nullptr;   // + class lists
+    const bool raw48 = use_pad && (double)per * std::ldexp(1.0, -47) <= 0.01 * plan->tol && std::getenv("EFGP_NO_RAW48") == nullptr;
     if (use_lds) {
         // fixed-point scale from max |c| (device side, no host round trip)
         if (need_max) {
@@ -1235,7 +1535,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         }
         hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream,
                            need_max ? (const unsigned long long*)d_cmax : (const unsigned long long*)nullptr,
-                           floor_bound, per, d_scale);
+                           floor_bound, per, d_scale, raw48 ? 46 : 61);
         EFGP_HIP_CHECK(hipGetLastError());
     }
 
@@ -1252,7 +1552,12 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     a.scale = d_scale;
     dim3 grid(nwg, nbatch);
     hipError_t e = hipSuccess;
-    if (plan->npts > 0) {
+    if (plan->npts > 0 && use_pad) {
+        KernelTimer timer("spread", stream);
+        if (plan->dim == 1) e = launch_spread_pad_d<1>(w->p.w, raw48, grid, pad_bytes, stream, a);
+        else if (plan->dim == 2) e = launch_spread_pad_d<2>(w->p.w, raw48, grid, pad_bytes, stream, a);
+        else e = launch_spread_pad_d<3>(w->p.w, raw48, grid, pad_bytes, stream, a);
+    } else if (plan->npts > 0) {
         KernelTimer timer("spread", stream);
         if (plan->dim == 1) e = launch_spread_d<1>(w->p.w, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
         else if (plan->dim == 2) e = launch_spread_d<2>(w->p.w, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
@@ -1505,7 +1810,12 @@ int efgp_nufft_type2(efgp_nufft_t* plan, const void* f, int nbatch, const int64_
     EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)fine, (hipfftDoubleComplex*)fine,
                                  isign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
     const bool cplx = !real_only;
-    const size_t lds_bytes = (size_t)g.cells * (cplx ? sizeof(double2) : sizeof(double));
+    size_t lds_bytes = (size_t)g.cells * (cplx ? sizeof(double2) : sizeof(double));
+    // real outputs: halo-padded LDS copy when it fits (no wrap arithmetic in the gather)
+    size_t halo_cells = 1;
+    for (int a_ = 0; a_ < plan->dim; ++a_) halo_cells *= (size_t)(g.nf[a_] + w->p.w - 1);
+    const bool use_halo = !cplx && halo_cells * sizeof(double) <= (size_t)ctx->max_lds && std::getenv("EFGP_NO_HALO") == nullptr;
+    if (use_halo) lds_bytes = halo_cells * sizeof(double);
     const bool use_lds = lds_bytes <= (size_t)ctx->max_lds;
     InterpArgs a;
     a.x = plan->x;
@@ -1515,12 +1825,13 @@ int efgp_nufft_type2(efgp_nufft_t* plan, const void* f, int nbatch, const int64_
     a.degree = w->p.degree;
     a.fine = fine;
     a.out = out;
-    int64_t want = (plan->npts + kInterpThreads - 1) / kInterpThreads;
+    const int thr = use_lds ? kInterpThreads : kInterpThreadsGlobal;
+    int64_t want = (plan->npts + thr - 1) / thr;
     int nwg;
     if (use_lds) {
         int per_cu = std::max(1, std::min(4, (int)((size_t)ctx->max_lds / std::max<size_t>(lds_bytes, 1))));
-        // each workgroup pays one fine-grid copy into LDS: keep >= 8 waves of points per workgroup
-        int64_t cap = std::max<int64_t>(1, plan->npts / (8 * kInterpThreads));
+        // each workgroup pays one fine-grid copy into LDS: keep >= 2 points per thread
+        int64_t cap = std::max<int64_t>(1, plan->npts / (2 * kInterpThreads));
         nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)ctx->num_cu * per_cu, want), cap));
     } else {
         nwg = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->num_cu * 8, want));
@@ -1528,7 +1839,11 @@ int efgp_nufft_type2(efgp_nufft_t* plan, const void* f, int nbatch, const int64_
     dim3 grid(nwg, nbatch);
     hipError_t e;
     KernelTimer timer("interp", stream);
-    if (plan->dim == 1) e = launch_interp_d<1>(w->p.w, cplx, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
+    if (use_halo) {
+        if (plan->dim == 1) e = launch_interp_halo_d<1>(w->p.w, grid, lds_bytes, stream, a);
+        else if (plan->dim == 2) e = launch_interp_halo_d<2>(w->p.w, grid, lds_bytes, stream, a);
+        else e = launch_interp_halo_d<3>(w->p.w, grid, lds_bytes, stream, a);
+    } else if (plan->dim == 1) e = launch_interp_d<1>(w->p.w, cplx, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
     else if (plan->dim == 2) e = launch_interp_d<2>(w->p.w, cplx, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
     else e = launch_interp_d<3>(w->p.w, cplx, use_lds, grid, use_lds ? lds_bytes : 0, stream, a);
     if (e != hipSuccess) {

