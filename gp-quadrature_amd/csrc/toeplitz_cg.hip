@@ -601,6 +601,27 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
     return EFGP_OK;
 }
 
+int efgp_cg_solve_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
+                        const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop,
+                        int batched_semantics, int* row_iters_dev, void* stream_) {
+    EFGP_REQUIRE(op && ws && b && x && row_iters_dev, "efgp_cg_solve_async: null argument");
+    EFGP_REQUIRE(nbatch >= 1, "efgp_cg_solve_async: nbatch must be >= 1");
+    EFGP_REQUIRE(variant == 0 || variant == 1, "efgp_cg_solve_async: variant must be 0 or 1");
+    EFGP_REQUIRE(batched_semantics || nbatch == 1, "efgp_cg_solve_async: single-system semantics need nbatch == 1");
+    EFGP_REQUIRE(sigmasq > 0.0 || variant == 0, "efgp_cg_solve_async: sigmasq must be positive for A_var");
+    if (!op->persistent_ok || std::getenv("EFGP_NO_PERSISTENT_CG") != nullptr) {
+        set_error("efgp_cg_solve_async: grid does not fit the persistent kernel");
+        return EFGP_EUNSUPPORTED;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(op->device);
+    if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * op->g.M, 2000000000);
+    KernelTimer timer("cg_persistent", stream);
+    return persistent_cg_launch(op->g, (const double2* const*)op->tw, op->vhat, (const double2*)ws, precond_diag, sigmasq,
+                                variant, tol, early_stop, batched_semantics, max_iter, (const double2*)b, (double2*)x, nbatch,
+                                row_iters_dev, stream);
+}
+
 int efgp_vdot_real(int device, const void* a, int a_is_complex, const void* b, int b_is_complex, int64_t count,
                    double* out_host, void* stream_) {
     EFGP_REQUIRE(out_host, "efgp_vdot_real: null out");

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "efgp_toeplitz_apply": (_I, [_VP, _VP, _I, _VP, _VP]),
     "efgp_toeplitz_fft_shape": (_I, [_VP, _PI64]),
     "efgp_cg_solve": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _VP]),
+    "efgp_cg_solve_async": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, _VP, _VP]),
     "efgp_vdot_real": (_I, [_I, _VP, _I, _VP, _I, _I64, C.POINTER(_D), _VP]),
 }
 
@@ -76,6 +77,9 @@ def lib():
         fn.argtypes = args
     _LIB = handle
     return handle
+
+
+EFGP_EUNSUPPORTED = -4
 
 
 def check(rc, what=""):

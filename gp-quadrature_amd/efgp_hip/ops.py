@@ -191,6 +191,58 @@ def cg_solve(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=Tru
     return x.reshape(b.shape), int(iters.value), [int(r) for r in rows]
 
 
+class LazyIterations:
+    """Iteration counts of an asynchronous CG solve; reading them waits for the solve (device tensor -> host)."""
+
+    def __init__(self, rows_dev, batched, max_iter):
+        self._rows_dev = rows_dev
+        self._batched = batched
+        self._max_iter = max_iter
+        self._rows = None
+
+    @property
+    def rows(self):
+        if self._rows is None:
+            self._rows = [int(v) for v in self._rows_dev.tolist()]
+        return self._rows
+
+    def __int__(self):
+        mx = max(self.rows)
+        # cg.py:193-199,243: the batched loop counts the terminating pass too
+        return mx + 1 if (self._batched and mx < self._max_iter) else mx
+
+    __index__ = __int__
+
+    def __repr__(self):
+        return str(int(self))
+
+
+def cg_solve_async(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=True, diag=None, batched=None):
+    """Like cg_solve but without host synchronisation: returns (x, LazyIterations) or None when the operator's
+    grid does not fit the persistent kernel (the caller then uses cg_solve)."""
+    from .lib import EFGP_EUNSUPPORTED
+    dev = op.dev
+    if batched is None:
+        batched = b.ndim > 1
+    bb = b.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous()
+    x = x0.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous().clone()
+    wsd = ws.to(device=dev, dtype=_CD).contiguous()
+    dg = diag.to(device=dev, dtype=_RD).contiguous() if diag is not None else None
+    B = bb.shape[0]
+    mi = int(max_iter) if max_iter is not None else 2 * op.size
+    rows_dev = torch.empty(B, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().efgp_cg_solve_async(op._h, _ptr(wsd), float(sigmasq), int(variant), _ptr(dg) if dg is not None else None,
+                                       _ptr(bb), _ptr(x), B, float(tol), mi, int(bool(early_stop)), int(bool(batched)),
+                                       _ptr(rows_dev), _stream(dev))
+    if rc == EFGP_EUNSUPPORTED:
+        return None
+    check(rc, "efgp_cg_solve_async")
+    # keep the operands alive until the stream has consumed them: torch's caching allocator only reuses a block
+    # for work enqueued later on the same stream, so dropping the Python references here is safe
+    return x.reshape(b.shape), LazyIterations(rows_dev, bool(batched), mi)
+
+
 def vdot_real(a, b):
     """Re <a, b> = Re sum conj(a) b for real or complex device vectors, reduced by the HIP kernel."""
     dev = a.device

@@ -30,7 +30,7 @@ from cg import ConjugateGradients
 from kernels.kernel_params import GPParams
 from utils.kernels import get_xis
 
-from efgp_hip import NufftPlan, ToeplitzOp, cg_solve, vdot_real, compute_device
+from efgp_hip import NufftPlan, ToeplitzOp, cg_solve, cg_solve_async, vdot_real, compute_device
 from efgp_hip.dist import PointShards
 
 TWO_PI = 2.0 * math.pi
@@ -697,7 +697,7 @@ class EFGPND(nn.Module):
         self._registered_optimizers = []
         self.last_gradient_stats = {}
         self._last_gradient_beta = None
-        self.last_fit_stats = {}
+        self._last_fit_stats = {}
         self._devdata = None
         self._fit_state = None
         self._shards = PointShards(enabled=bool(self.opts.get("shard_points", False)))
@@ -722,6 +722,14 @@ class EFGPND(nn.Module):
     @property
     def sigmasq(self) -> torch.Tensor:
         return self._gp_params.sig2
+
+    @property
+    def last_fit_stats(self) -> Dict:
+        """Diagnostics of the last fit (reading them waits for an asynchronous solve to finish)."""
+        st = dict(self._last_fit_stats)
+        if "mean_cg_iters" in st:
+            st["mean_cg_iters"] = int(st["mean_cg_iters"])
+        return st
 
     def _current_hypers(self):
         vals = {name: float(self.kernel.get_hyper(name)) for name in getattr(self.kernel, "hypers", [])}
@@ -839,7 +847,13 @@ class EFGPND(nn.Module):
             b0 = self._beta.detach().to(device=dev, dtype=torch.complex128)
         else:
             b0 = torch.zeros_like(rhs)
-        beta, iters, _ = cg_solve(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False)
+        # no host synchronisation when the solve fits the single-launch kernel: the iteration count stays on the
+        # device until somebody reads last_fit_stats, so the host can already prepare the next transform
+        res = cg_solve_async(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False)
+        if res is None:
+            beta, iters, _ = cg_solve(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False)
+        else:
+            beta, iters = res
 
         xis = grid.xis.to(dtype=rdtype)
         xis.h_float = grid.h
@@ -849,7 +863,7 @@ class EFGPND(nn.Module):
         self._toeplitz = toeplitz
         self._fit_state = dict(h=grid.h, mtot=grid.mtot, d=d, sig=sig, ws=grid.ws, beta=beta,
                                hypers=self._current_hypers(), Fy=Fy, v=v)
-        self.last_fit_stats = dict(mean_cg_iters=int(iters), mtot=grid.mtot, feature_count=grid.M, h=grid.h)
+        self._last_fit_stats = dict(mean_cg_iters=iters, mtot=grid.mtot, feature_count=grid.M, h=grid.h)
         self._fitted = True
         self._update_param_cache()
 

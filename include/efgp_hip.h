@@ -136,6 +136,15 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
                   int max_iter, int early_stop, int batched_semantics, int* iters_out,
                   int* row_iters_out, void* stream);
 
+/* Same solve without any host synchronisation: the per-row iteration counts are left in the DEVICE array
+ * row_iters_dev (nbatch ints) and the call returns as soon as the work is enqueued, so the host can prepare
+ * the next fit while this one runs.  Only available when the circulant grid fits the single-launch persistent
+ * kernel (power-of-two FFT sizes, <= 4608 padded elements); otherwise returns EFGP_EUNSUPPORTED and the
+ * caller uses efgp_cg_solve. */
+int efgp_cg_solve_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant,
+                        const double* precond_diag, const void* b, void* x, int nbatch, double tol,
+                        int max_iter, int early_stop, int batched_semantics, int* row_iters_dev, void* stream);
+
 /* ---- N-length reductions of the hyper-gradient (efgpnd.py:163, 170, 239) ----------------------
  * out_host[0] = Re sum_n conj(a_n) b_n over n < count; each operand is complex (interleaved) when
  * its *_is_complex flag is set, else real.  Wavefront-shuffle + LDS reduction, deterministic order.

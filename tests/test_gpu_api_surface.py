@@ -1,0 +1,208 @@
+"""GPU tests of the drop-in call surface: public classes / functions behave like the
+reference's -- shapes, devices, dtypes, layouts, error behaviour -- with values checked against the oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).detach().cpu().reshape(-1).to(torch.complex128)
+    b = torch.as_tensor(b).detach().cpu().reshape(-1).to(torch.complex128)
+    return float(torch.linalg.norm(a - b) / torch.linalg.norm(b))
+
+
+def _data(N=3000, d=2, seed=0, dtype=torch.float64):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(N, d, generator=g, dtype=torch.float64) * 2 - 1
+    y = torch.sin(3 * x[:, 0]) + (0.5 * torch.cos(2 * x[:, 1]) if d > 1 else 0) + 0.1 * torch.randn(N, generator=g, dtype=torch.float64)
+    return x.to(dtype), y.to(dtype)
+
+
+def test_nufft_class_cpu_tensors_roundtrip():
+    """CPU tensors in -> CPU tensors out (the reference runs on x.device); flat, shaped and batched layouts."""
+    from efgpnd import NUFFT
+    from oracle import efgp_oracle as O
+    x, y = _data(2000, 2)
+    op = NUFFT(x, torch.zeros(2, dtype=torch.float64), 0.3, 1e-9)
+    assert op.phi.shape == (2, 2000) and op.phi.device.type == "cpu"
+    assert torch.allclose(op.phi, (2 * math.pi * 0.3 * x).T)
+    f = op.type1(y, out_shape=(15, 15))
+    assert f.device.type == "cpu" and f.dtype == torch.complex128 and f.shape == (15, 15)
+    assert _rel(f, O.nudft_type1(x, 0.3, y, (15, 15))) < 1e-8
+    fb = op.type1(torch.stack([y, 2 * y, -y]).to(torch.complex128), out_shape=(15, 15))
+    assert fb.shape == (3, 15, 15) and _rel(fb[1], 2 * f) < 1e-8
+    c = op.type2(f.reshape(-1), out_shape=(15, 15))
+    assert c.shape == (2000,) and _rel(c, O.nudft_type2(x, 0.3, f, (15, 15))) < 1e-8
+    cb = op.type2(fb.reshape(3, -1), out_shape=(15, 15))
+    assert cb.shape == (3, 2000) and _rel(cb[2], -c) < 1e-8
+    assert _rel(op.type2(f), c) < 1e-12                       # already shaped, no out_shape
+    with pytest.raises(ValueError):
+        op.type2(f.reshape(-1))
+    # non-zero centre (reference: phi = 2 pi h (x - xcen))
+    op2 = NUFFT(x, torch.tensor([0.3, -0.2], dtype=torch.float64), 0.3, 1e-9)
+    assert _rel(op2.type1(y, out_shape=(9, 9)), O.nudft_type1(x - torch.tensor([0.3, -0.2], dtype=torch.float64), 0.3, y, (9, 9))) < 1e-8
+
+
+def test_toeplitz_layouts_and_errors():
+    from efgpnd import ToeplitzND, compute_convolution_vector_vectorized_dD
+    from oracle import efgp_oracle as O
+    x, _ = _data(500, 2)
+    v = compute_convolution_vector_vectorized_dD(3, x, 0.4)
+    assert v.shape == (13, 13) and v.device.type == "cpu" and v.dtype == torch.complex128
+    assert _rel(v, O.conv_vector(x, 0.4, 3)) < 5e-7
+    assert abs(v[6, 6].real - 500) < 1e-4
+    T = ToeplitzND(v)
+    To = O.Toeplitz(O.conv_vector(x, 0.4, 3))
+    assert T.ns == [7, 7] and T.Ls == [13, 13] and T.size == 49 and T.d == 2 and T.fft_shape == [16, 16]
+    g = torch.Generator().manual_seed(1)
+    u = torch.complex(torch.randn(4, 49, generator=g, dtype=torch.float64), torch.randn(4, 49, generator=g, dtype=torch.float64))
+    assert _rel(T(u), To(u)) < 1e-6                      # flat batch
+    assert T(u).shape == (4, 49) and T(u[0]).shape == (49,)
+    assert T(u.reshape(4, 7, 7)).shape == (4, 7, 7)      # block batch
+    assert _rel(T(u.reshape(2, 2, 7, 7)), To(u).reshape(2, 2, 7, 7)) < 1e-6
+    assert T(u[0].real).dtype == torch.complex128        # real input is promoted
+    with pytest.raises(ValueError):
+        T(torch.zeros(50, dtype=torch.complex128))
+    assert ToeplitzND(v, force_pow2=False).fft_shape == [16, 16] or ToeplitzND(v, force_pow2=False).fft_shape[0] >= 13
+
+
+def test_operators_and_cg_dispatch():
+    """create_A_mean / create_A_var / create_jacobi_precond compose with ConjugateGradients like the reference's
+    closures; the solve runs fused (iters and solution match the oracle CG)."""
+    from efgpnd import ToeplitzND, create_A_mean, create_A_var, create_Gv, create_jacobi_precond, setup_operators
+    from cg import ConjugateGradients
+    from oracle import efgp_oracle as O
+    x, _ = _data(800, 2, seed=2)
+    vo = O.conv_vector(x, 0.35, 5)
+    To = O.Toeplitz(vo)
+    g = torch.Generator().manual_seed(3)
+    ws = torch.exp(-2 * torch.rand(121, generator=g, dtype=torch.float64)).to(torch.complex128)
+    b = torch.complex(torch.randn(121, generator=g, dtype=torch.float64), torch.randn(121, generator=g, dtype=torch.float64))
+    T = ToeplitzND(vo)
+    A = create_A_mean(ws, T, 0.4, torch.complex128)
+    Av = create_A_var(ws, T, 0.4, torch.complex128)
+    G = create_Gv(ws, T, torch.complex128)
+    Ao = O.make_A_mean(ws, To, 0.4)
+    assert _rel(A(b), Ao(b)) < 1e-12 and _rel(Av(b), O.make_A_var(ws, To, 0.4)(b)) < 1e-12
+    assert _rel(G(b), ws * To(ws * b)) < 1e-12
+    assert _rel(A(torch.stack([b, 2 * b])), torch.stack([Ao(b), 2 * Ao(b)])) < 1e-12
+    assert len(setup_operators(ws, T, 0.4, torch.complex128)) == 3
+    Minv = create_jacobi_precond(ws, 0.4, diag_scale=vo[10, 10].real)
+    diag = O.jacobi_diag(ws, 0.4, 800.0)
+    assert _rel(Minv(b), b / diag) < 1e-12
+    cg = ConjugateGradients(A, b, torch.zeros_like(b), tol=1e-9, early_stopping=True, M_inv_apply=Minv)
+    xs = cg.solve()
+    xo, ito = O.cg_single(Ao, b, torch.zeros_like(b), 1e-9, diag=diag)
+    assert cg.iters_completed == ito and _rel(xs, xo) < 1e-8 and xs.device.type == "cpu"
+    B = torch.stack([b, b.conj(), 0.1 * b])
+    cgb = ConjugateGradients(Av, B, torch.zeros_like(B), tol=1e-8, max_iter=500)
+    xb = cgb.solve()
+    xob, itob = O.cg_batched(O.make_A_var(ws, To, 0.4), B, torch.zeros_like(B), 1e-8, max_iter=500)
+    assert cgb.iters_completed == itob and _rel(xb, xob) < 1e-7
+    # a user-supplied preconditioner falls back to the generic loop with the same semantics
+    cg2 = ConjugateGradients(A, b, torch.zeros_like(b), tol=1e-9, M_inv_apply=lambda r: r / diag)
+    assert _rel(cg2.solve(), xo) < 1e-8 and cg2.iters_completed == ito
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_model_dtypes_devices_and_shapes(dtype):
+    from efgpnd import EFGPND, efgp_nd
+    from oracle import efgp_oracle as O
+    x, y = _data(4000, 2, seed=4, dtype=dtype)
+    m = EFGPND(x, y, "SE", sigmasq=0.05, eps=1e-3, nufft_eps=1e-9, estimate_params=False, opts={"cg_tolerance": 1e-8})
+    m.kernel.set_hyper("lengthscale", 0.3)
+    m.kernel.set_hyper("variance", 1.2)
+    xn, _ = _data(300, 2, seed=5, dtype=dtype)
+    mean, var = m.predict(xn, variance_method="regular")
+    assert mean.shape == (300,) and var.shape == (300,) and mean.dtype == dtype and mean.device.type == "cpu"
+    assert m._beta.dtype == (torch.complex64 if dtype == torch.float32 else torch.complex128)
+    assert m._xis.shape[1] == 2 and hasattr(m._xis, "h_float") and m._ws.shape == m._beta.shape
+    k = O.KernelSpec("se", 2, m.kernel.get_hyper("lengthscale"), m.kernel.get_hyper("variance"))
+    f = O.fit(x.double(), y.double(), k, float(m.sigmasq.detach()), 1e-3, cg_tol=1e-8)
+    tol = 1e-5 if dtype == torch.float64 else 2e-4       # float32 inputs are rounded on the way in / out only
+    assert _rel(mean, O.predict_mean(f, xn.double())) < tol
+    assert _rel(var, O.variance_regular(f, xn.double(), cg_tol=1e-8)) < 10 * tol
+    _, nanvar = m.predict(xn, return_variance=False)
+    assert torch.isnan(nanvar).all()
+    with pytest.raises(ValueError):
+        m.predict(xn, variance_method="bogus")
+    with pytest.raises(ValueError):
+        m.predict(xn[:, :1])
+    if dtype == torch.float64:
+        beta, xis, ytrg, ws, toep = efgp_nd(x, y, float(m.sigmasq.detach()), m.kernel, 1e-3, xn, nufft_eps=1e-9,
+                                            opts={"cg_tolerance": 1e-8, "estimate_variance": True, "variance_method": "regular"})
+        assert _rel(ytrg["mean"], mean) < 1e-6 and _rel(ytrg["var"], var) < 1e-5 and beta.shape == ws.shape
+
+
+def test_one_dimensional_inputs_and_cuda_tensors():
+    from efgpnd import EFGPND
+    from oracle import efgp_oracle as O
+    x, y = _data(3000, 1, seed=6)
+    m = EFGPND(x[:, 0].cuda(), y.cuda(), "Matern32", sigmasq=0.1, eps=1e-3, nufft_eps=1e-9, estimate_params=False,
+               opts={"cg_tolerance": 1e-9})
+    m.kernel.set_hyper("lengthscale", 0.4)
+    m.kernel.set_hyper("variance", 0.9)
+    xn = torch.linspace(-1, 1, 64, dtype=torch.float64)
+    mean, var = m.predict(xn.cuda(), variance_method="regular")
+    assert mean.is_cuda and mean.shape == (64,)
+    k = O.KernelSpec("matern", 1, m.kernel.get_hyper("lengthscale"), m.kernel.get_hyper("variance"), 1.5)
+    f = O.fit(x, y, k, float(m.sigmasq.detach()), 1e-3, cg_tol=1e-9)
+    assert _rel(mean, O.predict_mean(f, xn)) < 1e-5
+    assert _rel(var, O.variance_regular(f, xn[:, None], cg_tol=1e-9)) < 1e-4
+
+
+def test_refit_on_changed_hypers_and_training_loop():
+    from efgpnd import EFGPND
+    x, y = _data(5000, 2, seed=7)
+    m = EFGPND(x.cuda(), y.cuda(), "SquaredExponential", eps=1e-3)      # estimate_params=True path
+    xn = x[:50].cuda()
+    m1, _ = m.predict(xn, return_variance=False)
+    it1 = m.last_fit_stats["mean_cg_iters"]
+    m.kernel.set_hyper("lengthscale", 2.0 * m.kernel.get_hyper("lengthscale"))
+    m2, _ = m.predict(xn, return_variance=False)                          # changed hypers -> refit
+    assert not torch.allclose(m1, m2)
+    opt = m.register_optimizer(torch.optim.Adam(m.parameters(), lr=0.05))
+    before = m._gp_params.raw.detach().clone()
+    for _ in range(3):
+        opt.zero_grad()
+        g = m.compute_gradients(trace_samples=3)
+        assert g.shape == (3,) and torch.isfinite(g).all()
+        opt.step()
+    assert not torch.equal(before, m._gp_params.raw.detach())
+    st = m.last_gradient_stats
+    assert st["trace_num_rhs"] == 6 and st["trace_samples"] == 3 and "stage_sec" in st
+    m.optimize_hyperparameters(max_iters=2, trace_samples=2, log_interval=1)
+    assert len(m.training_log["gradients"]) == 2 and m._fitted
+    lm = m.predict(xn, return_variance=False, compute_log_marginal=True)[2]
+    assert math.isfinite(float(lm))
+
+
+def test_logdet_slq_against_dense():
+    from efgpnd import ToeplitzND, logdet_slq
+    from oracle import efgp_oracle as O
+    x, _ = _data(300, 1, seed=8)
+    vo = O.conv_vector(x, 0.4, 6)
+    To = O.Toeplitz(vo)
+    M = To.size
+    g = torch.Generator().manual_seed(9)
+    ws = torch.exp(-torch.rand(M, generator=g, dtype=torch.float64)).to(torch.complex128)
+    Tm = torch.stack([To(torch.eye(M, dtype=torch.complex128)[i]) for i in range(M)], dim=1)
+    dense = torch.eye(M, dtype=torch.complex128) + (ws[:, None] * Tm * ws[None, :]) / 0.5
+    exact = float(torch.linalg.slogdet(dense)[1]) + 300 * math.log(0.5)
+    torch.manual_seed(0)
+    est = logdet_slq(ws, 0.5, ToeplitzND(vo), probes=200, steps=M, n=300)
+    assert abs(est - exact) < 0.05 * abs(exact) + 2.0
+
+
+def test_sample_posterior_small():
+    from efgpnd import EFGPND
+    x, y = _data(60, 1, seed=10)
+    m = EFGPND(x, y, "SE", sigmasq=0.05, eps=1e-4, estimate_params=False)
+    m.kernel.set_hyper("lengthscale", 0.3)
+    m.kernel.set_hyper("variance", 1.0)
+    s = m.sample_posterior(torch.linspace(-1, 1, 20, dtype=torch.float64)[:, None], 5)
+    assert s.shape == (20, 5) and np.isfinite(s).all()
