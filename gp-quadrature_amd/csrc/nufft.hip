@@ -760,6 +760,231 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_tile_kernel(TileSpreadA
 }
 
 // ------------------------------------------------------------------------------------------
+// Register-accumulating spreader over BASE-CELL-SORTED points (2-D).
+//   With the points counting-sorted by their first covered cell (tile size 1: the binning above), all
+//   points of a bin share the same W x W stencil, so their contributions can be summed in REGISTERS with
+//   plain FMAs and flushed once per run -- no LDS atomics in the inner loop (the LDS-resident spreader is
+//   bound by ~128 LDS atomics per point).
+//   A 16-lane group (one DPP row) takes a contiguous chunk of `chunk` sorted points and walks the cell runs
+//   inside it.  Per iteration the group handles 8 points, two lanes per point: lane s (0..7, "A") and lane
+//   s+8 ("B").  A evaluates the dimension-0 window of its point, B the dimension-1 window (same Horner
+//   polynomials, wave-uniform coefficients, different argument); one row_ror:8 DPP exchange gives A the
+//   column weights and B the lower-half row weights.  A accumulates stencil rows [0, RH), B rows [RH, W),
+//   all W columns, C channels.  At the end of a run the 8 partial stencils of each half are summed with DPP
+//   and added to the double-precision global grid.
+// ------------------------------------------------------------------------------------------
+struct CellSpreadArgs {
+    TileGeom t;               // T = 1: bins are cells
+    const double* xs;
+    const int* order;
+    const int* start;
+    StrengthSrc src;
+    const double* coef;
+    int degree;
+    int channels;
+    double* gacc;             // [batch][channels][cells] doubles, pre-zeroed
+    int64_t cells;
+    int npts;
+    int chunk;                // sorted points per 16-lane group (multiple of 8)
+};
+
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(old), lo, CTRL, 0xF, BANK_MASK, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(old), hi, CTRL, 0xF, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 8 lanes of each half of a DPP row (result in every lane of the half)
+__device__ __forceinline__ double sum8(double v) {
+    v += dpp_f64<0xB1, 0xF>(v, v);      // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xF>(v, v);      // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141, 0xF>(v, v);     // row_half_mirror
+    return v;
+}
+
+template <int W, int C, int DEG>
+__global__ __launch_bounds__(256) void spread_cell_kernel(CellSpreadArgs a) {
+    constexpr int RH = (W + 1) / 2;                  // stencil rows handled by the A lanes; B lanes: W - RH
+    constexpr int kRor8 = 0x128;                     // DPP row_ror:8 -- swaps the two 8-lane halves of a row
+    const TileGeom& t = a.t;
+    const int batch = blockIdx.y;
+    const int lane16 = threadIdx.x & 15;
+    const int half = lane16 >> 3, sub = lane16 & 7;
+    const int nf0 = t.nf[0], nf1 = t.nf[1];
+    const double my_scale = half ? t.scale[1] : t.scale[0];
+    const double my_xcen = half ? t.xcen[1] : t.xcen[0];
+    const double my_nf = half ? (double)nf1 : (double)nf0;
+    double* gacc = a.gacc + (int64_t)batch * C * a.cells;
+    const int group = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int lo = group * a.chunk;
+    if (lo >= a.npts) return;                         // whole 16-lane rows leave together
+    const int hi = min(lo + a.chunk, a.npts);
+    const_coef_ptr coef = (const_coef_ptr)a.coef;     // [>= DEG+1][W]; rows above the fitted degree are zero
+    const bool by_index = a.src.mode != STR_ONES;
+    // Staging ring in LDS (per group: 2 windows of kWin points; coordinates and strengths).  Window k+2 is in
+    // flight in registers (its strength gather needs the original indices, loaded one window earlier still)
+    // while window k is consumed, so the inner loop never waits on global memory.
+    constexpr int kWin = 64, kPer = kWin / 16, kRing = 2 * kWin;
+    extern __shared__ double stage_lds[];
+    double* sX0 = stage_lds + (threadIdx.x >> 4) * (4 * kRing);
+    double* sX1 = sX0 + kRing;
+    double* sC0 = sX1 + kRing;
+    double* sC1 = sC0 + kRing;
+    const int nwin = (hi - lo + kWin - 1) / kWin;
+    int ordR[kPer];
+    double2 xR[kPer];
+    double c0R[kPer], c1R[kPer];
+    auto load_ord = [&](int k) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < kPer; ++m) {
+            const int idx = min(lo + k * kWin + lane16 + 16 * m, hi - 1);
+            ordR[m] = by_index ? a.order[idx] : 0;
+        }
+    };
+    auto load_xc = [&](int k) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < kPer; ++m) {
+            const int pos = lo + k * kWin + lane16 + 16 * m;
+            const int idx = min(pos, hi - 1);
+            xR[m] = reinterpret_cast<const double2*>(a.xs)[idx];
+            fetch_strength(a.src, batch, (int64_t)ordR[m], c0R[m], c1R[m]);
+            if (pos >= hi) {
+                c0R[m] = 0.0;
+                c1R[m] = 0.0;
+            }
+        }
+    };
+    auto store_win = [&](int k) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < kPer; ++m) {
+            const int slot = ((k & 1) * kWin) + lane16 + 16 * m;
+            sX0[slot] = xR[m].x;
+            sX1[slot] = xR[m].y;
+            sC0[slot] = c0R[m];
+            if (C == 2) sC1[slot] = c1R[m];
+        }
+    };
+    load_ord(0);
+    load_xc(0);
+    if (nwin > 1) load_ord(1);
+    store_win(0);
+    if (nwin > 1) {
+        load_xc(1);
+        if (nwin > 2) load_ord(2);
+        store_win(1);
+    }
+    if (nwin > 2) {
+        load_xc(2);
+        if (nwin > 3) load_ord(3);
+    }
+    int kw = 0;                                        // window being consumed; windows kw, kw+1 are in LDS
+    int win_end = min(lo + kWin, hi);
+    // cell run that contains sorted position `lo`
+    int bin;
+    {
+        int l = 0, r = t.nbins;                       // invariant: start[l] <= lo < start[r]
+        while (r - l > 1) {
+            const int m = (l + r) >> 1;
+            if (a.start[m] <= lo) l = m;
+            else r = m;
+        }
+        bin = l;
+    }
+    int pos = lo;
+    while (pos < hi) {
+        while (a.start[bin + 1] <= pos) ++bin;        // skip empty cells
+        const int seg_hi = min(a.start[bin + 1], hi);
+        const int b0 = bin / t.nt[1], b1 = bin - b0 * t.nt[1];          // T = 1: tile index = first covered cell
+        const double my_first = half ? (double)b1 : (double)b0;
+        double acc0[RH][W], acc1[RH][W];
+#pragma unroll
+        for (int r = 0; r < RH; ++r)
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                acc0[r][c] = 0.0;
+                acc1[r][c] = 0.0;
+            }
+        while (pos < seg_hi) {
+            if (pos >= win_end) {                      // advance the staging ring by one window
+                ++kw;
+                win_end = min(lo + (kw + 1) * kWin, hi);
+                if (kw + 1 < nwin) store_win(kw + 1);
+                if (kw + 2 < nwin) {
+                    load_xc(kw + 2);
+                    if (kw + 3 < nwin) load_ord(kw + 3);
+                }
+            }
+            const int take = min(8, seg_hi - pos);
+            const bool valid = sub < take;
+            const int slot = (pos - lo + (valid ? sub : 0)) & (kRing - 1);
+            const double xcur = half ? sX1[slot] : sX0[slot];
+            double c0 = sC0[slot];
+            double c1 = C == 2 ? sC1[slot] : 0.0;
+            if (!valid) {
+                c0 = 0.0;
+                c1 = 0.0;
+            }
+            pos += take;
+            // window of this lane's dimension.  The first covered cell is the run's cell (known from the bin),
+            // not re-derived from X, so a rounding difference against the binning pass cannot shift the stencil.
+            double e[W];
+            {
+                const double X = fold(my_scale * (xcur - my_xcen), my_nf);
+                const double i0 = my_first > X ? my_first - my_nf : my_first;
+                const double sv = 2.0 * (i0 - X + 0.5 * W) - 1.0;
+#pragma unroll
+                for (int j = 0; j < W; ++j) e[j] = coef[DEG * W + j];
+#pragma unroll
+                for (int k = DEG - 1; k >= 0; --k) {
+#pragma unroll
+                    for (int j = 0; j < W; ++j) e[j] = fma(e[j], sv, coef[k * W + j]);
+                }
+            }
+            // S[c]: column (dimension-1) weights -- A lanes take them from their B partner, B lanes own them
+            // F[r]: row (dimension-0) weights of this half -- A lanes own rows [0,RH), B lanes take rows [RH,W) from A
+            double S[W], F0[RH], F1[RH];
+#pragma unroll
+            for (int c = 0; c < W; ++c) S[c] = dpp_f64<kRor8, 0x3>(e[c], e[c]);
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                double f;
+                if (RH + r < W) f = dpp_f64<kRor8, 0xC>(e[r], e[RH + r]);
+                else f = half ? 0.0 : e[r];            // odd W: the B half has one row less
+                F0[r] = f * c0;
+                F1[r] = f * c1;
+            }
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+#pragma unroll
+                for (int c = 0; c < W; ++c) {
+                    acc0[r][c] = fma(F0[r], S[c], acc0[r][c]);
+                    if (C == 2) acc1[r][c] = fma(F1[r], S[c], acc1[r][c]);
+                }
+            }
+        }
+        // reduce over the 8 lanes of the half and add the half-stencil to the grid
+        const int nrows = half == 0 ? RH : W - RH;
+        const int r0 = half * RH;
+#pragma unroll
+        for (int r = 0; r < RH; ++r) {
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                const double s0 = sum8(acc0[r][c]);
+                const double s1 = C == 2 ? sum8(acc1[r][c]) : 0.0;
+                // lane `sub` == (r*W + c) & 7 writes this element: spreads the atomics over the 8 lanes
+                if (sub == ((r * W + c) & 7) && r < nrows) {
+                    const int g0 = wrap(b0 + r0 + r, nf0), g1 = wrap(b1 + c, nf1);
+                    const int64_t gi = (int64_t)g0 * nf1 + g1;
+                    unsafeAtomicAdd(&gacc[gi], s0);
+                    if (C == 2) unsafeAtomicAdd(&gacc[a.cells + gi], s1);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // mode <-> fine-grid index bookkeeping shared by the deconvolve / precorrect kernels
 // ------------------------------------------------------------------------------------------
 struct ModeGeom {
@@ -1059,7 +1284,7 @@ struct WindowSet {          // device copies of the window data for one (toleran
     double tol = 0.0;
     int dim = 0;
     EsParams p;
-    double* d_coef = nullptr;       // [degree+1][W]
+    double* d_coef = nullptr;       // [kMaxDegree+1][W], rows above `degree` are zero
     double* d_fac[3] = {nullptr, nullptr, nullptr};
     int64_t nm[3] = {0, 0, 0};
     int64_t nf[3] = {0, 0, 0};
@@ -1141,7 +1366,7 @@ static int get_window(efgp_nufft_s* plan, const int64_t* n_modes, hipStream_t st
     }
     es_make_params(plan->tol, sigma_min, &w->p);
     const int W = w->p.w, deg = w->p.degree;
-    std::vector<double> coef((size_t)(deg + 1) * W);
+    std::vector<double> coef((size_t)(kMaxDegree + 1) * W, 0.0);          // rows above `deg` stay zero (padded Horner)
     for (int k = 0; k <= deg; ++k)
         for (int j = 0; j < W; ++j) coef[(size_t)k * W + j] = w->p.coef[j * (kMaxDegree + 1) + k];
     if (hipMalloc((void**)&w->d_coef, coef.size() * sizeof(double)) != hipSuccess) {
@@ -1304,7 +1529,9 @@ static hipError_t launch_interp_d(int W, bool cplx, bool use_lds, dim3 grid, siz
 }
 
 // ---- tiled path: geometry, binning, launch -------------------------------------------------------
-static bool make_tile_geom(const efgp_nufft_s* plan, const WindowSet* w, int channels, size_t lds_budget, TileGeom* out) {
+// force_tile > 0: use that tile size (1 = bins are single cells, for the cell-sorted spreader)
+static bool make_tile_geom(const efgp_nufft_s* plan, const WindowSet* w, int channels, size_t lds_budget, TileGeom* out,
+                           int force_tile = 0) {
     TileGeom t;
     const int d = plan->dim, W = w->p.w;
     t.d = d;
@@ -1313,8 +1540,9 @@ static bool make_tile_geom(const efgp_nufft_s* plan, const WindowSet* w, int cha
     const double cells_max = (double)lds_budget / (8.0 * channels);
     int ext = (int)std::floor(std::pow(cells_max, 1.0 / d));
     while (ext > W && std::pow((double)ext, d) > cells_max) --ext;
-    const int Tmax = ext - (W - 1);
-    if (Tmax < 2) return false;
+    int Tmax = ext - (W - 1);
+    if (force_tile > 0) Tmax = force_tile;
+    if (Tmax < 1 || (force_tile == 0 && Tmax < 2)) return false;
     t.nbins = 1;
     for (int a = 0; a < 3; ++a) {
         if (a < d) {
@@ -1334,7 +1562,7 @@ static bool make_tile_geom(const efgp_nufft_s* plan, const WindowSet* w, int cha
             t.xcen[a] = 0.0;
         }
     }
-    if (t.nbins > 8192) return false;           // LDS histograms of the binning kernels
+    if (t.nbins > 16384) return false;          // LDS histograms of the binning kernels (2 x 64 KB)
     *out = t;
     return true;
 }
@@ -1378,6 +1606,14 @@ static int get_bins(efgp_nufft_s* plan, const TileGeom& t, int channels, hipStre
     const int nwg = (int)std::max<int64_t>(1, (plan->npts + 32 * 1024 - 1) / (32 * 1024));
     const size_t lds_h = (size_t)t.nbins * sizeof(int), lds_s = (size_t)2 * t.nbins * sizeof(int);
 #define EFGP_BIN_LAUNCH(D_)                                                                                              \
+    if (lds_s > 65536) {                                                                                                  \
+        EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)bin_scatter_kernel<D_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           (int)lds_s));                                                                  \
+    }                                                                                                                     \
+    if (lds_h > 65536) {                                                                                                  \
+        EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)bin_hist_kernel<D_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                           (int)lds_h));                                                                  \
+    }                                                                                                                     \
     hipLaunchKernelGGL((bin_hist_kernel<D_>), dim3(nwg), dim3(1024), lds_h, stream, t, plan->x, plan->npts, hist);        \
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, stream, (const int*)hist, t.nbins, b->start, cursor);     \
     hipLaunchKernelGGL((bin_scatter_kernel<D_>), dim3(nwg), dim3(1024), lds_s, stream, t, plan->x, plan->npts, cursor,    \
@@ -1412,6 +1648,29 @@ static hipError_t launch_tile_d(int W, dim3 grid, size_t lds_bytes, hipStream_t 
     return hipErrorInvalidValue;
 }
 
+constexpr size_t kCellLds = 16 * 4 * 128 * sizeof(double);    // 16 groups x (x0, x1, c0, c1) x 2 windows of 64 points
+// the cell kernel unrolls its Horner loop: degrees are padded up to W + 2 or W + 4 (zero rows in the table)
+template <int W>
+static hipError_t launch_cell_w(int channels, int degree, dim3 grid, hipStream_t s, const CellSpreadArgs& a) {
+    if (degree <= W + 2) {
+        if (channels == 2) hipLaunchKernelGGL((spread_cell_kernel<W, 2, W + 2>), grid, dim3(256), kCellLds, s, a);
+        else hipLaunchKernelGGL((spread_cell_kernel<W, 1, W + 2>), grid, dim3(256), kCellLds, s, a);
+    } else {
+        if (channels == 2) hipLaunchKernelGGL((spread_cell_kernel<W, 2, W + 4>), grid, dim3(256), kCellLds, s, a);
+        else hipLaunchKernelGGL((spread_cell_kernel<W, 1, W + 4>), grid, dim3(256), kCellLds, s, a);
+    }
+    return hipGetLastError();
+}
+static hipError_t launch_cell(int W, int channels, int degree, dim3 grid, hipStream_t s, const CellSpreadArgs& a) {
+    switch (W) {
+#define EFGP_CASE(w_) case w_: return launch_cell_w<w_>(channels, degree, grid, s, a);
+        EFGP_CASE(2) EFGP_CASE(3) EFGP_CASE(4) EFGP_CASE(5) EFGP_CASE(6) EFGP_CASE(7) EFGP_CASE(8) EFGP_CASE(9)
+        EFGP_CASE(10)
+#undef EFGP_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
 // spread + reduce + FFT; leaves the transformed fine grids in SLOT_FINE
 static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int mode, int nbatch, int isign,
                           hipStream_t stream, double2** fine_out, unsigned long long seed = 0, int64_t index_offset = 0) {
@@ -1431,6 +1690,63 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     src.index_offset = index_offset;
     const size_t lds_bytes = (size_t)channels * (size_t)g.cells * sizeof(double);
     const bool use_lds = lds_bytes <= (size_t)ctx->max_lds && plan->npts > 0;
+    // 2-D with many points per fine-grid cell: register accumulation over base-cell-sorted points
+    {
+        const char* force = std::getenv("EFGP_CELLSORT");          // "1" force on, "0" force off (diagnostics)
+        const double per_cell = (double)plan->npts / (double)g.cells;
+        bool use_cells = plan->dim == 2 && w->p.w <= 10 && w->p.degree <= w->p.w + 4 && g.cells <= 16384 && per_cell >= 64.0;
+        if (force) use_cells = plan->dim == 2 && w->p.w <= 10 && w->p.degree <= w->p.w + 4 && g.cells <= 16384 && force[0] == '1' && plan->npts > 0;
+        TileGeom cg;
+        if (use_cells && make_tile_geom(plan, w, channels, (size_t)ctx->max_lds - 4096, &cg, 1)) {
+            BinSet* bins = nullptr;
+            int rc = get_bins(plan, cg, channels, stream, &bins);
+            if (rc != EFGP_OK) return rc;
+            const size_t acc_bytes = (size_t)nbatch * channels * (size_t)g.cells * sizeof(double);
+            double* gacc = (double*)scratch(ctx, SLOT_SLABS, acc_bytes);
+            double2* fine = (double2*)scratch(ctx, SLOT_FINE, (size_t)nbatch * (size_t)g.cells * sizeof(double2));
+            if (!gacc || !fine) return EFGP_ENOMEM;
+            EFGP_HIP_CHECK(hipMemsetAsync(gacc, 0, acc_bytes, stream));
+            CellSpreadArgs ca;
+            ca.t = cg;
+            ca.xs = bins->xs;
+            ca.order = bins->order;
+            ca.start = bins->start;
+            ca.src = src;
+            ca.coef = w->d_coef;
+            ca.degree = w->p.degree;
+            ca.channels = channels;
+            ca.gacc = gacc;
+            ca.cells = g.cells;
+            // enough 16-lane groups for ~4 rounds of the chip's resident waves, chunks long enough to amortise the flushes
+            int64_t chunk = (plan->npts + 32767) / 32768;
+            chunk = std::min<int64_t>(1024, std::max<int64_t>(128, (chunk + 7) / 8 * 8));
+            if (const char* ce = std::getenv("EFGP_CELL_CHUNK")) chunk = std::max(8, std::atoi(ce) / 8 * 8);   // diagnostics
+            ca.npts = (int)plan->npts;
+            ca.chunk = (int)chunk;
+            const int64_t ngroups = (plan->npts + chunk - 1) / chunk;
+            const int blocks = (int)((ngroups + 15) / 16);
+            hipError_t e;
+            {
+                KernelTimer timer("spread", stream);
+                e = launch_cell(w->p.w, channels, w->p.degree, dim3(blocks, nbatch), stream, ca);
+            }
+            if (e != hipSuccess) {
+                set_error("cell-sorted spread kernel launch failed: %s", hipGetErrorString(e));
+                return EFGP_EHIP;
+            }
+            const int rb = (int)((g.cells + 63) / 64);
+            hipLaunchKernelGGL((reduce_slabs_kernel<false>), dim3(rb, nbatch), dim3(512), 0, stream, (const double*)gacc, 1,
+                               channels, g.cells, (const double*)nullptr, fine);
+            EFGP_HIP_CHECK(hipGetLastError());
+            hipfftHandle fh;
+            rc = fft_plan(ctx, plan->dim, g.nf, nbatch, stream, &fh);
+            if (rc != EFGP_OK) return rc;
+            EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)fine, (hipfftDoubleComplex*)fine,
+                                         isign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
+            *fine_out = fine;
+            return EFGP_OK;
+        }
+    }
     // grids beyond LDS: tile-sorted points + LDS tiles (large N), else global atomics (small N)
     TileGeom tg;
     const bool use_tiles = !use_lds && plan->npts >= 32768 && std::getenv("EFGP_NO_TILES") == nullptr &&

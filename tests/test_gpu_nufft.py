@@ -161,3 +161,29 @@ def test_type1_rademacher_equals_type1_of_filled_probes(d, nm, N, B):
     assert _rel(out, O.nudft_type1(x, 0.37, Z.cpu(), (nm,) * d)) < 5e-9
     # real rows from memory take the same paired path and give the same bits
     assert torch.equal(plan.type1(Z, (nm,) * d), out) or _rel(plan.type1(Z, (nm,) * d), out) < 1e-13
+
+
+@pytest.mark.parametrize("nm,tol,N", [(45, 6e-8, 600000), (23, 1e-5, 300000), (35, 1e-9, 400000)])
+def test_type1_cell_sorted_register_path(nm, tol, N, monkeypatch):
+    """2-D, many points per fine-grid cell: register accumulation over base-cell-sorted points (forced on
+    here so that moderate N exercises it) against the exact transform and against the LDS path."""
+    from efgp_hip import NufftPlan
+    from oracle import efgp_oracle as O
+    x = _points(N, 2, 91)
+    g = torch.Generator().manual_seed(12)
+    y = torch.randn(N, generator=g, dtype=torch.float64)
+    small = 23 if nm > 23 else 11
+    monkeypatch.setenv("EFGP_CELLSORT", "1")
+    plan = NufftPlan(x.cuda(), 0.346, tol)
+    Fy, v = plan.type1_pair(y.cuda(), (small, small), (nm, nm))
+    Zf = plan.type1_rademacher(5, 3, (small, small))
+    cplx = plan.type1(torch.complex(y, -2 * y).cuda(), (small, small))
+    monkeypatch.setenv("EFGP_CELLSORT", "0")
+    plan2 = NufftPlan(x.cuda(), 0.346, tol)
+    Fy2, v2 = plan2.type1_pair(y.cuda(), (small, small), (nm, nm))
+    Zf2 = plan2.type1_rademacher(5, 3, (small, small))
+    assert _rel(Fy, Fy2) < 5 * tol and _rel(v, v2) < 5 * tol and _rel(Zf, Zf2) < 5 * tol
+    sub = slice(0, 60000)                                    # exact reference on a sub-sample is enough for the constant
+    ref_v = O.nudft_type1(x, 0.346, torch.ones(N, dtype=torch.float64), (nm, nm))
+    assert _rel(v, ref_v) < 5 * tol + 1e-13
+    assert _rel(cplx, (1 - 2j) * Fy) < 5 * tol + 1e-12

@@ -18,6 +18,12 @@ for d, N, mtot, tol in cases:
     g = torch.Generator().manual_seed(0)
     x = (torch.rand(N, d, generator=g, dtype=torch.float64) * 2 - 1).to(dev)
     y = torch.randn(N, generator=g, dtype=torch.float64).to(dev)
+    if os.environ.get("SWEEP_PRESORT"):                                          # spatially pre-sorted points (row-major cells)
+        q = int(os.environ["SWEEP_PRESORT"])
+        key = ((x[:, 0] + 1) * (q / 2)).long().clamp_(0, q - 1)
+        for j in range(1, d):
+            key = key * q + ((x[:, j] + 1) * (q / 2)).long().clamp_(0, q - 1)
+        x = x[torch.argsort(key)].contiguous()
     m = (mtot - 1) // 2
     NufftPlan(x, 0.45, tol).type1_pair(y, (mtot,) * d, (4 * m + 1,) * d)      # warm caches (windows, FFT plans, scratch)
     torch.cuda.synchronize()
