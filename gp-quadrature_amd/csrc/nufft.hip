@@ -765,13 +765,17 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_tile_kernel(TileSpreadA
 //   points of a bin share the same W x W stencil, so their contributions can be summed in REGISTERS with
 //   plain FMAs and flushed once per run -- no LDS atomics in the inner loop (the LDS-resident spreader is
 //   bound by ~128 LDS atomics per point).
-//   A 16-lane group (one DPP row) takes a contiguous chunk of `chunk` sorted points and walks the cell runs
-//   inside it.  Per iteration the group handles 8 points, two lanes per point: lane s (0..7, "A") and lane
-//   s+8 ("B").  A evaluates the dimension-0 window of its point, B the dimension-1 window (same Horner
-//   polynomials, wave-uniform coefficients, different argument); one row_ror:8 DPP exchange gives A the
-//   column weights and B the lower-half row weights.  A accumulates stencil rows [0, RH), B rows [RH, W),
-//   all W columns, C channels.  At the end of a run the 8 partial stencils of each half are summed with DPP
-//   and added to the double-precision global grid.
+//   A wavefront takes a contiguous chunk of sorted points and walks the cell runs inside it, 16 points per
+//   iteration; all control flow is wave-uniform.  The 4 lanes of a point (one per DPP row: role = lane/16)
+//   each own one quadrant of the stencil (rows [0,RH) or the mirrored rows, columns likewise).  The window
+//   is even, so polynomial W-1-j at s equals polynomial j at -s: every lane evaluates the SAME first RH
+//   Horner polynomials (at +-s), whose coefficients stay resident in VGPRs -- no per-iteration coefficient
+//   traffic and no cross-lane exchange in the inner loop.  Coordinates and strengths are staged through a
+//   small LDS ring two windows of 64 points ahead (the strength gather is a dependent load), so the inner
+//   loop does not wait on global memory.  At the end of a run the 16 partial quadrants of each role are
+//   summed over the DPP row and added to the double-precision global grid.
+//   Sums are floating point in run order: deterministic for a fixed plan and launch geometry, but not the
+//   exact fixed-point arithmetic of the LDS spreaders.
 // ------------------------------------------------------------------------------------------
 struct CellSpreadArgs {
     TileGeom t;               // T = 1: bins are cells
@@ -779,15 +783,15 @@ struct CellSpreadArgs {
     const int* order;
     const int* start;
     StrengthSrc src;
-    const double* coef;
-    int degree;
+    const double* coef;       // [kMaxDegree + 1][W], rows above the fitted degree are zero
     int channels;
     double* gacc;             // [batch][channels][cells] doubles, pre-zeroed
     int64_t cells;
     int npts;
-    int chunk;                // sorted points per 16-lane group (multiple of 8)
+    int chunk;                // sorted points per wavefront
 };
 
+// 64-bit DPP move: lanes of the banks in BANK_MASK read `v` through the DPP pattern, the others keep `old`
 template <int CTRL, int BANK_MASK>
 __device__ __forceinline__ double dpp_f64(double old, double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -795,113 +799,148 @@ __device__ __forceinline__ double dpp_f64(double old, double v) {
     hi = __builtin_amdgcn_update_dpp(__double2hiint(old), hi, CTRL, 0xF, BANK_MASK, false);
     return __hiloint2double(hi, lo);
 }
-// sum over the 8 lanes of each half of a DPP row (result in every lane of the half)
-__device__ __forceinline__ double sum8(double v) {
-    v += dpp_f64<0xB1, 0xF>(v, v);      // quad_perm [1,0,3,2]
-    v += dpp_f64<0x4E, 0xF>(v, v);      // quad_perm [2,3,0,1]
-    v += dpp_f64<0x141, 0xF>(v, v);     // row_half_mirror
-    return v;
+// Reduce-scatter over the 16 lanes of a DPP row: every lane holds 16 partial values v[0..15]; on return lane p
+// of the row holds the row-wide sum of v[p].  Each step halves the list: a lane keeps the half selected by one
+// bit of its lane index and adds the partner's copy of that half (partners: lane^8, mirror within 8, lane^2,
+// lane^1).  For the two upper bits the keep/send selection rides on the DPP bank mask (banks = 4 lanes).
+__device__ __forceinline__ double reduce_scatter16(double (&v)[16], int pt) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                     // row_ror:8; lanes 0-7 keep v[i], lanes 8-15 keep v[i+8]
+        const double x = dpp_f64<0x128, 0x3>(v[i + 8], v[i]);
+        const double y = dpp_f64<0x128, 0xC>(v[i], v[i + 8]);
+        v[i] = x + y;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                     // row_half_mirror; lanes with bit 2 clear keep v[i]
+        const double x = dpp_f64<0x141, 0x5>(v[i + 4], v[i]);
+        const double y = dpp_f64<0x141, 0xA>(v[i], v[i + 4]);
+        v[i] = x + y;
+    }
+    const bool b1 = (pt & 2) != 0, b0 = (pt & 1) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                     // quad_perm [2,3,0,1]
+        const double keep = b1 ? v[i + 2] : v[i], send = b1 ? v[i] : v[i + 2];
+        v[i] = keep + dpp_f64<0x4E, 0xF>(send, send);
+    }
+    const double keep = b0 ? v[1] : v[0], send = b0 ? v[0] : v[1];
+    return keep + dpp_f64<0xB1, 0xF>(send, send);      // quad_perm [1,0,3,2]
 }
+
+constexpr int kCellWin = 64;                                            // staged points per window (one per lane)
+constexpr size_t kCellLds = 4 * 2 * kCellWin * 2 * sizeof(double2);     // 4 waves x 2 windows x (xy, c01)
+typedef const __attribute__((address_space(4))) int* const_int_ptr;
 
 template <int W, int C, int DEG>
 __global__ __launch_bounds__(256) void spread_cell_kernel(CellSpreadArgs a) {
-    constexpr int RH = (W + 1) / 2;                  // stencil rows handled by the A lanes; B lanes: W - RH
-    constexpr int kRor8 = 0x128;                     // DPP row_ror:8 -- swaps the two 8-lane halves of a row
+    constexpr int RH = (W + 1) / 2;                  // polynomials / stencil rows / columns per quadrant
+    constexpr bool kOdd = (W & 1) != 0;
+    constexpr int kWin = kCellWin, kRing = 2 * kWin;
     const TileGeom& t = a.t;
     const int batch = blockIdx.y;
-    const int lane16 = threadIdx.x & 15;
-    const int half = lane16 >> 3, sub = lane16 & 7;
+    const int lane = threadIdx.x & 63;
+    const int pt = lane & 15, role = lane >> 4;
+    const bool ra = (role >> 1) != 0, rb = (role & 1) != 0;     // mirrored rows / mirrored columns
     const int nf0 = t.nf[0], nf1 = t.nf[1];
-    const double my_scale = half ? t.scale[1] : t.scale[0];
-    const double my_xcen = half ? t.xcen[1] : t.xcen[0];
-    const double my_nf = half ? (double)nf1 : (double)nf0;
     double* gacc = a.gacc + (int64_t)batch * C * a.cells;
-    const int group = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int lo = group * a.chunk;
-    if (lo >= a.npts) return;                         // whole 16-lane rows leave together
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int lo = wave * a.chunk;
+    if (lo >= a.npts) return;
     const int hi = min(lo + a.chunk, a.npts);
-    const_coef_ptr coef = (const_coef_ptr)a.coef;     // [>= DEG+1][W]; rows above the fitted degree are zero
     const bool by_index = a.src.mode != STR_ONES;
-    // Staging ring in LDS (per group: 2 windows of kWin points; coordinates and strengths).  Window k+2 is in
-    // flight in registers (its strength gather needs the original indices, loaded one window earlier still)
-    // while window k is consumed, so the inner loop never waits on global memory.
-    constexpr int kWin = 64, kPer = kWin / 16, kRing = 2 * kWin;
-    extern __shared__ double stage_lds[];
-    double* sX0 = stage_lds + (threadIdx.x >> 4) * (4 * kRing);
-    double* sX1 = sX0 + kRing;
-    double* sC0 = sX1 + kRing;
-    double* sC1 = sC0 + kRing;
-    const int nwin = (hi - lo + kWin - 1) / kWin;
-    int ordR[kPer];
-    double2 xR[kPer];
-    double c0R[kPer], c1R[kPer];
-    auto load_ord = [&](int k) __attribute__((always_inline)) {
+    const_int_ptr start = (const_int_ptr)a.start;     // written by the binning kernels of an earlier launch
+    // Horner coefficients of polynomials 0..RH-1, pinned in VGPRs (the asm keeps the compiler from treating
+    // them as wave-uniform scalars, which it would spill and read back lane by lane)
+    double cf[DEG + 1][RH];
+    {
+        const_coef_ptr coef = (const_coef_ptr)a.coef;
 #pragma unroll
-        for (int m = 0; m < kPer; ++m) {
-            const int idx = min(lo + k * kWin + lane16 + 16 * m, hi - 1);
-            ordR[m] = by_index ? a.order[idx] : 0;
-        }
+        for (int k = 0; k <= DEG; ++k)
+#pragma unroll
+            for (int j = 0; j < RH; ++j) {
+                double v = coef[k * W + j];
+                asm volatile("" : "+v"(v));
+                cf[k][j] = v;
+            }
+    }
+    // staging ring: lane l stages sorted position (window base + l)
+    extern __shared__ double2 stage_lds[];
+    double2* sXY = stage_lds + (threadIdx.x >> 6) * (2 * kRing);
+    double2* sC = sXY + kRing;
+    const int nwin = (hi - lo + kWin - 1) / kWin;
+    int ordN = 0;
+    double x0N = 0.0, x1N = 0.0, c0N = 0.0, c1N = 0.0;
+    auto load_ord = [&](int k) __attribute__((always_inline)) {
+        const int idx = min(lo + k * kWin + lane, hi - 1);
+        ordN = by_index ? a.order[idx] : 0;
     };
     auto load_xc = [&](int k) __attribute__((always_inline)) {
-#pragma unroll
-        for (int m = 0; m < kPer; ++m) {
-            const int pos = lo + k * kWin + lane16 + 16 * m;
-            const int idx = min(pos, hi - 1);
-            xR[m] = reinterpret_cast<const double2*>(a.xs)[idx];
-            fetch_strength(a.src, batch, (int64_t)ordR[m], c0R[m], c1R[m]);
-            if (pos >= hi) {
-                c0R[m] = 0.0;
-                c1R[m] = 0.0;
-            }
-        }
+        const int idx = min(lo + k * kWin + lane, hi - 1);
+        const double2 xy = reinterpret_cast<const double2*>(a.xs)[idx];
+        x0N = xy.x;
+        x1N = xy.y;
+        fetch_strength(a.src, batch, (int64_t)ordN, c0N, c1N);
     };
-    auto store_win = [&](int k) __attribute__((always_inline)) {
-#pragma unroll
-        for (int m = 0; m < kPer; ++m) {
-            const int slot = ((k & 1) * kWin) + lane16 + 16 * m;
-            sX0[slot] = xR[m].x;
-            sX1[slot] = xR[m].y;
-            sC0[slot] = c0R[m];
-            if (C == 2) sC1[slot] = c1R[m];
-        }
+    auto store_win = [&](int k) __attribute__((always_inline)) {     // first use of the loaded registers: waits here
+        const bool ok = lo + k * kWin + lane < hi;
+        const int slot = (k & 1) * kWin + lane;
+        sXY[slot] = make_double2(x0N, x1N);
+        sC[slot] = make_double2(ok ? c0N : 0.0, ok ? c1N : 0.0);
     };
-    load_ord(0);
-    load_xc(0);
-    if (nwin > 1) load_ord(1);
-    store_win(0);
-    if (nwin > 1) {
-        load_xc(1);
+    // prologue: windows 0 and 1 go to LDS, window 2 stays in flight in registers, indices of window 3 are
+    // requested -- issued as two batches of independent loads (indices, then coordinates + strengths)
+    {
+        int ordA, ordB = 0;
+        load_ord(0);
+        ordA = ordN;
+        if (nwin > 1) {
+            load_ord(1);
+            ordB = ordN;
+        }
         if (nwin > 2) load_ord(2);
-        store_win(1);
-    }
-    if (nwin > 2) {
-        load_xc(2);
+        const int ordC = ordN;
+        double xa0, xa1, ca0, ca1;
+        ordN = ordA;
+        load_xc(0);
+        xa0 = x0N; xa1 = x1N; ca0 = c0N; ca1 = c1N;
+        double xb0 = 0.0, xb1 = 0.0, cb0 = 0.0, cb1 = 0.0;
+        if (nwin > 1) {
+            ordN = ordB;
+            load_xc(1);
+            xb0 = x0N; xb1 = x1N; cb0 = c0N; cb1 = c1N;
+        }
+        if (nwin > 2) {
+            ordN = ordC;
+            load_xc(2);
+        }
+        const double xc0 = x0N, xc1 = x1N, cc0 = c0N, cc1 = c1N;
         if (nwin > 3) load_ord(3);
+        x0N = xa0; x1N = xa1; c0N = ca0; c1N = ca1;
+        store_win(0);
+        if (nwin > 1) {
+            x0N = xb0; x1N = xb1; c0N = cb0; c1N = cb1;
+            store_win(1);
+        }
+        x0N = xc0; x1N = xc1; c0N = cc0; c1N = cc1;
     }
     int kw = 0;                                        // window being consumed; windows kw, kw+1 are in LDS
     int win_end = min(lo + kWin, hi);
-    // cell run that contains sorted position `lo`
-    int bin;
-    {
-        int l = 0, r = t.nbins;                       // invariant: start[l] <= lo < start[r]
-        while (r - l > 1) {
-            const int m = (l + r) >> 1;
-            if (a.start[m] <= lo) l = m;
-            else r = m;
-        }
-        bin = l;
-    }
+    // cell run that contains sorted position `lo`: the bin of that point, corrected against the run table
+    int bin = __builtin_amdgcn_readfirstlane(tile_of_point<2>(t, a.xs, (int64_t)lo));
+    bin = min(max(bin, 0), t.nbins - 1);
+    while (bin > 0 && start[bin] > lo) --bin;
+    const double scale0 = t.scale[0], scale1 = t.scale[1], xcen0 = t.xcen[0], xcen1 = t.xcen[1];
+    const double dnf0 = (double)nf0, dnf1 = (double)nf1, inv0 = 1.0 / dnf0, inv1 = 1.0 / dnf1;
     int pos = lo;
     while (pos < hi) {
-        while (a.start[bin + 1] <= pos) ++bin;        // skip empty cells
-        const int seg_hi = min(a.start[bin + 1], hi);
+        while (start[bin + 1] <= pos) ++bin;          // skip empty cells
+        const int seg_hi = min(start[bin + 1], hi);
         const int b0 = bin / t.nt[1], b1 = bin - b0 * t.nt[1];          // T = 1: tile index = first covered cell
-        const double my_first = half ? (double)b1 : (double)b0;
-        double acc0[RH][W], acc1[RH][W];
+        const double base0 = (double)b0 + 0.5 * W, base1 = (double)b1 + 0.5 * W;
+        double acc0[RH][RH], acc1[RH][RH];
 #pragma unroll
         for (int r = 0; r < RH; ++r)
 #pragma unroll
-            for (int c = 0; c < W; ++c) {
+            for (int c = 0; c < RH; ++c) {
                 acc0[r][c] = 0.0;
                 acc1[r][c] = 0.0;
             }
@@ -915,70 +954,77 @@ __global__ __launch_bounds__(256) void spread_cell_kernel(CellSpreadArgs a) {
                     if (kw + 3 < nwin) load_ord(kw + 3);
                 }
             }
-            const int take = min(8, seg_hi - pos);
-            const bool valid = sub < take;
-            const int slot = (pos - lo + (valid ? sub : 0)) & (kRing - 1);
-            const double xcur = half ? sX1[slot] : sX0[slot];
-            double c0 = sC0[slot];
-            double c1 = C == 2 ? sC1[slot] : 0.0;
-            if (!valid) {
-                c0 = 0.0;
-                c1 = 0.0;
-            }
+            const int take = min(16, seg_hi - pos);
+            const bool valid = pt < take;
+            const int slot = (pos - lo + (valid ? pt : 0)) & (kRing - 1);
+            const double2 xy = sXY[slot];
+            double2 cc = sC[slot];
+            if (!valid) cc = make_double2(0.0, 0.0);
             pos += take;
-            // window of this lane's dimension.  The first covered cell is the run's cell (known from the bin),
-            // not re-derived from X, so a rounding difference against the binning pass cannot shift the stencil.
-            double e[W];
+            // Horner variables.  u = (first cell - X + W/2) mod nf lies in [0,1); the first covered cell is the
+            // run's cell (known from the bin), not re-derived from X, so a rounding difference against the
+            // binning pass cannot shift the stencil.
+            double t0, t1;
             {
-                const double X = fold(my_scale * (xcur - my_xcen), my_nf);
-                const double i0 = my_first > X ? my_first - my_nf : my_first;
-                const double sv = 2.0 * (i0 - X + 0.5 * W) - 1.0;
+                double u = base0 - scale0 * (xy.x - xcen0);
+                u -= dnf0 * rint((u - 0.5) * inv0);
+                const double sv = 2.0 * u - 1.0;
+                t0 = ra ? -sv : sv;
+            }
+            {
+                double u = base1 - scale1 * (xy.y - xcen1);
+                u -= dnf1 * rint((u - 0.5) * inv1);
+                const double sv = 2.0 * u - 1.0;
+                t1 = rb ? -sv : sv;
+            }
+            double R[RH], Cw[RH];
 #pragma unroll
-                for (int j = 0; j < W; ++j) e[j] = coef[DEG * W + j];
+            for (int j = 0; j < RH; ++j) {
+                R[j] = cf[DEG][j];
+                Cw[j] = cf[DEG][j];
+            }
 #pragma unroll
-                for (int k = DEG - 1; k >= 0; --k) {
+            for (int k = DEG - 1; k >= 0; --k) {
 #pragma unroll
-                    for (int j = 0; j < W; ++j) e[j] = fma(e[j], sv, coef[k * W + j]);
+                for (int j = 0; j < RH; ++j) {
+                    R[j] = fma(R[j], t0, cf[k][j]);
+                    Cw[j] = fma(Cw[j], t1, cf[k][j]);
                 }
             }
-            // S[c]: column (dimension-1) weights -- A lanes take them from their B partner, B lanes own them
-            // F[r]: row (dimension-0) weights of this half -- A lanes own rows [0,RH), B lanes take rows [RH,W) from A
-            double S[W], F0[RH], F1[RH];
-#pragma unroll
-            for (int c = 0; c < W; ++c) S[c] = dpp_f64<kRor8, 0x3>(e[c], e[c]);
-#pragma unroll
-            for (int r = 0; r < RH; ++r) {
-                double f;
-                if (RH + r < W) f = dpp_f64<kRor8, 0xC>(e[r], e[RH + r]);
-                else f = half ? 0.0 : e[r];            // odd W: the B half has one row less
-                F0[r] = f * c0;
-                F1[r] = f * c1;
+            if (kOdd) {                                // the middle row / column belongs to the unmirrored quadrant
+                if (ra) R[RH - 1] = 0.0;
+                if (rb) Cw[RH - 1] = 0.0;
             }
 #pragma unroll
             for (int r = 0; r < RH; ++r) {
+                const double f0 = R[r] * cc.x;
+                const double f1 = C == 2 ? R[r] * cc.y : 0.0;
 #pragma unroll
-                for (int c = 0; c < W; ++c) {
-                    acc0[r][c] = fma(F0[r], S[c], acc0[r][c]);
-                    if (C == 2) acc1[r][c] = fma(F1[r], S[c], acc1[r][c]);
+                for (int c = 0; c < RH; ++c) {
+                    acc0[r][c] = fma(f0, Cw[c], acc0[r][c]);
+                    if (C == 2) acc1[r][c] = fma(f1, Cw[c], acc1[r][c]);
                 }
             }
         }
-        // reduce over the 8 lanes of the half and add the half-stencil to the grid
-        const int nrows = half == 0 ? RH : W - RH;
-        const int r0 = half * RH;
+        // reduce-scatter the 16 point-lanes of each role: lane p of a role ends with quadrant element p, so that
+        // ONE atomic wave-instruction per channel adds the whole W x W stencil (W-element contiguous row pieces)
+        {
+            static_assert(RH * RH <= 16, "quadrant must fit one DPP row");
+            const int er = pt / RH, ec = pt - er * RH;
+            bool mine = pt < RH * RH;
+            if (kOdd && ((ra && er == RH - 1) || (rb && ec == RH - 1))) mine = false;
+            const int g0 = wrap(b0 + (ra ? W - 1 - er : er), nf0), g1 = wrap(b1 + (rb ? W - 1 - ec : ec), nf1);
+            const int64_t gi = (int64_t)g0 * nf1 + g1;
+            double v[16];
 #pragma unroll
-        for (int r = 0; r < RH; ++r) {
+            for (int e = 0; e < 16; ++e) v[e] = e < RH * RH ? acc0[e / RH][e % RH] : 0.0;
+            const double s0 = reduce_scatter16(v, pt);
+            if (mine) unsafeAtomicAdd(&gacc[gi], s0);
+            if (C == 2) {
 #pragma unroll
-            for (int c = 0; c < W; ++c) {
-                const double s0 = sum8(acc0[r][c]);
-                const double s1 = C == 2 ? sum8(acc1[r][c]) : 0.0;
-                // lane `sub` == (r*W + c) & 7 writes this element: spreads the atomics over the 8 lanes
-                if (sub == ((r * W + c) & 7) && r < nrows) {
-                    const int g0 = wrap(b0 + r0 + r, nf0), g1 = wrap(b1 + c, nf1);
-                    const int64_t gi = (int64_t)g0 * nf1 + g1;
-                    unsafeAtomicAdd(&gacc[gi], s0);
-                    if (C == 2) unsafeAtomicAdd(&gacc[a.cells + gi], s1);
-                }
+                for (int e = 0; e < 16; ++e) v[e] = e < RH * RH ? acc1[e / RH][e % RH] : 0.0;
+                const double s1 = reduce_scatter16(v, pt);
+                if (mine) unsafeAtomicAdd(&gacc[a.cells + gi], s1);
             }
         }
     }
@@ -1648,8 +1694,8 @@ static hipError_t launch_tile_d(int W, dim3 grid, size_t lds_bytes, hipStream_t 
     return hipErrorInvalidValue;
 }
 
-constexpr size_t kCellLds = 16 * 4 * 128 * sizeof(double);    // 16 groups x (x0, x1, c0, c1) x 2 windows of 64 points
 // the cell kernel unrolls its Horner loop: degrees are padded up to W + 2 or W + 4 (zero rows in the table)
+constexpr int kCellMaxW = 8;       // register budget: RH^2 accumulators per channel + RH (DEG+1) coefficients
 template <int W>
 static hipError_t launch_cell_w(int channels, int degree, dim3 grid, hipStream_t s, const CellSpreadArgs& a) {
     if (degree <= W + 2) {
@@ -1664,8 +1710,7 @@ static hipError_t launch_cell_w(int channels, int degree, dim3 grid, hipStream_t
 static hipError_t launch_cell(int W, int channels, int degree, dim3 grid, hipStream_t s, const CellSpreadArgs& a) {
     switch (W) {
 #define EFGP_CASE(w_) case w_: return launch_cell_w<w_>(channels, degree, grid, s, a);
-        EFGP_CASE(2) EFGP_CASE(3) EFGP_CASE(4) EFGP_CASE(5) EFGP_CASE(6) EFGP_CASE(7) EFGP_CASE(8) EFGP_CASE(9)
-        EFGP_CASE(10)
+        EFGP_CASE(2) EFGP_CASE(3) EFGP_CASE(4) EFGP_CASE(5) EFGP_CASE(6) EFGP_CASE(7) EFGP_CASE(8)
 #undef EFGP_CASE
     }
     return hipErrorInvalidValue;
@@ -1692,10 +1737,12 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     const bool use_lds = lds_bytes <= (size_t)ctx->max_lds && plan->npts > 0;
     // 2-D with many points per fine-grid cell: register accumulation over base-cell-sorted points
     {
-        const char* force = std::getenv("EFGP_CELLSORT");          // "1" force on, "0" force off (diagnostics)
-        const double per_cell = (double)plan->npts / (double)g.cells;
-        bool use_cells = plan->dim == 2 && w->p.w <= 10 && w->p.degree <= w->p.w + 4 && g.cells <= 16384 && per_cell >= 64.0;
-        if (force) use_cells = plan->dim == 2 && w->p.w <= 10 && w->p.degree <= w->p.w + 4 && g.cells <= 16384 && force[0] == '1' && plan->npts > 0;
+        // Opt-in (EFGP_CELLSORT=1): the kernel itself is 1.2-1.7x faster than the LDS-atomic spreader at >= 250 points
+        // per cell, but the per-plan counting sort it needs (0.15 ms at N=1e6, 0.6 ms at N=1e7) only pays off after
+        // several passes over the same plan; see DESIGN.md.
+        const char* force = std::getenv("EFGP_CELLSORT");
+        const bool use_cells = force && force[0] == '1' && plan->dim == 2 && w->p.w <= kCellMaxW &&
+                               w->p.degree <= w->p.w + 4 && g.cells <= 16384 && plan->npts > 0;
         TileGeom cg;
         if (use_cells && make_tile_geom(plan, w, channels, (size_t)ctx->max_lds - 4096, &cg, 1)) {
             BinSet* bins = nullptr;
@@ -1713,18 +1760,18 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
             ca.start = bins->start;
             ca.src = src;
             ca.coef = w->d_coef;
-            ca.degree = w->p.degree;
             ca.channels = channels;
             ca.gacc = gacc;
             ca.cells = g.cells;
-            // enough 16-lane groups for ~4 rounds of the chip's resident waves, chunks long enough to amortise the flushes
-            int64_t chunk = (plan->npts + 32767) / 32768;
-            chunk = std::min<int64_t>(1024, std::max<int64_t>(128, (chunk + 7) / 8 * 8));
-            if (const char* ce = std::getenv("EFGP_CELL_CHUNK")) chunk = std::max(8, std::atoi(ce) / 8 * 8);   // diagnostics
+            // enough wavefronts for a few rounds of the chip's resident waves, chunks long enough to amortise the flushes
+            // one chunk per resident wave slot (2 per SIMD) when N is large: balanced, one prologue per wave
+            int64_t chunk = (plan->npts + 8 * (int64_t)ctx->num_cu - 1) / (8 * (int64_t)ctx->num_cu);
+            chunk = std::max<int64_t>(256, (chunk + 63) / 64 * 64);
+            if (const char* ce = std::getenv("EFGP_CELL_CHUNK")) chunk = std::max(64, std::atoi(ce) / 64 * 64);   // diagnostics
             ca.npts = (int)plan->npts;
             ca.chunk = (int)chunk;
-            const int64_t ngroups = (plan->npts + chunk - 1) / chunk;
-            const int blocks = (int)((ngroups + 15) / 16);
+            const int64_t nwaves = (plan->npts + chunk - 1) / chunk;
+            const int blocks = (int)((nwaves + 3) / 4);
             hipError_t e;
             {
                 KernelTimer timer("spread", stream);
