@@ -100,22 +100,66 @@ struct GridGeom {
 // vector global loads inside the Horner loop -- a chain of ~2*degree dependent L2 round trips per point.
 typedef const __attribute__((address_space(4))) double* const_coef_ptr;
 
-template <int W>
-__device__ __forceinline__ void window_values(const double* __restrict__ coef_generic, int degree, double X, int64_t nf,
-                                              int& first, double (&val)[W]) {
-    const_coef_ptr coef = (const_coef_ptr)coef_generic;
-    // first covered cell and the Horner variable (see EsParams::coef)
-    double i0 = ceil(X - 0.5 * W);
-    double s = 2.0 * (i0 - X + 0.5 * W) - 1.0;
+// All dimensions of a point at once, with half the coefficient traffic: the window is even, so polynomial
+// W-1-j at s equals polynomial j at -s.  Only the first RH = ceil(W/2) polynomials are read (table
+// `sym` behind the plain one: [kMaxDegree+1][RHP] doubles, one scalar load per degree) and every loaded
+// coefficient feeds 2*D FMAs as a scalar operand.
+__host__ __device__ constexpr int sym_row(int W) { return (W + 1) / 2 <= 2 ? 2 : ((W + 1) / 2 <= 4 ? 4 : 8); }
+
+template <int D, int W>
+__device__ __forceinline__ void window_eval(const double* __restrict__ coef_generic, int degree, const double (&X)[3],
+                                            int64_t nf0, int64_t nf1, int64_t nf2, int& f0, int& f1, int& f2,
+                                            double (&v0)[W], double (&v1)[W], double (&v2)[W]) {
+    constexpr int RH = (W + 1) / 2, RHP = sym_row(W);
+    const_coef_ptr coef = (const_coef_ptr)(coef_generic + (kMaxDegree + 1) * W);
+    const int64_t nfs[3] = {nf0, nf1, nf2};
+    int fs[3] = {0, 0, 0};
+    double s[D];
 #pragma unroll
-    for (int j = 0; j < W; ++j) val[j] = coef[degree * W + j];
+    for (int d = 0; d < D; ++d) {
+        const double i0 = ceil(X[d] - 0.5 * W);
+        s[d] = 2.0 * (i0 - X[d] + 0.5 * W) - 1.0;
+        int f = (int)i0;
+        if (f < 0) f += (int)nfs[d];
+        fs[d] = f;
+    }
+    double vp[D][RH], vm[D][RH];
+#pragma unroll
+    for (int j = 0; j < RH; ++j) {
+        const double c = coef[degree * RHP + j];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            vp[d][j] = c;
+            vm[d][j] = c;
+        }
+    }
     for (int k = degree - 1; k >= 0; --k) {
 #pragma unroll
-        for (int j = 0; j < W; ++j) val[j] = fma(val[j], s, coef[k * W + j]);
+        for (int j = 0; j < RH; ++j) {
+            const double c = coef[k * RHP + j];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                vp[d][j] = fma(vp[d][j], s[d], c);
+                vm[d][j] = fma(vm[d][j], -s[d], c);
+            }
+        }
     }
-    int f = (int)i0;
-    if (f < 0) f += (int)nf;
-    first = f;
+    f0 = fs[0];
+    f1 = fs[1];
+    f2 = fs[2];
+#pragma unroll
+    for (int j = 0; j < RH; ++j) {
+        v0[j] = vp[0][j];
+        if (W - 1 - j != j) v0[W - 1 - j] = vm[0][j];
+        if (D > 1) {
+            v1[j] = vp[D > 1 ? 1 : 0][j];
+            if (W - 1 - j != j) v1[W - 1 - j] = vm[D > 1 ? 1 : 0][j];
+        }
+        if (D > 2) {
+            v2[j] = vp[D > 2 ? 2 : 0][j];
+            if (W - 1 - j != j) v2[W - 1 - j] = vm[D > 2 ? 2 : 0][j];
+        }
+    }
 }
 
 __device__ __forceinline__ double fold(double X, double nf) {
@@ -197,16 +241,11 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
         double v0[W], v1[W], v2[W];
         int f0 = 0, f1 = 0, f2 = 0;
         {
-            double X = fold(a.g.scale[0] * (a.x[n * D + 0] - a.g.xcen[0]), (double)nf0);
-            window_values<W>(a.coef, a.degree, X, nf0, f0, v0);
-        }
-        if (D > 1) {
-            double X = fold(a.g.scale[1] * (a.x[n * D + 1] - a.g.xcen[1]), (double)nf1);
-            window_values<W>(a.coef, a.degree, X, nf1, f1, v1);
-        }
-        if (D > 2) {
-            double X = fold(a.g.scale[2] * (a.x[n * D + 2] - a.g.xcen[2]), (double)nf2);
-            window_values<W>(a.coef, a.degree, X, nf2, f2, v2);
+            double Xw[3] = {0.0, 0.0, 0.0};
+            Xw[0] = fold(a.g.scale[0] * (a.x[n * D + 0] - a.g.xcen[0]), (double)nf0);
+            if (D > 1) Xw[1] = fold(a.g.scale[1] * (a.x[n * D + 1] - a.g.xcen[1]), (double)nf1);
+            if (D > 2) Xw[2] = fold(a.g.scale[2] * (a.x[n * D + 2] - a.g.xcen[2]), (double)nf2);
+            window_eval<D, W>(a.coef, a.degree, Xw, nf0, nf1, nf2, f0, f1, f2, v0, v1, v2);
         }
         if (D == 1) {
 #pragma unroll
@@ -357,16 +396,11 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_pad_kernel(SpreadArgs a
         double v0[W], v1[W], v2[W];
         int f0 = 0, f1 = 0, f2 = 0;
         {
-            double X = fold(a.g.scale[0] * (a.x[n * D + 0] - a.g.xcen[0]), (double)nf0);
-            window_values<W>(a.coef, a.degree, X, nf0, f0, v0);
-        }
-        if (D > 1) {
-            double X = fold(a.g.scale[1] * (a.x[n * D + 1] - a.g.xcen[1]), (double)nf1);
-            window_values<W>(a.coef, a.degree, X, nf1, f1, v1);
-        }
-        if (D > 2) {
-            double X = fold(a.g.scale[2] * (a.x[n * D + 2] - a.g.xcen[2]), (double)nf2);
-            window_values<W>(a.coef, a.degree, X, nf2, f2, v2);
+            double Xw[3] = {0.0, 0.0, 0.0};
+            Xw[0] = fold(a.g.scale[0] * (a.x[n * D + 0] - a.g.xcen[0]), (double)nf0);
+            if (D > 1) Xw[1] = fold(a.g.scale[1] * (a.x[n * D + 1] - a.g.xcen[1]), (double)nf1);
+            if (D > 2) Xw[2] = fold(a.g.scale[2] * (a.x[n * D + 2] - a.g.xcen[2]), (double)nf2);
+            window_eval<D, W>(a.coef, a.degree, Xw, nf0, nf1, nf2, f0, f1, f2, v0, v1, v2);
         }
         if (D == 1) {
             double* p = lds + f0;
@@ -692,20 +726,15 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_tile_kernel(TileSpreadA
             double v0[W], v1[W], v2[W];
             int f0 = 0, f1 = 0, f2 = 0;
             {
-                double X = fold(t.scale[0] * (a.xs[n * D + 0] - t.xcen[0]), (double)t.nf[0]);
-                window_values<W>(a.coef, a.degree, X, t.nf[0], f0, v0);
-                f0 -= o[0];
-            }
-            if (D > 1) {
-                double X = fold(t.scale[1] * (a.xs[n * D + 1] - t.xcen[1]), (double)t.nf[1]);
-                window_values<W>(a.coef, a.degree, X, t.nf[1], f1, v1);
-                f1 -= o[1];
-            }
-            if (D > 2) {
-                double X = fold(t.scale[2] * (a.xs[n * D + 2] - t.xcen[2]), (double)t.nf[2]);
-                window_values<W>(a.coef, a.degree, X, t.nf[2], f2, v2);
-                f2 -= o[2];
-            }
+            double Xw[3] = {0.0, 0.0, 0.0};
+            Xw[0] = fold(t.scale[0] * (a.xs[n * D + 0] - t.xcen[0]), (double)t.nf[0]);
+            if (D > 1) Xw[1] = fold(t.scale[1] * (a.xs[n * D + 1] - t.xcen[1]), (double)t.nf[1]);
+            if (D > 2) Xw[2] = fold(t.scale[2] * (a.xs[n * D + 2] - t.xcen[2]), (double)t.nf[2]);
+            window_eval<D, W>(a.coef, a.degree, Xw, t.nf[0], t.nf[1], t.nf[2], f0, f1, f2, v0, v1, v2);
+            f0 -= o[0];
+            if (D > 1) f1 -= o[1];
+            if (D > 2) f2 -= o[2];
+        }
             if (D == 1) {
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
@@ -1185,16 +1214,11 @@ __global__ __launch_bounds__(USE_LDS ? kInterpThreads : kInterpThreadsGlobal) vo
         double v0[W], v1[W], v2[W];
         int f0 = 0, f1 = 0, f2 = 0;
         {
-            double X = fold(a.g.scale[0] * (a.x[n * D + 0] - a.g.xcen[0]), (double)nf0);
-            window_values<W>(a.coef, a.degree, X, nf0, f0, v0);
-        }
-        if (D > 1) {
-            double X = fold(a.g.scale[1] * (a.x[n * D + 1] - a.g.xcen[1]), (double)nf1);
-            window_values<W>(a.coef, a.degree, X, nf1, f1, v1);
-        }
-        if (D > 2) {
-            double X = fold(a.g.scale[2] * (a.x[n * D + 2] - a.g.xcen[2]), (double)nf2);
-            window_values<W>(a.coef, a.degree, X, nf2, f2, v2);
+            double Xw[3] = {0.0, 0.0, 0.0};
+            Xw[0] = fold(a.g.scale[0] * (a.x[n * D + 0] - a.g.xcen[0]), (double)nf0);
+            if (D > 1) Xw[1] = fold(a.g.scale[1] * (a.x[n * D + 1] - a.g.xcen[1]), (double)nf1);
+            if (D > 2) Xw[2] = fold(a.g.scale[2] * (a.x[n * D + 2] - a.g.xcen[2]), (double)nf2);
+            window_eval<D, W>(a.coef, a.degree, Xw, nf0, nf1, nf2, f0, f1, f2, v0, v1, v2);
         }
         double sre = 0.0, sim = 0.0;
         if (D == 1) {
@@ -1272,16 +1296,11 @@ __global__ __launch_bounds__(kInterpThreads) void interp_real_halo_kernel(Interp
         double v0[W], v1[W], v2[W];
         int f0 = 0, f1 = 0, f2 = 0;
         {
-            double X = fold(a.g.scale[0] * (a.x[n * D + 0] - a.g.xcen[0]), (double)nf0);
-            window_values<W>(a.coef, a.degree, X, nf0, f0, v0);
-        }
-        if (D > 1) {
-            double X = fold(a.g.scale[1] * (a.x[n * D + 1] - a.g.xcen[1]), (double)nf1);
-            window_values<W>(a.coef, a.degree, X, nf1, f1, v1);
-        }
-        if (D > 2) {
-            double X = fold(a.g.scale[2] * (a.x[n * D + 2] - a.g.xcen[2]), (double)nf2);
-            window_values<W>(a.coef, a.degree, X, nf2, f2, v2);
+            double Xw[3] = {0.0, 0.0, 0.0};
+            Xw[0] = fold(a.g.scale[0] * (a.x[n * D + 0] - a.g.xcen[0]), (double)nf0);
+            if (D > 1) Xw[1] = fold(a.g.scale[1] * (a.x[n * D + 1] - a.g.xcen[1]), (double)nf1);
+            if (D > 2) Xw[2] = fold(a.g.scale[2] * (a.x[n * D + 2] - a.g.xcen[2]), (double)nf2);
+            window_eval<D, W>(a.coef, a.degree, Xw, nf0, nf1, nf2, f0, f1, f2, v0, v1, v2);
         }
         double acc = 0.0;
         if (D == 1) {
@@ -1412,9 +1431,15 @@ static int get_window(efgp_nufft_s* plan, const int64_t* n_modes, hipStream_t st
     }
     es_make_params(plan->tol, sigma_min, &w->p);
     const int W = w->p.w, deg = w->p.degree;
-    std::vector<double> coef((size_t)(kMaxDegree + 1) * W, 0.0);          // rows above `deg` stay zero (padded Horner)
-    for (int k = 0; k <= deg; ++k)
+    // two tables: [kMaxDegree+1][W] (rows above `deg` stay zero: padded Horner), then the first ceil(W/2)
+    // polynomials again as [kMaxDegree+1][sym_row(W)] for window_eval
+    const int RHP = sym_row(W);
+    std::vector<double> coef((size_t)(kMaxDegree + 1) * (W + RHP), 0.0);
+    for (int k = 0; k <= deg; ++k) {
         for (int j = 0; j < W; ++j) coef[(size_t)k * W + j] = w->p.coef[j * (kMaxDegree + 1) + k];
+        for (int j = 0; j < (W + 1) / 2; ++j)
+            coef[(size_t)(kMaxDegree + 1) * W + (size_t)k * RHP + j] = w->p.coef[j * (kMaxDegree + 1) + k];
+    }
     if (hipMalloc((void**)&w->d_coef, coef.size() * sizeof(double)) != hipSuccess) {
         free_window(w);
         set_error("hipMalloc window coefficients failed");

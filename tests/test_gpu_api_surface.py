@@ -206,3 +206,58 @@ def test_sample_posterior_small():
     m.kernel.set_hyper("variance", 1.0)
     s = m.sample_posterior(torch.linspace(-1, 1, 20, dtype=torch.float64)[:, None], 5)
     assert s.shape == (20, 5) and np.isfinite(s).all()
+
+
+def test_weighted_toeplitz_and_circulant_preconditioners():
+    """Row (f)4: the weighted Toeplitz operator F^* diag(w) F (pg_classifier.py:377-384) and the circulant
+    preconditioners of benchmark_prism_mean_preconditioners.py:131-191, composed from the HIP operators."""
+    from efgpnd import NUFFT, ToeplitzND, create_A_mean
+    from cg import ConjugateGradients
+    from preconditioners import (weighted_toeplitz, wrap_to_circulant_kernel, scalar_circulant_preconditioner,
+                                 sandwich_circulant_preconditioner)
+    from oracle import efgp_oracle as O
+    x, _ = _data(3000, 2, seed=5)
+    h, m = 0.3, 6
+    mtot = 2 * m + 1
+    g = torch.Generator().manual_seed(4)
+    w = torch.rand(3000, generator=g, dtype=torch.float64) * 0.25          # Polya-Gamma style positive weights
+    op = NUFFT(x.cuda(), torch.zeros(2, dtype=torch.float64), h, 1e-12)
+    Tw = weighted_toeplitz(op, w.cuda(), (mtot, mtot))
+    v_exact = O.nudft_type1(x, h, w.to(torch.complex128), (4 * m + 1, 4 * m + 1))
+    assert _rel(op.type1(w.cuda().to(torch.complex128), out_shape=(4 * m + 1, 4 * m + 1)), v_exact) < 1e-9
+    u = torch.complex(torch.randn(mtot * mtot, generator=g, dtype=torch.float64), torch.randn(mtot * mtot, generator=g, dtype=torch.float64))
+    # dense check: F^* diag(w) F u
+    k = torch.arange(-m, m + 1, dtype=torch.float64)
+    kk = torch.cartesian_prod(k, k)
+    F = torch.exp(2j * torch.pi * h * (x @ kk.T))
+    dense = F.conj().T @ (w.to(torch.complex128) * (F @ u))
+    assert _rel(Tw(u.cuda()), dense) < 1e-9
+    # circulant wrap: same as the entry-by-entry definition
+    vo = O.conv_vector(x, h, m)
+    circ = wrap_to_circulant_kernel(vo)
+    ref = torch.zeros(mtot, mtot, dtype=vo.dtype)
+    for i in range(4 * m + 1):
+        for j in range(4 * m + 1):
+            ref[(i - 2 * m) % mtot, (j - 2 * m) % mtot] += vo[i, j]
+    assert _rel(circ, ref) < 1e-14
+    # preconditioned solves agree with the Jacobi solve and with each other
+    ws = torch.exp(-0.04 * (kk ** 2).sum(1)).to(torch.complex128)
+    sigmasq = 20.0
+    T = ToeplitzND(vo.cuda())
+    A = create_A_mean(ws.cuda(), T, sigmasq, torch.complex128)
+    b = (ws * (F.conj().T @ torch.randn(3000, generator=g, dtype=torch.float64).to(torch.complex128))).cuda()
+    diag = (3000.0 * ws.abs() ** 2 + sigmasq).cuda()
+    base = ConjugateGradients(A, b, torch.zeros_like(b), tol=1e-9, M_inv_apply=lambda r: r / diag)
+    xj = base.solve()
+    assert base.iters_completed < 2 * mtot * mtot                 # converged, not capped
+    for make in (lambda: scalar_circulant_preconditioner(vo.cuda(), ws.cuda(), sigmasq, "mean"),
+                 lambda: scalar_circulant_preconditioner(vo.cuda(), ws.cuda(), sigmasq, "max"),
+                 lambda: sandwich_circulant_preconditioner(vo.cuda(), ws.cuda(), sigmasq, "median"),
+                 lambda: sandwich_circulant_preconditioner(vo.cuda(), ws.cuda(), sigmasq, "geom")):
+        Minv = make()
+        cgp = ConjugateGradients(A, b, torch.zeros_like(b), tol=1e-9, M_inv_apply=Minv)
+        xp = cgp.solve()
+        assert _rel(xp, xj) < 1e-6 and cgp.iters_completed < 2 * mtot * mtot
+        assert _rel(A(xp), b) < 5e-9
+        r2 = torch.randn(2, mtot * mtot, generator=g, dtype=torch.float64).to(torch.complex128).cuda()
+        assert Minv(r2).shape == r2.shape and _rel(Minv(r2)[1], Minv(r2[1])) < 1e-12
