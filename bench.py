@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n-per-gpu", type=int, default=N_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--main-only", action="store_true",
+                    help="timed steps only (no CG-rate / gradient / CPU-baseline extras): for rocprofv3 --pmc passes, so "
+                         "that every profiled launch belongs to the fit step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,6 +148,15 @@ def main():
     fits_per_s = args.steps / elapsed
     mean_iters = model.last_fit_stats["mean_cg_iters"]
     mtot = model.last_fit_stats["mtot"]
+
+    if args.main_only:
+        if rank == 0:
+            print(json.dumps({"metric": "GP-fits/sec (main-only profiling run)", "value": fits_per_s * world,
+                              "ms_per_step": ms_per_step, "steps": args.steps, "warmup": args.warmup, "n_gpus": world}))
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # fit-only time and CG iteration rate (forced 200 iterations, no early stop), untimed region
     barrier()
