@@ -66,7 +66,10 @@ struct Geom {
 struct Args {
     Geom g;
     const double2* ws;
-    const double* diag;
+    const double* diag;      // Jacobi diagonal [M] or null
+    const double* diag_scale;   // when diag is null and this is not: diagonal = (*diag_scale) * |ws|^2 + sigmasq (device scalar)
+    int b_times_ws;          // right-hand side is ws .* b (the fit's D F*y, efgpnd.py:792)
+    int zero_x0;             // x0 = 0: x is output only and the initial operator application is skipped (A 0 = 0)
     const double2* vhat;     // [prod F] (unpadded row-major), already divided by prod F
     double sigmasq;
     int variant;
@@ -317,24 +320,34 @@ __device__ __forceinline__ double wave_sum(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// Jacobi diagonal entry t: explicit array, or scale * |ws_t|^2 + sigmasq with the two roundings of the
+// reference's torch expression (efgpnd.py:795-799), or 1 (no preconditioner)
+__device__ __forceinline__ double jacobi_entry(const Args& a, double2 w, int t) {
+    if (a.diag) return a.diag[t];
+    if (a.diag_scale) return __dadd_rn(__dmul_rn(*a.diag_scale, __dadd_rn(__dmul_rn(w.x, w.x), __dmul_rn(w.y, w.y))), a.sigmasq);
+    return 1.0;
+}
+
+// Block reductions.  The single sum and the pair use DISJOINT scratch (red[2*kRedWaves ..] vs red[0 ..]), and a
+// scratch region is rewritten only after other barriers have passed since its last read (the other reduction
+// and the FFT phases sit in between), so no barrier is needed in front of the writes.
 __device__ __forceinline__ double block_sum2(double v, double* red) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) red[wid] = v;
+    double* r1 = red + 2 * kRedWaves;
+    if (lane == 0) r1[wid] = v;
     __syncthreads();
     double t = 0.0;
 #pragma unroll
-    for (int i = 0; i < kRedWaves; ++i) t += red[i];
+    for (int i = 0; i < kRedWaves; ++i) t += r1[i];
     return t;
 }
 
-// two sums with one pair of barriers
+// two sums with one barrier
 __device__ __forceinline__ void block_sum_pair(double& u, double& v, double* red) {
     u = wave_sum(u);
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    __syncthreads();
     if (lane == 0) {
         red[wid] = u;
         red[kRedWaves + wid] = v;
@@ -363,7 +376,7 @@ __device__ __forceinline__ int grid_offset(const Geom& g, int flat, int shift) {
 
 __global__ __launch_bounds__(kThreads) void cg_persistent_kernel(Args a) {
     extern __shared__ double2 lds2[];
-    __shared__ double red[2 * kRedWaves];
+    __shared__ double red[3 * kRedWaves];
     const Geom& g = a.g;
     double2* bufA = lds2;
     double2* bufB = lds2 + g.padded;
@@ -383,14 +396,15 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_kernel(Args a) {
     // per-thread slices of the vectors (element t lives in thread t % kThreads, slot t / kThreads)
     double2 xv[kSlots], rv[kSlots], pv[kSlots], wsv[kSlots];
     double dg[kSlots];
+    const bool precond = a.diag != nullptr || a.diag_scale != nullptr;
     int off_in[kSlots], off_out[kSlots];
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
         const int t = threadIdx.x + s * kThreads;
         if (t < M) {
-            xv[s] = a.x[base + t];
+            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x[base + t];
             wsv[s] = a.ws[t];
-            dg[s] = a.diag ? a.diag[t] : 1.0;
+            dg[s] = jacobi_entry(a, wsv[s], t);
             off_in[s] = grid_offset(g, t, 0);
             off_out[s] = grid_offset(g, t, 1);
         } else {
@@ -473,15 +487,21 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_kernel(Args a) {
 
     // r = b - A x0, z = r / diag, p = z
     double2 Ap[kSlots];
-    apply_A(xv, Ap);
+    if (a.zero_x0) {
+#pragma unroll
+        for (int s = 0; s < (int)(sizeof(Ap) / sizeof(Ap[0])); ++s) Ap[s] = make_double2(0.0, 0.0);
+    } else {
+        apply_A(xv, Ap);
+    }
     double rz = 0.0, bb = 0.0;
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
         const int t = threadIdx.x + s * kThreads;
         if (t < M) {
             double2 bv = a.b[base + t];
+            if (a.b_times_ws) bv = cmulp(wsv[s], bv);
             rv[s] = csub(bv, Ap[s]);
-            pv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            pv[s] = precond ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
             rz += rv[s].x * pv[s].x + rv[s].y * pv[s].y;
             bb += bv.x * bv.x + bv.y * bv.y;
         }
@@ -506,7 +526,7 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_kernel(Args a) {
             xv[s].y += alpha * pv[s].y;
             rv[s].x -= alpha * Ap[s].x;
             rv[s].y -= alpha * Ap[s].y;
-            zv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            zv[s] = precond ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
             rr += rv[s].x * rv[s].x + rv[s].y * rv[s].y;
             rzn += rv[s].x * zv[s].x + rv[s].y * zv[s].y;
         }
@@ -570,7 +590,7 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
     using namespace s64;
     constexpr int KS = 2;                   // M = n*n <= 1024 = KS * kThreads
     extern __shared__ double2 lds2[];
-    __shared__ double red[2 * kRedWaves];
+    __shared__ double red[3 * kRedWaves];
     double2* const bufA = lds2;
     double2* const bufB = lds2 + BUF;
     const int n = a.g.n[0];                 // block size per dimension (n0 == n1 for this kernel)
@@ -606,14 +626,15 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
 
     double2 xv[KS], rv[KS], pv[KS], wsv[KS];
     double dg[KS];
+    const bool precond = a.diag != nullptr || a.diag_scale != nullptr;
     int off_in[KS], off_out[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int t = tid + s * kThreads;
         if (t < M) {
-            xv[s] = a.x[base + t];
+            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x[base + t];
             wsv[s] = a.ws[t];
-            dg[s] = a.diag ? a.diag[t] : 1.0;
+            dg[s] = jacobi_entry(a, wsv[s], t);
             const int i0 = t / n, i1 = t - i0 * n;
             off_in[s] = i0 * LD + i1;
             off_out[s] = (i0 + n - 1) * LD + (i1 + n - 1);
@@ -708,19 +729,26 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
                 Au[s] = make_double2(0.0, 0.0);
             }
         }
-        __syncthreads();
+        // no barrier here: the next LDS writes are reduction scratch (disjoint) and, behind that reduction's
+        // barrier, bufA -- whose last readers (P7) are already behind the barrier above
         EFGP_STAMP(8);
     };
 
     double2 Ap[KS];
-    apply_A(xv, Ap);
+    if (a.zero_x0) {
+#pragma unroll
+        for (int s = 0; s < (int)(sizeof(Ap) / sizeof(Ap[0])); ++s) Ap[s] = make_double2(0.0, 0.0);
+    } else {
+        apply_A(xv, Ap);
+    }
     double rz = 0.0, bb = 0.0;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         if (tid + s * kThreads < M) {
-            const double2 bv = a.b[base + tid + s * kThreads];
+            double2 bv = a.b[base + tid + s * kThreads];
+            if (a.b_times_ws) bv = cmulp(wsv[s], bv);
             rv[s] = csub(bv, Ap[s]);
-            pv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            pv[s] = precond ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
             rz += rv[s].x * pv[s].x + rv[s].y * pv[s].y;
             bb += bv.x * bv.x + bv.y * bv.y;
         }
@@ -744,7 +772,7 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
             xv[s].y += alpha * pv[s].y;
             rv[s].x -= alpha * Ap[s].x;
             rv[s].y -= alpha * Ap[s].y;
-            zv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            zv[s] = precond ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
             rr += rv[s].x * rv[s].x + rv[s].y * rv[s].y;
             rzn += rv[s].x * zv[s].x + rv[s].y * zv[s].y;
         }
@@ -811,7 +839,8 @@ bool persistent_cg_eligible(const ToepGeom& tg) {
 
 int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, const double2* vhat, const double2* ws,
                          const double* diag, double sigmasq, int variant, double tol, int early_stop, int batched,
-                         int max_iter, const double2* b, double2* x, int rows, int* d_iters, hipStream_t stream) {
+                         int max_iter, const double2* b, double2* x, int rows, int* d_iters, hipStream_t stream,
+                         const double* diag_scale, int b_times_ws, int zero_x0) {
     using namespace pcg;
     Args a;
     Geom& g = a.g;
@@ -963,6 +992,9 @@ int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, con
     }
     a.ws = ws;
     a.diag = diag;
+    a.diag_scale = diag_scale;
+    a.b_times_ws = b_times_ws;
+    a.zero_x0 = zero_x0;
     a.vhat = vhat;
     a.sigmasq = sigmasq;
     a.variant = variant;

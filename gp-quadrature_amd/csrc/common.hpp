@@ -75,6 +75,8 @@ struct DeviceCtx {
     std::vector<void*> window_cache;
     // cached FFT twiddle tables of the persistent CG: length -> device table
     std::map<int64_t, void*> twiddles;
+    // SLOT_SCALE holds the spreader's max|c| accumulator: zeroed once, then reset by the kernel that consumes it
+    bool scale_slot_ready = false;
 };
 
 // returns the context of `device` (creates it, queries properties); nullptr + error on failure

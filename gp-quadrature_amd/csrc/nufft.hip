@@ -484,10 +484,12 @@ __global__ __launch_bounds__(1024) void maxabs_kernel(const double* __restrict__
 }
 
 // scale[0] = S = largest power of two with  max|c| * S <= 2^min(50,sum_bits)  and  points_per_wg * max|c| * S <= 2^sum_bits
-__global__ void fixed_scale_kernel(const unsigned long long* __restrict__ cmax_bits, double floor_bound, int64_t per,
+// Consumes the max|c| accumulator and resets it to zero for the next transform (no memset launch per call).
+__global__ void fixed_scale_kernel(unsigned long long* __restrict__ cmax_bits, double floor_bound, int64_t per,
                                    double* __restrict__ scale, int sum_bits) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double cmax = cmax_bits ? __longlong_as_double((long long)*cmax_bits) : 0.0;
+    if (cmax_bits) *cmax_bits = 0ull;
     cmax = fmax(cmax, floor_bound);         // the implicit all-ones channel has magnitude 1
     if (!(cmax > 0.0) || !isfinite(cmax)) cmax = 1.0;
     // every value below 2^50 (or 2^(sum_bits)) and every per-workgroup sum below 2^sum_bits
@@ -1079,9 +1081,8 @@ __device__ __forceinline__ int64_t mode_of_slot(int64_t slot, int64_t nm, int mo
 // type 1: out[b][slot] = fac * FFT(fine)[k mod nf]; optional Hermitian split for the (y, ones) pair
 //   part = 0: plain;  part = 1: (H[k] + conj(H[-k]))/2;  part = 2: (H[k] - conj(H[-k]))/(2i)
 //   part = 3: fine grid g holds real rows (2g, 2g+1): both parts are written, to out rows 2g and 2g+1
-__global__ void deconvolve_kernel(const double2* __restrict__ fine, int64_t cells, ModeGeom m, int part,
-                                  double2* __restrict__ out) {
-    const int batch = blockIdx.y;
+__device__ __forceinline__ void deconvolve_body(const double2* __restrict__ fine, int64_t cells, const ModeGeom& m, int part,
+                                                double2* __restrict__ out, int batch) {
     const double2* F = fine + (int64_t)batch * cells;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m.total; t += (int64_t)gridDim.x * blockDim.x) {
         int64_t rem = t;
@@ -1118,41 +1119,62 @@ __global__ void deconvolve_kernel(const double2* __restrict__ fine, int64_t cell
         out[(int64_t)batch * m.total + t] = r;
     }
 }
+__global__ void deconvolve_kernel(const double2* __restrict__ fine, int64_t cells, ModeGeom m, int part,
+                                  double2* __restrict__ out) {
+    deconvolve_body(fine, cells, m, part, out, blockIdx.y);
+}
+// the fit-time pair in one launch: blockIdx.y = 0 -> part 1 into out_a on box ma, 1 -> part 2 into out_b on box mb
+__global__ void deconvolve_pair_kernel(const double2* __restrict__ fine, int64_t cells, ModeGeom ma, double2* __restrict__ out_a,
+                                       ModeGeom mb, double2* __restrict__ out_b) {
+    if (blockIdx.y == 0) deconvolve_body(fine, cells, ma, 1, out_a, 0);
+    else deconvolve_body(fine, cells, mb, 2, out_b, 0);
+}
 
-// type 2: fine[b][k mod nf] = fac * f[b][slot] (fine pre-zeroed).  herm != 0 stores the Hermitian part
+// type 2: fine[b][k mod nf] = fac * f[b][slot] (* mul[slot] when given), zero outside the mode box: every
+// fine cell is written, so the grid needs no memset.  herm != 0 stores the Hermitian part
 // (f[k] + conj f[-k])/2 so that the transformed grid is real (real_only outputs).
-__global__ void precorrect_kernel(const double2* __restrict__ fin, ModeGeom m, int herm, int64_t cells,
-                                  double2* __restrict__ fine) {
+__global__ void precorrect_kernel(const double2* __restrict__ fin, const double2* __restrict__ mul, ModeGeom m, int herm,
+                                  int64_t cells, double2* __restrict__ fine) {
     const int batch = blockIdx.y;
     const double2* fb = fin + (int64_t)batch * m.total;
     double2* F = fine + (int64_t)batch * cells;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m.total; t += (int64_t)gridDim.x * blockDim.x) {
-        int64_t rem = t;
-        int64_t slots[3];
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (int64_t)gridDim.x * blockDim.x) {
+        int64_t rem = c;
+        int64_t ks[3] = {0, 0, 0};
+        bool inside = true;
         for (int a = m.d - 1; a >= 0; --a) {
-            slots[a] = rem % m.nm[a];
-            rem /= m.nm[a];
+            const int64_t i = rem % m.nf[a];
+            rem /= m.nf[a];
+            const int64_t k = i <= (m.nf[a] - 1) / 2 ? i : i - m.nf[a];
+            ks[a] = k;
+            inside = inside && k >= -(m.nm[a] / 2) && k <= (m.nm[a] - 1) / 2;
         }
-        int64_t idx = 0, tn = 0;
-        bool has_neg = true;
-        double f = 1.0;
-        for (int a = 0; a < m.d; ++a) {
-            int64_t k = mode_of_slot(slots[a], m.nm[a], m.modeord);
-            f *= m.fac[a][k + m.nm[a] / 2];
-            idx = idx * m.nf[a] + (k < 0 ? k + m.nf[a] : k);
-            // slot of -k inside the mode box (may not exist for even sizes)
-            int64_t kn = -k;
-            int64_t kmin = -(m.nm[a] / 2), kmax = (m.nm[a] - 1) / 2;
-            if (kn < kmin || kn > kmax) has_neg = false;
-            int64_t sn = m.modeord == 0 ? kn - kmin : (kn >= 0 ? kn : kn + m.nm[a]);
-            tn = tn * m.nm[a] + sn;
+        double2 r = make_double2(0.0, 0.0);
+        if (inside) {
+            int64_t t = 0, tn = 0;
+            bool has_neg = true;
+            double f = 1.0;
+            for (int a = 0; a < m.d; ++a) {
+                const int64_t k = ks[a], kmin = -(m.nm[a] / 2), kmax = (m.nm[a] - 1) / 2;
+                f *= m.fac[a][k - kmin];
+                t = t * m.nm[a] + (m.modeord == 0 ? k - kmin : (k >= 0 ? k : k + m.nm[a]));
+                const int64_t kn = -k;                       // slot of -k inside the mode box (absent for even sizes)
+                if (kn < kmin || kn > kmax) has_neg = false;
+                tn = tn * m.nm[a] + (m.modeord == 0 ? kn - kmin : (kn >= 0 ? kn : kn + m.nm[a]));
+            }
+            double2 v = fb[t];
+            if (mul) v = make_double2(v.x * mul[t].x - v.y * mul[t].y, v.x * mul[t].y + v.y * mul[t].x);
+            if (herm) {
+                double2 u = make_double2(0.0, 0.0);
+                if (has_neg) {
+                    u = fb[tn];
+                    if (mul) u = make_double2(u.x * mul[tn].x - u.y * mul[tn].y, u.x * mul[tn].y + u.y * mul[tn].x);
+                }
+                v = make_double2(0.5 * (v.x + u.x), 0.5 * (v.y - u.y));
+            }
+            r = make_double2(v.x * f, v.y * f);
         }
-        double2 v = fb[t];
-        if (herm) {
-            double2 u = has_neg ? fb[tn] : make_double2(0.0, 0.0);
-            v = make_double2(0.5 * (v.x + u.x), 0.5 * (v.y - u.y));
-        }
-        F[idx] = make_double2(v.x * f, v.y * f);
+        F[c] = r;
     }
 }
 
@@ -1741,6 +1763,17 @@ static hipError_t launch_cell(int W, int channels, int degree, dim3 grid, hipStr
     return hipErrorInvalidValue;
 }
 
+// 64-byte block: [0] S, [1] 1/S (doubles), [4] max|c| bit pattern.  Zeroed when first allocated; afterwards
+// fixed_scale_kernel leaves the accumulator at zero.
+static char* scale_slot(DeviceCtx* ctx, hipStream_t stream) {
+    char* misc = (char*)scratch(ctx, SLOT_SCALE, 64);
+    if (misc && !ctx->scale_slot_ready) {
+        if (hipMemsetAsync(misc, 0, 64, stream) != hipSuccess) return nullptr;
+        ctx->scale_slot_ready = true;
+    }
+    return misc;
+}
+
 // spread + reduce + FFT; leaves the transformed fine grids in SLOT_FINE
 static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int mode, int nbatch, int isign,
                           hipStream_t stream, double2** fine_out, unsigned long long seed = 0, int64_t index_offset = 0) {
@@ -1830,20 +1863,19 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         const size_t acc_bytes = (size_t)nbatch * channels * (size_t)g.cells * sizeof(long long);
         long long* gacc = (long long*)scratch(ctx, SLOT_SLABS, acc_bytes);
         double2* fine = (double2*)scratch(ctx, SLOT_FINE, (size_t)nbatch * (size_t)g.cells * sizeof(double2));
-        char* misc = (char*)scratch(ctx, SLOT_SCALE, 64);
+        char* misc = scale_slot(ctx, stream);
         if (!gacc || !fine || !misc) return EFGP_ENOMEM;
         double* d_scale = (double*)misc;
         unsigned long long* d_cmax = (unsigned long long*)(misc + 32);
         EFGP_HIP_CHECK(hipMemsetAsync(gacc, 0, acc_bytes, stream));
         if (need_max) {
-            EFGP_HIP_CHECK(hipMemsetAsync(d_cmax, 0, sizeof(unsigned long long), stream));
             const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nvals + 8191) / 8192, 256));
             hipLaunchKernelGGL(maxabs_kernel, dim3(blocks), dim3(1024), 0, stream, c, nvals, d_cmax);
             EFGP_HIP_CHECK(hipGetLastError());
         }
         // the global int64 grid sums over ALL points: bound the scale with N instead of points per workgroup
         hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream,
-                           need_max ? (const unsigned long long*)d_cmax : (const unsigned long long*)nullptr,
+                           need_max ? d_cmax : (unsigned long long*)nullptr,
                            floor_bound, plan->npts, d_scale, 61);
         EFGP_HIP_CHECK(hipGetLastError());
         TileSpreadArgs ta;
@@ -1900,7 +1932,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     const size_t slab_bytes = (size_t)nbatch * nslab * channels * (size_t)g.cells * sizeof(double);
     double* slabs = (double*)scratch(ctx, SLOT_SLABS, slab_bytes);
     double2* fine = (double2*)scratch(ctx, SLOT_FINE, (size_t)nbatch * (size_t)g.cells * sizeof(double2));
-    char* misc = (char*)scratch(ctx, SLOT_SCALE, 64);
+    char* misc = scale_slot(ctx, stream);
     if (!slabs || !fine || !misc) return EFGP_ENOMEM;
     double* d_scale = (double*)misc;                                  // [0] S, [1] 1/S
     unsigned long long* d_cmax = (unsigned long long*)(misc + 32);
@@ -1916,13 +1948,12 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     if (use_lds) {
         // fixed-point scale from max |c| (device side, no host round trip)
         if (need_max) {
-            EFGP_HIP_CHECK(hipMemsetAsync(d_cmax, 0, sizeof(unsigned long long), stream));
             const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nvals + 8191) / 8192, 256));
             hipLaunchKernelGGL(maxabs_kernel, dim3(blocks), dim3(1024), 0, stream, c, nvals, d_cmax);
             EFGP_HIP_CHECK(hipGetLastError());
         }
         hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream,
-                           need_max ? (const unsigned long long*)d_cmax : (const unsigned long long*)nullptr,
+                           need_max ? d_cmax : (unsigned long long*)nullptr,
                            floor_bound, per, d_scale, raw48 ? 46 : 61);
         EFGP_HIP_CHECK(hipGetLastError());
     }
@@ -2159,15 +2190,39 @@ int efgp_nufft_type1_pair(efgp_nufft_t* plan, const double* y, const int64_t* n_
         return EFGP_OK;
     };
     if (mode == STR_REAL_AND_ONES) {
-        rc = sub(n_modes_y, 1, out_y);
-        if (rc != EFGP_OK) return rc;
-        return sub(n_modes_one, 2, out_ones);
+        ModeGeom ma = make_modes(plan, w, n_modes_y, 0), mb = make_modes(plan, w, n_modes_one, 0);
+        for (int a = 0; a < plan->dim; ++a) {
+            ma.fac[a] = w->d_fac[a] + (box[a] / 2 - n_modes_y[a] / 2);
+            mb.fac[a] = w->d_fac[a] + (box[a] / 2 - n_modes_one[a] / 2);
+        }
+        int64_t cells = 1;
+        for (int a = 0; a < 3; ++a) cells *= w->nf[a];
+        const int64_t most = std::max(ma.total, mb.total);
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((most + 255) / 256, 2048));
+        hipLaunchKernelGGL(deconvolve_pair_kernel, dim3(blocks, 2), dim3(256), 0, stream, (const double2*)fine, cells, ma,
+                           (double2*)out_y, mb, (double2*)out_ones);
+        EFGP_HIP_CHECK(hipGetLastError());
+        return EFGP_OK;
     }
     return out_y ? sub(n_modes_y, 0, out_y) : sub(n_modes_one, 0, out_ones);
 }
 
+static int type2_impl(efgp_nufft_t* plan, const void* f, const void* mode_scale, int nbatch, const int64_t* n_modes, int isign,
+                      int modeord, void* out, int real_only, void* stream_);
+
 int efgp_nufft_type2(efgp_nufft_t* plan, const void* f, int nbatch, const int64_t* n_modes, int isign, int modeord,
                      void* out, int real_only, void* stream_) {
+    return type2_impl(plan, f, nullptr, nbatch, n_modes, isign, modeord, out, real_only, stream_);
+}
+
+int efgp_nufft_type2_scaled(efgp_nufft_t* plan, const void* f, const void* mode_scale, int nbatch, const int64_t* n_modes,
+                            int isign, int modeord, void* out, int real_only, void* stream_) {
+    EFGP_REQUIRE(mode_scale, "efgp_nufft_type2_scaled: null mode_scale");
+    return type2_impl(plan, f, mode_scale, nbatch, n_modes, isign, modeord, out, real_only, stream_);
+}
+
+static int type2_impl(efgp_nufft_t* plan, const void* f, const void* mode_scale, int nbatch, const int64_t* n_modes, int isign,
+                      int modeord, void* out, int real_only, void* stream_) {
     EFGP_REQUIRE(plan && f && n_modes, "efgp_nufft_type2: null argument");
     EFGP_REQUIRE(nbatch >= 1, "efgp_nufft_type2: nbatch must be >= 1");
     EFGP_REQUIRE(plan->npts == 0 || out, "efgp_nufft_type2: null out");
@@ -2183,13 +2238,12 @@ int efgp_nufft_type2(efgp_nufft_t* plan, const void* f, int nbatch, const int64_
     const GridGeom g = make_geom(plan, w);
     double2* fine = (double2*)scratch(ctx, SLOT_FINE, (size_t)nbatch * (size_t)g.cells * sizeof(double2));
     if (!fine) return EFGP_ENOMEM;
-    EFGP_HIP_CHECK(hipMemsetAsync(fine, 0, (size_t)nbatch * (size_t)g.cells * sizeof(double2), stream));
     ModeGeom m = make_modes(plan, w, n_modes, modeord);
     {
         int threads = 256;
-        int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((m.total + threads - 1) / threads, 2048));
-        hipLaunchKernelGGL(precorrect_kernel, dim3(blocks, nbatch), dim3(threads), 0, stream, (const double2*)f, m,
-                           real_only ? 1 : 0, g.cells, fine);
+        int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((g.cells + threads - 1) / threads, 2048));
+        hipLaunchKernelGGL(precorrect_kernel, dim3(blocks, nbatch), dim3(threads), 0, stream, (const double2*)f,
+                           (const double2*)mode_scale, m, real_only ? 1 : 0, g.cells, fine);
         EFGP_HIP_CHECK(hipGetLastError());
     }
     hipfftHandle fh;

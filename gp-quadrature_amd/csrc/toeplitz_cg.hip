@@ -44,10 +44,10 @@ __device__ __forceinline__ int64_t pad_index(const ToepGeom& g, int64_t flat, in
 }
 
 // pad[row][:] = 0 except the leading n-box which receives scale .* src[rows[row]]
-// (scale may be null).  One launch covers all rows: grid = (blocks, nrows).
+// (scale may be null), times the real `factor`.  One launch covers all rows: grid = (blocks, nrows).
 __global__ void pad_scale_kernel(ToepGeom g, const double2* __restrict__ src, int64_t src_stride,
                                  const double2* __restrict__ scale, const int* __restrict__ rows,
-                                 const int* __restrict__ row_active, double2* __restrict__ pad) {
+                                 const int* __restrict__ row_active, double2* __restrict__ pad, double factor) {
     const int slot = blockIdx.y;
     const int row = rows ? rows[slot] : slot;
     if (row < 0) return;
@@ -69,6 +69,8 @@ __global__ void pad_scale_kernel(ToepGeom g, const double2* __restrict__ src, in
             for (int a = 0; a < g.d; ++a) flat = flat * g.n[a] + coords[a];
             v = S[flat];
             if (scale) v = cmul(v, scale[flat]);
+            v.x *= factor;
+            v.y *= factor;
         }
         P[t] = v;
     }
@@ -241,13 +243,6 @@ __global__ __launch_bounds__(kCgThreads) void cg_update_kernel(CgArgs a) {
     }
 }
 
-__global__ void scale_kernel(double2* p, int64_t n, double s) {
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-        p[t].x *= s;
-        p[t].y *= s;
-    }
-}
-
 template <bool AC, bool BC>
 __global__ void vdot_real_kernel(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
                                  double* __restrict__ partial) {
@@ -349,7 +344,7 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
     }
     hipLaunchKernelGGL(pad_scale_kernel, grid_for(op->g.Ftot, 1, kVecThreads), dim3(kVecThreads), 0, stream, gv,
                        (const double2*)v, gv.M, (const double2*)nullptr, (const int*)nullptr, (const int*)nullptr,
-                       op->vhat);
+                       op->vhat, 1.0 / (double)op->g.Ftot);   // the inverse transform's 1/Ftot, folded in before the FFT
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         pool_free(ctx, op->vhat, (size_t)op->g.Ftot * sizeof(double2));
@@ -367,16 +362,6 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
         pool_free(ctx, op->vhat, (size_t)op->g.Ftot * sizeof(double2));
         delete op;
         return rc;
-    }
-    // fold the 1/Ftot of the inverse transform into vhat (hipFFT transforms are unnormalised)
-    hipLaunchKernelGGL(scale_kernel, grid_for(op->g.Ftot, 1, kVecThreads), dim3(kVecThreads), 0, stream, op->vhat,
-                       op->g.Ftot, 1.0 / (double)op->g.Ftot);
-    e = hipGetLastError();
-    if (e != hipSuccess) {
-        pool_free(ctx, op->vhat, (size_t)op->g.Ftot * sizeof(double2));
-        delete op;
-        set_error("efgp_toeplitz_create: scale launch failed: %s", hipGetErrorString(e));
-        return EFGP_EHIP;
     }
     op->persistent_ok = persistent_cg_eligible(op->g);
     if (op->persistent_ok) {
@@ -438,7 +423,7 @@ int efgp_toeplitz_apply(efgp_toeplitz_t* op, const void* x, int nbatch, void* y,
         if (!pad) return EFGP_ENOMEM;
         hipLaunchKernelGGL(pad_scale_kernel, grid_for(op->g.Ftot, rows, kVecThreads), dim3(kVecThreads), 0, stream, op->g,
                            (const double2*)x + r0 * op->g.M, op->g.M, (const double2*)nullptr, (const int*)nullptr,
-                           (const int*)nullptr, pad);
+                           (const int*)nullptr, pad, 1.0);
         EFGP_HIP_CHECK(hipGetLastError());
         int rc = circulant(op, pad, rows, stream);
         if (rc != EFGP_OK) return rc;
@@ -523,7 +508,7 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
 
         // r0 = b - A x0
         hipLaunchKernelGGL(pad_scale_kernel, grid_for(g.Ftot, rows, kVecThreads), dim3(kVecThreads), 0, stream, g,
-                           (const double2*)a.x, g.M, a.ws, (const int*)nullptr, (const int*)nullptr, pad);
+                           (const double2*)a.x, g.M, a.ws, (const int*)nullptr, (const int*)nullptr, pad, 1.0);
         EFGP_HIP_CHECK(hipGetLastError());
         int rc = circulant(op, pad, rows, stream);
         if (rc != EFGP_OK) return rc;
@@ -551,7 +536,7 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
             for (int k = 0; k < burst; ++k) {
                 KernelTimer timer("cg_iteration", stream);
                 hipLaunchKernelGGL(pad_scale_kernel, grid_for(g.Ftot, slots, kVecThreads), dim3(kVecThreads), 0, stream, g,
-                                   (const double2*)a.p, g.M, a.ws, a.rows, (const int*)nullptr, pad);
+                                   (const double2*)a.p, g.M, a.ws, a.rows, (const int*)nullptr, pad, 1.0);
                 EFGP_HIP_CHECK(hipGetLastError());
                 rc = circulant(op, pad, slots, stream);
                 if (rc != EFGP_OK) return rc;
@@ -620,6 +605,22 @@ int efgp_cg_solve_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int
     return persistent_cg_launch(op->g, (const double2* const*)op->tw, op->vhat, (const double2*)ws, precond_diag, sigmasq,
                                 variant, tol, early_stop, batched_semantics, max_iter, (const double2*)b, (double2*)x, nbatch,
                                 row_iters_dev, stream);
+}
+
+int efgp_cg_solve_mean_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, const double* diag_scale_dev, const void* fy,
+                             void* x, double tol, int max_iter, int early_stop, int* iters_dev, void* stream_) {
+    EFGP_REQUIRE(op && ws && fy && x && iters_dev, "efgp_cg_solve_mean_async: null argument");
+    if (!op->persistent_ok || std::getenv("EFGP_NO_PERSISTENT_CG") != nullptr) {
+        set_error("efgp_cg_solve_mean_async: grid does not fit the persistent kernel");
+        return EFGP_EUNSUPPORTED;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(op->device);
+    if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * op->g.M, 2000000000);
+    KernelTimer timer("cg_persistent", stream);
+    return persistent_cg_launch(op->g, (const double2* const*)op->tw, op->vhat, (const double2*)ws, nullptr, sigmasq, 0, tol,
+                                early_stop, 0, max_iter, (const double2*)fy, (double2*)x, 1, iters_dev, stream, diag_scale_dev,
+                                1, 1);
 }
 
 int efgp_vdot_real(int device, const void* a, int a_is_complex, const void* b, int b_is_complex, int64_t count,

@@ -18,6 +18,7 @@ struct ToepGeom {
 bool persistent_cg_eligible(const ToepGeom& g);
 int persistent_cg_launch(const ToepGeom& g, const double2* const* twiddles, const double2* vhat, const double2* ws,
                          const double* diag, double sigmasq, int variant, double tol, int early_stop, int batched,
-                         int max_iter, const double2* b, double2* x, int rows, int* d_iters, hipStream_t stream);
+                         int max_iter, const double2* b, double2* x, int rows, int* d_iters, hipStream_t stream,
+                         const double* diag_scale = nullptr, int b_times_ws = 0, int zero_x0 = 0);
 
 }  // namespace efgp

@@ -49,12 +49,14 @@ _SIGNATURES = {
     "efgp_rademacher_fill": (_I, [_I, C.c_uint64, _I64, _I, _I64, _VP, _VP]),
     "efgp_nufft_type1_pair": (_I, [_VP, _VP, _PI64, _VP, _PI64, _VP, _VP]),
     "efgp_nufft_type2": (_I, [_VP, _VP, _I, _PI64, _I, _I, _VP, _I, _VP]),
+    "efgp_nufft_type2_scaled": (_I, [_VP, _VP, _VP, _I, _PI64, _I, _I, _VP, _I, _VP]),
     "efgp_toeplitz_create": (_I, [C.POINTER(_VP), _I, _I, _PI64, _VP, _I, _VP]),
     "efgp_toeplitz_destroy": (_I, [_VP]),
     "efgp_toeplitz_apply": (_I, [_VP, _VP, _I, _VP, _VP]),
     "efgp_toeplitz_fft_shape": (_I, [_VP, _PI64]),
     "efgp_cg_solve": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _VP]),
     "efgp_cg_solve_async": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, _VP, _VP]),
+    "efgp_cg_solve_mean_async": (_I, [_VP, _VP, _D, _VP, _VP, _VP, _D, _I, _I, _VP, _VP]),
     "efgp_vdot_real": (_I, [_I, _VP, _I, _VP, _I, _I64, C.POINTER(_D), _VP]),
 }
 

@@ -113,8 +113,9 @@ class NufftPlan:
                                               _stream(self.dev)), "efgp_nufft_type1_pair")
         return out_o
 
-    def type2(self, f, n_modes, modeord=0, real_only=False, isign=+1, batched=None):
-        """f (prod,) | (*n_modes) | (B, ...) complex -> (N,) | (B,N) complex128 (float64 if real_only)."""
+    def type2(self, f, n_modes, modeord=0, real_only=False, isign=+1, batched=None, mode_scale=None):
+        """f (prod,) | (*n_modes) | (B, ...) complex -> (N,) | (B,N) complex128 (float64 if real_only).
+        mode_scale (prod,) complex: the modes are multiplied by it inside the transform (F (ws * beta))."""
         M = 1
         for m in n_modes:
             M *= int(m)
@@ -124,8 +125,16 @@ class NufftPlan:
         B = ff.shape[0]
         out = torch.empty((B, self.npts), dtype=_RD if real_only else _CD, device=self.dev)
         with torch.cuda.device(self.dev):
-            check(lib().efgp_nufft_type2(self._h, _ptr(ff), B, _i64(n_modes), isign, int(modeord), _ptr(out),
-                                         int(bool(real_only)), _stream(self.dev)), "efgp_nufft_type2")
+            if mode_scale is None:
+                check(lib().efgp_nufft_type2(self._h, _ptr(ff), B, _i64(n_modes), isign, int(modeord), _ptr(out),
+                                             int(bool(real_only)), _stream(self.dev)), "efgp_nufft_type2")
+            else:
+                sc = mode_scale.reshape(-1).to(device=self.dev, dtype=_CD).contiguous()
+                if sc.numel() != M:
+                    raise ValueError(f"mode_scale has {sc.numel()} entries, the mode box has {M}")
+                check(lib().efgp_nufft_type2_scaled(self._h, _ptr(ff), _ptr(sc), B, _i64(n_modes), isign, int(modeord),
+                                                    _ptr(out), int(bool(real_only)), _stream(self.dev)),
+                      "efgp_nufft_type2_scaled")
         return out if batched else out[0]
 
 
@@ -241,6 +250,34 @@ def cg_solve_async(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_st
     # keep the operands alive until the stream has consumed them: torch's caching allocator only reuses a block
     # for work enqueued later on the same stream, so dropping the Python references here is safe
     return x.reshape(b.shape), LazyIterations(rows_dev, bool(batched), mi)
+
+
+def cg_solve_mean_async(op, ws, sigmasq, diag_scale, fy, tol, max_iter=None, early_stop=True):
+    """The fit's mean system (D T D + sigmasq I) beta = D fy from beta_0 = 0 in ONE launch and without host
+    synchronisation: the right-hand side ws*fy, the Jacobi diagonal diag_scale*|ws|^2 + sigmasq and the zero start
+    are formed inside the kernel.  diag_scale: 0-dim float64 device tensor (may be a view, e.g. v[centre].real) or
+    None for no preconditioner.  Returns (beta, LazyIterations) or None when the grid does not fit the kernel."""
+    from .lib import EFGP_EUNSUPPORTED
+    dev = op.dev
+    ff = fy.reshape(-1).to(device=dev, dtype=_CD).contiguous()
+    if ff.numel() != op.size:
+        raise ValueError(f"fy has {ff.numel()} entries, the operator has {op.size}")
+    wsd = ws.reshape(-1).to(device=dev, dtype=_CD).contiguous()
+    x = torch.empty(op.size, dtype=_CD, device=dev)
+    ds = None
+    if diag_scale is not None:
+        ds = diag_scale.to(device=dev, dtype=_RD)        # no copy for a float64 view on the device
+        if ds.numel() != 1:
+            raise ValueError("diag_scale must hold one value")
+    mi = int(max_iter) if max_iter is not None else 2 * op.size
+    rows_dev = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().efgp_cg_solve_mean_async(op._h, _ptr(wsd), float(sigmasq), _ptr(ds) if ds is not None else None, _ptr(ff),
+                                            _ptr(x), float(tol), mi, int(bool(early_stop)), _ptr(rows_dev), _stream(dev))
+    if rc == EFGP_EUNSUPPORTED:
+        return None
+    check(rc, "efgp_cg_solve_mean_async")
+    return x.reshape(fy.shape), LazyIterations(rows_dev, False, mi)
 
 
 def vdot_real(a, b):

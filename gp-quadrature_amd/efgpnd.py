@@ -30,7 +30,7 @@ from cg import ConjugateGradients
 from kernels.kernel_params import GPParams
 from utils.kernels import get_xis
 
-from efgp_hip import NufftPlan, ToeplitzOp, cg_solve, cg_solve_async, vdot_real, compute_device
+from efgp_hip import NufftPlan, ToeplitzOp, cg_solve, cg_solve_async, cg_solve_mean_async, vdot_real, compute_device
 from efgp_hip.dist import PointShards
 
 TWO_PI = 2.0 * math.pi
@@ -836,24 +836,26 @@ class EFGPND(nn.Module):
         grid = _Grid(self.kernel, self.eps, dd["L"], d, dev)
         plan = NufftPlan(xd, grid.h, min(float(nufft_eps), _CONV_TOL))
         Fy, v = _normal_equations(plan, yd, grid, self._shards)
-        rhs = grid.ws * Fy
         toeplitz = ToeplitzND(v, force_pow2=True)
-        diag = None
-        if self.opts.get("mean_cg_preconditioner", True):
-            diag = _center_value(v) * grid.ws.abs().pow(2).real + sig
+        use_precond = self.opts.get("mean_cg_preconditioner", True)
         tol = self.opts.get("cg_tolerance", 1e-4)
-        if self.opts.get("mean_cg_warm_start", True) and self._beta is not None and \
-                tuple(self._beta.shape) == tuple(rhs.shape):
-            b0 = self._beta.detach().to(device=dev, dtype=torch.complex128)
-        else:
-            b0 = torch.zeros_like(rhs)
-        # no host synchronisation when the solve fits the single-launch kernel: the iteration count stays on the
-        # device until somebody reads last_fit_stats, so the host can already prepare the next transform
-        res = cg_solve_async(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False)
+        warm = self.opts.get("mean_cg_warm_start", True) and self._beta is not None and \
+            tuple(self._beta.shape) == tuple(Fy.shape)
+        # Cold start on a grid that fits the single-launch kernel: rhs = ws*F*y (:792), the Jacobi diagonal
+        # v[0]|ws|^2 + sigma^2 (:795-799) and beta_0 = 0 are formed inside the solve kernel -- one launch, no host
+        # synchronisation (the iteration count stays on the device until somebody reads last_fit_stats).
+        res = None
+        if not warm:
+            res = cg_solve_mean_async(toeplitz._op, grid.ws, sig, _center_value(v) if use_precond else None, Fy, tol,
+                                      early_stop=True)
         if res is None:
-            beta, iters, _ = cg_solve(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False)
-        else:
-            beta, iters = res
+            rhs = grid.ws * Fy
+            diag = _center_value(v) * grid.ws.abs().pow(2).real + sig if use_precond else None
+            b0 = self._beta.detach().to(device=dev, dtype=torch.complex128) if warm else torch.zeros_like(rhs)
+            res = cg_solve_async(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False)
+            if res is None:
+                res = cg_solve(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False)[:2]
+        beta, iters = res
 
         xis = grid.xis.to(dtype=rdtype)
         xis.h_float = grid.h
@@ -893,7 +895,7 @@ class EFGPND(nn.Module):
         t0 = time.perf_counter()
         shape = (st["mtot"],) * d                       # carried explicitly (the reference re-derives it, :908)
         plan = NufftPlan(xn, st["h"], float(nufft_eps))
-        mean = plan.type2(st["ws"] * st["beta"], shape, real_only=True)
+        mean = plan.type2(st["beta"], shape, real_only=True, mode_scale=st["ws"])     # F (ws * beta), efgpnd.py:919-922
         out_mean = mean.to(device=self.device, dtype=rdtype)
         t1 = time.perf_counter()
         if return_variance:

@@ -107,6 +107,12 @@ int efgp_nufft_type1_pair(efgp_nufft_t* plan, const double* y, const int64_t* n_
 int efgp_nufft_type2(efgp_nufft_t* plan, const void* f, int nbatch, const int64_t* n_modes, int isign,
                      int modeord, void* out, int real_only, void* stream);
 
+/* Same, with the modes multiplied on the fly by a mode-shaped complex array shared by all batch rows:
+ *     out[b, n] = sum_k mode_scale[k] f[b, k] exp(isign * i * k . phi_n)
+ * i.e. the reference's F (ws * beta) at efgpnd.py:919-922 without materialising ws * beta. */
+int efgp_nufft_type2_scaled(efgp_nufft_t* plan, const void* f, const void* mode_scale, int nbatch, const int64_t* n_modes,
+                            int isign, int modeord, void* out, int real_only, void* stream);
+
 /* ---- Toeplitz operator: replaces efgpnd.py ToeplitzND (:1239-1393) --------------------------
  * v: (L_1,...,L_d) complex, T[j,l] = v[j - l + (n-1)], n_a = (L_a+1)/2.  FFT length per dimension
  * is next_pow2(L_a) when force_pow2 (efgpnd.py:1269) else the next 2^a3^b5^c size >= L_a. */
@@ -144,6 +150,15 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
 int efgp_cg_solve_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant,
                         const double* precond_diag, const void* b, void* x, int nbatch, double tol,
                         int max_iter, int early_stop, int batched_semantics, int* row_iters_dev, void* stream);
+
+/* The fit's mean system in one launch, straight from the transform outputs (efgpnd.py:792-803):
+ *     (D T D + sigmasq I) beta = D fy,   D = diag(ws),   beta_0 = 0,
+ * Jacobi diagonal (*diag_scale_dev) * |ws|^2 + sigmasq when diag_scale_dev is not NULL (device pointer to the
+ * real centre value of the Toeplitz vector, efgpnd.py:795-799), single-system stopping rule of cg.py:116-150.
+ * Replaces the reference's separate ws*Fy, |ws|^2 diagonal and zeros(x0) tensor ops plus efgp_cg_solve_async.
+ * EFGP_EUNSUPPORTED when the grid does not fit the single-launch kernel (callers fall back to efgp_cg_solve). */
+int efgp_cg_solve_mean_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, const double* diag_scale_dev, const void* fy,
+                             void* x, double tol, int max_iter, int early_stop, int* iters_dev, void* stream);
 
 /* ---- N-length reductions of the hyper-gradient (efgpnd.py:163, 170, 239) ----------------------
  * out_host[0] = Re sum_n conj(a_n) b_n over n < count; each operand is complex (interleaved) when

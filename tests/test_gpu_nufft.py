@@ -77,6 +77,14 @@ def test_type2_fft_order_and_batch():
     ref = torch.stack([O.nudft_type2(x, h, f[b], (nm, nm), fft_order=True) for b in range(3)])
     assert out.shape == (3, N)
     assert _rel(out, ref) < 5e-9
+    # modes scaled inside the transform (F (ws * beta)): same as scaling first; shared by the batch rows
+    sc = torch.complex(torch.randn(nm, nm, generator=g, dtype=torch.float64), torch.randn(nm, nm, generator=g, dtype=torch.float64))
+    for ro in (False, True):
+        a = plan.type2(f.cuda(), (nm, nm), real_only=ro, mode_scale=sc.cuda())
+        b = plan.type2((f * sc).cuda(), (nm, nm), real_only=ro)
+        assert _rel(a, b) < 1e-13
+    with pytest.raises(ValueError):
+        plan.type2(f.cuda(), (nm, nm), mode_scale=sc[:3].cuda())
 
 
 def test_type1_batched_and_pair():

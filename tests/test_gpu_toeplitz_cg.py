@@ -116,3 +116,32 @@ def test_persistent_and_multikernel_cg_agree(d, mtot, monkeypatch):
         assert _rel(xg, xo) < 1e-7
     assert abs(out["persistent_1"][1] - out["multikernel_1"][1]) <= 1
     assert _rel(out["persistent_1"][0], out["multikernel_1"][0]) < 1e-7
+
+
+@pytest.mark.parametrize("d,mtot,precond", [(2, 23, True), (2, 23, False), (1, 35, True), (3, 7, True), (2, 15, True)])
+def test_fused_mean_system_matches_general_solve(d, mtot, precond):
+    """efgp_cg_solve_mean_async forms ws*F*y, the Jacobi diagonal v[0]|ws|^2+sigma^2 and beta_0 = 0 inside the
+    kernel: same iterates as the general entry point given the materialised tensors (and as the oracle)."""
+    from efgp_hip import ToeplitzOp, cg_solve, cg_solve_mean_async
+    from oracle import efgp_oracle as O
+    x, v, T = _setup(d, mtot, N=900, seed=4)
+    M = T.size
+    g = torch.Generator().manual_seed(8)
+    ws = torch.exp(-2.5 * torch.rand(M, generator=g, dtype=torch.float64)).to(torch.complex128)
+    sig2 = 0.25
+    fy = torch.complex(torch.randn(M, generator=g, dtype=torch.float64), torch.randn(M, generator=g, dtype=torch.float64))
+    vd = v.cuda()
+    centre = vd[tuple((s - 1) // 2 for s in vd.shape)].real            # a view into v: no copy, no kernel
+    op = ToeplitzOp(vd)
+    res = cg_solve_mean_async(op, ws.cuda(), sig2, centre if precond else None, fy.cuda(), 1e-8)
+    assert res is not None
+    beta, lazy = res
+    rhs = ws * fy
+    diag = (float(centre) * ws.abs().pow(2).real + sig2) if precond else None
+    xg, itg, _ = cg_solve(op, ws.cuda(), sig2, 0, rhs.cuda(), torch.zeros_like(rhs).cuda(), 1e-8,
+                          diag=diag.cuda() if precond else None, batched=False)
+    assert int(lazy) == itg
+    assert _rel(beta, xg) < 1e-13
+    xo, ito = O.cg_single(O.make_A_mean(ws, T, sig2), rhs, torch.zeros_like(rhs), 1e-8, diag=diag)
+    assert abs(int(lazy) - ito) <= (0 if ito < 100 else 1 + ito // 200) and _rel(beta, xo) < 1e-7
+    assert beta.shape == fy.shape
