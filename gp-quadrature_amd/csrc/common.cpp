@@ -150,6 +150,8 @@ void release_ctx(int device) {
         for (int s = 0; s < SLOT_COUNT; ++s)
             if (c->buf[s]) (void)hipFree(c->buf[s]);
         if (c->host_pinned) (void)hipHostFree(c->host_pinned);
+        if (c->aux_event) (void)hipEventDestroy(c->aux_event);
+        if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
         for (auto& kv : c->pool)
             for (void* p : kv.second) (void)hipFree(p);
         for (auto& kv : c->twiddles) (void)hipFree(kv.second);

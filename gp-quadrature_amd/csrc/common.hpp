@@ -77,6 +77,9 @@ struct DeviceCtx {
     std::map<int64_t, void*> twiddles;
     // SLOT_SCALE holds the spreader's max|c| accumulator: zeroed once, then reset by the kernel that consumes it
     bool scale_slot_ready = false;
+    // side stream for hipGraph capture (capture is not allowed on the legacy default stream torch usually hands us)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aux_event = nullptr;
 };
 
 // returns the context of `device` (creates it, queries properties); nullptr + error on failure

@@ -43,6 +43,20 @@ __device__ __forceinline__ int64_t pad_index(const ToepGeom& g, int64_t flat, in
     return idx;
 }
 
+// the same in 32-bit arithmetic (grids of the CG path have far fewer than 2^31 cells): a third of the ALU work
+__device__ __forceinline__ int pad_index32(const ToepGeom& g, int flat, int off_mul) {
+    int idx = 0, stride = 1;
+    for (int a = g.d - 1; a >= 0; --a) {
+        const int na = (int)g.n[a];
+        const int q = flat / na;
+        const int ia = flat - q * na;
+        flat = q;
+        idx += (ia + off_mul * (na - 1)) * stride;
+        stride *= (int)g.F[a];
+    }
+    return idx;
+}
+
 // pad[row][:] = 0 except the leading n-box which receives scale .* src[rows[row]]
 // (scale may be null), times the real `factor`.  One launch covers all rows: grid = (blocks, nrows).
 __global__ void pad_scale_kernel(ToepGeom g, const double2* __restrict__ src, int64_t src_stride,
@@ -96,9 +110,15 @@ __global__ void crop_kernel(ToepGeom g, const double2* __restrict__ pad, double2
 struct CgRowScalars {   // one per row
     double rz;
     double den;        // |b| or 1
+    double pAp;        // <p, A p> + div_eps of the current iteration (written by the last block of cg_dot_kernel)
+    double beta;       // p <- z + beta p is applied by the NEXT iteration's cg_pad_kernel when do_p is set
     int active;
     int iters;         // iterations in which this row was updated
+    int do_p;
+    int pad_;
 };
+
+constexpr int kCgBlocksMax = 64;     // workgroups per system in the multi-kernel update (partials per reduction)
 
 struct CgArgs {
     ToepGeom g;
@@ -113,10 +133,15 @@ struct CgArgs {
     double2* x;
     double2* r;
     double2* p;
-    const double2* pad;       // inverse-FFT output, row slot = blockIdx.x
+    double2* ap;              // A p of the current iteration (written by cg_dot_kernel, read by cg_axpy_kernel)
+    const double2* pad;       // inverse-FFT output, row slot = blockIdx.y
+    double2* pad_out;         // the same buffer, written by cg_pad_kernel
     const int* rows;          // slot -> row (null: identity)
     CgRowScalars* sc;
     int* status;              // [0] = number of active rows (recomputed by host), [1] = any-change flag
+    double* partial;          // [rows][3][kCgBlocksMax] per-workgroup partial sums
+    int* counter;             // [rows][2] arrival counters of the two reductions
+    int nblk;                 // workgroups per system
 };
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -170,34 +195,131 @@ __global__ __launch_bounds__(kCgThreads) void cg_init_kernel(CgArgs a) {
         a.sc[row].den = bn > 0.0 ? bn : 1.0;
         a.sc[row].active = 1;
         a.sc[row].iters = 0;
+        a.sc[row].pAp = 1.0;
+        a.sc[row].beta = 0.0;
+        a.sc[row].do_p = 0;
+        a.sc[row].pad_ = 0;
     }
 }
 
-// one CG iteration for the row in slot blockIdx.x (cg.py:116-150 / :193-241)
-__global__ __launch_bounds__(kCgThreads) void cg_update_kernel(CgArgs a) {
-    __shared__ double red[kCgThreads / 64];
-    const int slot = blockIdx.x;
+// ---- one CG iteration (cg.py:116-150 / :193-241), spread over nblk workgroups per system ----------------
+// A system with M up to ~2e5 unknowns is far too long for one workgroup (measured: 60 us per iteration at
+// M = 12167), so the iteration is three launches over (nblk, slots) grids; dot products are reduced in two
+// deterministic levels: fixed-order sums inside a workgroup, then the LAST workgroup to arrive (device-scope
+// arrival counter) adds the nblk partials in index order and publishes the scalars.  The direction update
+// p <- z + beta p is deferred into the next iteration's pad kernel, which needs ws .* p anyway.
+__device__ __forceinline__ double load_agent(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // bypasses this CU's L1
+}
+// returns true in every thread of the LAST workgroup of `row` to arrive at counter `which`
+__device__ __forceinline__ bool arrive_last(const CgArgs& a, int row, int which, int* flag) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int prev = atomicAdd(&a.counter[2 * row + which], 1);
+        *flag = prev == a.nblk - 1;
+        if (*flag) a.counter[2 * row + which] = 0;       // all arrivals of this iteration are in
+    }
+    __syncthreads();
+    const bool last = *flag != 0;
+    if (last) __threadfence();
+    return last;
+}
+__device__ __forceinline__ void block_range(const CgArgs& a, int64_t& lo, int64_t& hi) {
+    const int64_t per = (a.g.M + a.nblk - 1) / a.nblk;
+    lo = (int64_t)blockIdx.x * per;
+    hi = lo + per < a.g.M ? lo + per : a.g.M;
+}
+
+// pad[slot] = zero-padded ws .* p, after the deferred direction update p <- r/diag + beta p
+__global__ __launch_bounds__(kVecThreads) void cg_pad_kernel(CgArgs a) {
+    const int slot = blockIdx.y;
     const int row = a.rows ? a.rows[slot] : slot;
     if (row < 0) return;
-    CgRowScalars sc = a.sc[row];
+    const CgRowScalars sc = a.sc[row];
     if (!sc.active) return;
-    const int64_t M = a.g.M;
+    const ToepGeom& g = a.g;
+    double2* P = a.pad_out + (int64_t)slot * g.Ftot;
+    const int64_t base = (int64_t)row * g.M;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < g.Ftot; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t rem = t, flat = 0;
+        bool inside = true;
+        int64_t coords[3];
+        for (int q = g.d - 1; q >= 0; --q) {
+            coords[q] = rem % g.F[q];
+            rem /= g.F[q];
+            inside = inside && coords[q] < g.n[q];
+        }
+        double2 v = make_double2(0.0, 0.0);
+        if (inside) {
+            for (int q = 0; q < g.d; ++q) flat = flat * g.n[q] + coords[q];
+            double2 pv = a.p[base + flat];
+            if (sc.do_p) {
+                double2 zv = a.r[base + flat];
+                if (a.diag) {
+                    zv.x /= a.diag[flat];
+                    zv.y /= a.diag[flat];
+                }
+                pv = make_double2(zv.x + sc.beta * pv.x, zv.y + sc.beta * pv.y);
+                a.p[base + flat] = pv;
+            }
+            v = cmul(pv, a.ws[flat]);
+        }
+        P[t] = v;
+    }
+}
+
+// A p and <p, A p>
+__global__ __launch_bounds__(kVecThreads) void cg_dot_kernel(CgArgs a) {
+    __shared__ double red[kVecThreads / 64];
+    __shared__ int flag;
+    const int slot = blockIdx.y;
+    const int row = a.rows ? a.rows[slot] : slot;
+    if (row < 0) return;
+    if (!a.sc[row].active) return;
     const double2* P = a.pad + (int64_t)slot * a.g.Ftot;
-    const int64_t base = (int64_t)row * M;
-    // pass 1: <p, Ap>
+    const int64_t base = (int64_t)row * a.g.M;
+    int64_t lo, hi;
+    block_range(a, lo, hi);
     double pAp = 0.0;
-    for (int64_t t = threadIdx.x; t < M; t += kCgThreads) {
-        double2 pv = a.p[base + t];
-        double2 Ap = apply_A(a, a.ws[t], P[pad_index(a.g, t, 1)], pv);
+    for (int64_t t = lo + threadIdx.x; t < hi; t += kVecThreads) {
+        const double2 pv = a.p[base + t];
+        const double2 Ap = apply_A(a, a.ws[t], P[pad_index32(a.g, (int)t, 1)], pv);
+        a.ap[base + t] = Ap;
         pAp += pv.x * Ap.x + pv.y * Ap.y;
     }
-    pAp = block_sum(pAp, red) + kDivEps;
-    const double alpha = sc.rz / pAp;
-    // pass 2: x += alpha p, r -= alpha Ap, |r|^2, <r, r/diag>
+    pAp = block_sum(pAp, red);
+    double* part = a.partial + (int64_t)row * 3 * kCgBlocksMax;
+    if (threadIdx.x == 0) part[blockIdx.x] = pAp;
+    if (arrive_last(a, row, 0, &flag)) {
+        __shared__ double fin[kCgBlocksMax];
+        if (threadIdx.x < a.nblk) fin[threadIdx.x] = load_agent(&part[threadIdx.x]);     // loads in parallel
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < a.nblk; ++i) t += fin[i];                                    // summed in index order
+            a.sc[row].pAp = t + kDivEps;
+        }
+    }
+}
+
+// x += alpha p, r -= alpha A p, |r|^2, <r, r/diag>; the last workgroup decides convergence and beta
+__global__ __launch_bounds__(kVecThreads) void cg_axpy_kernel(CgArgs a) {
+    __shared__ double red[kVecThreads / 64];
+    __shared__ int flag;
+    const int slot = blockIdx.y;
+    const int row = a.rows ? a.rows[slot] : slot;
+    if (row < 0) return;
+    const CgRowScalars sc = a.sc[row];
+    if (!sc.active) return;
+    const int64_t base = (int64_t)row * a.g.M;
+    int64_t lo, hi;
+    block_range(a, lo, hi);
+    const double alpha = sc.rz / sc.pAp;
     double rr = 0.0, rz_new = 0.0;
-    for (int64_t t = threadIdx.x; t < M; t += kCgThreads) {
-        double2 pv = a.p[base + t];
-        double2 Ap = apply_A(a, a.ws[t], P[pad_index(a.g, t, 1)], pv);
+    for (int64_t t = lo + threadIdx.x; t < hi; t += kVecThreads) {
+        const double2 pv = a.p[base + t];
+        const double2 Ap = a.ap[base + t];
         double2 xv = a.x[base + t];
         double2 rv = a.r[base + t];
         xv.x += alpha * pv.x;
@@ -206,40 +328,44 @@ __global__ __launch_bounds__(kCgThreads) void cg_update_kernel(CgArgs a) {
         rv.y -= alpha * Ap.y;
         a.x[base + t] = xv;
         a.r[base + t] = rv;
-        double q = rv.x * rv.x + rv.y * rv.y;
+        const double q = rv.x * rv.x + rv.y * rv.y;
         rr += q;
         rz_new += a.diag ? q / a.diag[t] : q;
     }
     rr = block_sum(rr, red);
     rz_new = block_sum(rz_new, red);
-    const double rnorm = sqrt(rr);
-    const bool conv = a.early_stop && ((rnorm / (sc.den + kDivEps) < a.tol) || (a.batched && rnorm < 1e-12));
-    if (!a.batched && conv) {            // cg.py:132 -- stop before touching p
-        if (threadIdx.x == 0) {
-            a.sc[row].active = 0;
-            a.sc[row].iters = sc.iters + 1;
-            atomicAdd(&a.status[1], 1);
-        }
-        return;
-    }
-    const double beta = rz_new / (sc.rz + kDivEps);
-    for (int64_t t = threadIdx.x; t < M; t += kCgThreads) {
-        double2 rv = a.r[base + t];
-        double2 pv = a.p[base + t];
-        double2 zv = rv;
-        if (a.diag) {
-            zv.x = rv.x / a.diag[t];
-            zv.y = rv.y / a.diag[t];
-        }
-        a.p[base + t] = make_double2(zv.x + beta * pv.x, zv.y + beta * pv.y);
-    }
+    double* part = a.partial + (int64_t)row * 3 * kCgBlocksMax;
     if (threadIdx.x == 0) {
-        a.sc[row].rz = rz_new;
-        a.sc[row].iters = sc.iters + 1;
-        if (conv) {                      // batched: deactivate after the p update, cg.py:229-241
-            a.sc[row].active = 0;
-            atomicAdd(&a.status[1], 1);
+        part[kCgBlocksMax + blockIdx.x] = rr;
+        part[2 * kCgBlocksMax + blockIdx.x] = rz_new;
+    }
+    if (!arrive_last(a, row, 1, &flag)) return;
+    __shared__ double fin[2 * kCgBlocksMax];
+    if (threadIdx.x < a.nblk) {
+        fin[threadIdx.x] = load_agent(&part[kCgBlocksMax + threadIdx.x]);
+        fin[kCgBlocksMax + threadIdx.x] = load_agent(&part[2 * kCgBlocksMax + threadIdx.x]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double srr = 0.0, srz = 0.0;
+        for (int i = 0; i < a.nblk; ++i) {
+            srr += fin[i];
+            srz += fin[kCgBlocksMax + i];
         }
+        const double rnorm = sqrt(srr);
+        const bool conv = a.early_stop && ((rnorm / (sc.den + kDivEps) < a.tol) || (a.batched && rnorm < 1e-12));
+        CgRowScalars out = sc;
+        out.iters = sc.iters + 1;
+        if (conv) {                          // single: stop before the p update (cg.py:132); batched: after it
+            out.active = 0;                  // (cg.py:229-241) -- p is never used again either way
+            out.do_p = 0;
+            atomicAdd(&a.status[1], 1);
+        } else {
+            out.beta = srz / (sc.rz + kDivEps);
+            out.do_p = 1;
+        }
+        if (!(conv && !a.batched)) out.rz = srz;
+        a.sc[row] = out;
     }
 }
 
@@ -475,14 +601,35 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         return EFGP_OK;
     }
 
+    // The iteration bursts below are replayed as hipGraphs, which cannot be captured on the legacy default stream:
+    // run the multi-kernel solve on a side stream ordered after the caller's stream (the final poll of every group
+    // synchronises the host with it, so later work on the caller's stream is ordered after the solve).
+    if (!timing_enabled() && std::getenv("EFGP_NO_CG_GRAPH") == nullptr) {
+        if (!ctx->aux_stream) {
+            if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ctx->aux_event, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->aux_stream = nullptr;
+            }
+        }
+        if (ctx->aux_stream) {
+            EFGP_HIP_CHECK(hipEventRecord(ctx->aux_event, stream));
+            EFGP_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_event, 0));
+            stream = ctx->aux_stream;
+        }
+    }
     // rows are processed in groups whose padded grids fit ~512 MB of scratch
     const int64_t group_cap = std::max<int64_t>(1, (int64_t)(512ll << 20) / (g.Ftot * (int64_t)sizeof(double2)));
     int global_iters = 0;
     for (int64_t r0 = 0; r0 < nbatch; r0 += group_cap) {
         const int rows = (int)std::min<int64_t>(group_cap, nbatch - r0);
         double2* pad = (double2*)scratch(ctx, SLOT_TOEP_PAD, (size_t)rows * (size_t)g.Ftot * sizeof(double2));
-        double2* vec = (double2*)scratch(ctx, SLOT_CG_VEC, (size_t)2 * rows * (size_t)g.M * sizeof(double2));
-        const size_t sc_bytes = (size_t)rows * sizeof(CgRowScalars) + (size_t)rows * sizeof(int) + 64;
+        double2* vec = (double2*)scratch(ctx, SLOT_CG_VEC, (size_t)3 * rows * (size_t)g.M * sizeof(double2));
+        // scalars | status (64 B) + slot->row map | arrival counters | per-workgroup partial sums
+        const size_t off_status = ((size_t)rows * sizeof(CgRowScalars) + 63) & ~size_t(63);
+        const size_t off_counter = off_status + 64 + (((size_t)rows * sizeof(int) + 63) & ~size_t(63));
+        const size_t off_partial = off_counter + (((size_t)2 * rows * sizeof(int) + 63) & ~size_t(63));
+        const size_t sc_bytes = off_partial + (size_t)rows * 3 * kCgBlocksMax * sizeof(double);
         char* scb = (char*)scratch(ctx, SLOT_CG_SCALARS, sc_bytes);
         int* host = pinned_host(ctx, (size_t)rows * sizeof(CgRowScalars) + 64);
         if (!pad || !vec || !scb || !host) return EFGP_ENOMEM;
@@ -499,12 +646,17 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         a.x = (double2*)x + r0 * g.M;
         a.r = vec;
         a.p = vec + (int64_t)rows * g.M;
+        a.ap = vec + (int64_t)2 * rows * g.M;
         a.pad = pad;
+        a.pad_out = pad;
         a.rows = nullptr;
         a.sc = (CgRowScalars*)scb;
-        a.status = (int*)(scb + (size_t)rows * sizeof(CgRowScalars));
+        a.status = (int*)(scb + off_status);
         int* d_rows = a.status + 16;
-        EFGP_HIP_CHECK(hipMemsetAsync(a.status, 0, 64, stream));
+        a.counter = (int*)(scb + off_counter);
+        a.partial = (double*)(scb + off_partial);
+        a.nblk = (int)std::max<int64_t>(1, std::min<int64_t>(kCgBlocksMax, (g.M + kVecThreads - 1) / kVecThreads));
+        EFGP_HIP_CHECK(hipMemsetAsync(a.status, 0, off_partial - off_status, stream));      // status, map, counters
 
         // r0 = b - A x0
         hipLaunchKernelGGL(pad_scale_kernel, grid_for(g.Ftot, rows, kVecThreads), dim3(kVecThreads), 0, stream, g,
@@ -524,6 +676,10 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         int last_active_it = 0;       // number of iterations in which at least one row was active
         const int poll_every = 8;
         std::vector<CgRowScalars> hsc(rows);
+        bool use_graph = !timing_enabled() && std::getenv("EFGP_NO_CG_GRAPH") == nullptr;
+        hipGraphExec_t graph_exec = nullptr;
+        int graph_slots = -1;
+        const int* graph_rows = nullptr;
         while (it < max_iter && n_active > 0) {
             const int burst = std::min(poll_every, max_iter - it);
             // FFT batch = number of slots (bucketed to a power of two to bound the number of plans)
@@ -533,15 +689,60 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
                 while (p2 < n_active) p2 <<= 1;
                 slots = std::min(p2, rows);
             }
-            for (int k = 0; k < burst; ++k) {
-                KernelTimer timer("cg_iteration", stream);
-                hipLaunchKernelGGL(pad_scale_kernel, grid_for(g.Ftot, slots, kVecThreads), dim3(kVecThreads), 0, stream, g,
-                                   (const double2*)a.p, g.M, a.ws, a.rows, (const int*)nullptr, pad, 1.0);
+            // One iteration = 5 launches of ours + two rocFFT executions (~11 kernels): enqueueing them one by one
+            // costs the host ~300 us per iteration (measured, 3-D 64^3), far more than the GPU needs.  A full burst is
+            // therefore captured ONCE into a hipGraph per (slots, row map) state and replayed with one launch.
+            auto enqueue_iteration = [&]() -> int {
+                hipLaunchKernelGGL(cg_pad_kernel, grid_for(g.Ftot, slots, kVecThreads), dim3(kVecThreads), 0, stream, a);
                 EFGP_HIP_CHECK(hipGetLastError());
-                rc = circulant(op, pad, slots, stream);
-                if (rc != EFGP_OK) return rc;
-                hipLaunchKernelGGL(cg_update_kernel, dim3(slots), dim3(kCgThreads), 0, stream, a);
+                int rcc = circulant(op, pad, slots, stream);
+                if (rcc != EFGP_OK) return rcc;
+                hipLaunchKernelGGL(cg_dot_kernel, dim3(a.nblk, slots), dim3(kVecThreads), 0, stream, a);
+                hipLaunchKernelGGL(cg_axpy_kernel, dim3(a.nblk, slots), dim3(kVecThreads), 0, stream, a);
                 EFGP_HIP_CHECK(hipGetLastError());
+                return EFGP_OK;
+            };
+            bool launched = false;
+            if (use_graph && burst == poll_every) {
+                if (graph_exec && (graph_slots != slots || graph_rows != a.rows)) {
+                    (void)hipGraphExecDestroy(graph_exec);
+                    graph_exec = nullptr;
+                }
+                if (!graph_exec) {
+                    hipGraph_t graph = nullptr;
+                    // make sure the FFT plan exists and is bound to the stream before capturing
+                    hipfftHandle fh_unused;
+                    rc = fft_plan(ctx, g.d, g.F, slots, stream, &fh_unused);
+                    if (rc != EFGP_OK) return rc;
+                    bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                    if (ok) {
+                        int rcap = EFGP_OK;
+                        for (int k = 0; k < burst && rcap == EFGP_OK; ++k) rcap = enqueue_iteration();
+                        const hipError_t ee = hipStreamEndCapture(stream, &graph);
+                        ok = rcap == EFGP_OK && ee == hipSuccess && graph != nullptr;
+                    }
+                    if (ok) ok = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0) == hipSuccess;
+                    if (graph) (void)hipGraphDestroy(graph);
+                    if (!ok) {
+                        (void)hipGetLastError();
+                        graph_exec = nullptr;
+                        use_graph = false;            // this runtime cannot capture the sequence: enqueue directly
+                    } else {
+                        graph_slots = slots;
+                        graph_rows = a.rows;
+                    }
+                }
+                if (graph_exec) {
+                    EFGP_HIP_CHECK(hipGraphLaunch(graph_exec, stream));
+                    launched = true;
+                }
+            }
+            if (!launched) {
+                for (int k = 0; k < burst; ++k) {
+                    KernelTimer timer("cg_iteration", stream);
+                    rc = enqueue_iteration();
+                    if (rc != EFGP_OK) return rc;
+                }
             }
             it += burst;
             EFGP_HIP_CHECK(hipMemcpyAsync(hsc.data(), a.sc, (size_t)rows * sizeof(CgRowScalars), hipMemcpyDeviceToHost, stream));
@@ -567,6 +768,7 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
             }
             n_active = new_active;
         }
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         // iteration counts (cg.py:152 single; cg.py:193-199,243 batched: +1 for the terminating pass)
         int group_iters;
         if (!batched_semantics) {

@@ -260,12 +260,15 @@ class _Grid:
         self.xis_1d = xis_1d
         mesh = torch.meshgrid(*(xis_1d for _ in range(d)), indexing="ij")
         self.xis = torch.stack(mesh, dim=-1).view(-1, d)                         # (M,d) host float64
-        S = kernel.spectral_density(self.xis).to(torch.float64)
-        self.ws_host = torch.sqrt(S.to(torch.complex128) * self.h ** d)          # (M,) complex, imag 0
-        self.ws = self.ws_host.to(dev)
+        # Small grids: evaluate the spectral density on the host (one upload instead of several launches).  Large
+        # grids (3-D): on the device -- torch's CPU reductions switch to their threaded path above 32768 elements,
+        # which costs tens of milliseconds per call on a many-core host (measured: 89 ms for M = 12167, d = 3).
+        where = self.xis if self.M * d <= 16384 else self.xis.to(dev)
+        S = kernel.spectral_density(where).to(torch.float64)
+        self.ws = torch.sqrt(S.to(torch.complex128) * self.h ** d).to(dev)       # (M,) complex, imag 0
         self.dprime = None
         if want_grad:
-            self.dprime = (self.h ** d * kernel.spectral_grad(self.xis)).to(torch.complex128).to(dev)   # (M,H)
+            self.dprime = (self.h ** d * kernel.spectral_grad(where)).to(torch.complex128).to(dev)   # (M,H)
 
 
 def _domain_length(xd: torch.Tensor, shards: PointShards) -> float:
