@@ -1132,7 +1132,7 @@ __global__ void deconvolve_pair_kernel(const double2* __restrict__ fine, int64_t
 
 // type 2: fine[b][k mod nf] = fac * f[b][slot] (* mul[slot] when given), zero outside the mode box: every
 // fine cell is written, so the grid needs no memset.  herm != 0 stores the Hermitian part
-// (f[k] + conj f[-k])/2 so that the transformed grid is real (real_only outputs).
+// (f[k] + conj f[-k])/2, whose transform is the real part of the full one (real_only outputs).
 __global__ void precorrect_kernel(const double2* __restrict__ fin, const double2* __restrict__ mul, ModeGeom m, int herm,
                                   int64_t cells, double2* __restrict__ fine) {
     const int batch = blockIdx.y;
@@ -1164,12 +1164,11 @@ __global__ void precorrect_kernel(const double2* __restrict__ fin, const double2
             }
             double2 v = fb[t];
             if (mul) v = make_double2(v.x * mul[t].x - v.y * mul[t].y, v.x * mul[t].y + v.y * mul[t].x);
-            if (herm) {
-                double2 u = make_double2(0.0, 0.0);
-                if (has_neg) {
-                    u = fb[tn];
-                    if (mul) u = make_double2(u.x * mul[tn].x - u.y * mul[tn].y, u.x * mul[tn].y + u.y * mul[tn].x);
-                }
+            // a mode without partner (k = -nm/2 of an even box) stays as it is: the gather reads only the real part of
+            // the transformed grid, and Re(f e^{ikx}) is that mode's whole contribution to the real part
+            if (herm && has_neg) {
+                double2 u = fb[tn];
+                if (mul) u = make_double2(u.x * mul[tn].x - u.y * mul[tn].y, u.x * mul[tn].y + u.y * mul[tn].x);
                 v = make_double2(0.5 * (v.x + u.x), 0.5 * (v.y - u.y));
             }
             r = make_double2(v.x * f, v.y * f);
@@ -1564,6 +1563,170 @@ template <int D>
 static hipError_t launch_spread_d(int W, bool use_lds, dim3 grid, size_t lds_bytes, hipStream_t s, const SpreadArgs& a) {
     switch (W) {
 #define EFGP_CASE(w_) case w_: return launch_spread_dw<D, w_>(use_lds, grid, lds_bytes, s, a);
+        EFGP_CASE(2) EFGP_CASE(3) EFGP_CASE(4) EFGP_CASE(5) EFGP_CASE(6) EFGP_CASE(7) EFGP_CASE(8) EFGP_CASE(9)
+        EFGP_CASE(10) EFGP_CASE(11) EFGP_CASE(12) EFGP_CASE(13) EFGP_CASE(14) EFGP_CASE(15) EFGP_CASE(16)
+#undef EFGP_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
+// Tiled type-2 gather for fine grids beyond LDS (all 3-D cases, large 2-D): the counterpart of
+// spread_tile_kernel.  Points are counting-sorted by tile once per plan (same binning kernels); a workgroup
+// takes a contiguous chunk of sorted points and, per tile segment, copies the tile's (T+W-1)^d neighbourhood of
+// the fine grid (real part only for real outputs) into LDS with the wrap-around resolved, then every thread
+// gathers its points from LDS with plain strided reads and writes the result to the point's original slot.
+// Before: W^d reads per point through L2 (15.4 ms at N=1e7, d=3).
+// ------------------------------------------------------------------------------------------
+struct TileInterpArgs {
+    TileGeom t;
+    const double* xs;         // tile-sorted coordinates
+    const int* order;         // sorted position -> original index
+    const int* start;         // [nbins + 1]
+    int64_t npts;
+    int64_t chunk;            // sorted points per workgroup
+    const double* coef;
+    int degree;
+    const double2* fine;      // [batch][cells]
+    int64_t cells;
+    void* out;                // [batch][npts] complex or real
+};
+
+template <int D, int W, bool CPLX>
+__global__ __launch_bounds__(kInterpThreads) void interp_tile_kernel(TileInterpArgs a) {
+    extern __shared__ double lds[];
+    __shared__ int s_bin;
+    const TileGeom& t = a.t;
+    const int batch = blockIdx.y;
+    const int e0 = t.ext[0], e1 = t.ext[1], e2 = t.ext[2];
+    const int tcells = e0 * e1 * e2;
+    const int64_t lo = (int64_t)blockIdx.x * a.chunk;
+    const int64_t hi = lo + a.chunk < a.npts ? lo + a.chunk : a.npts;
+    if (lo >= hi) return;
+    const double2* F = a.fine + (int64_t)batch * a.cells;
+    double2* lc = reinterpret_cast<double2*>(lds);
+    if (threadIdx.x == 0) {
+        int l = 0, r = t.nbins;            // invariant: start[l] <= lo < start[r]
+        while (r - l > 1) {
+            const int m = (l + r) >> 1;
+            if ((int64_t)a.start[m] <= lo) l = m;
+            else r = m;
+        }
+        s_bin = l;
+    }
+    __syncthreads();
+    int bin = s_bin;
+    int64_t cur = lo;
+    while (cur < hi) {
+        while ((int64_t)a.start[bin + 1] <= cur) ++bin;            // skip empty tiles
+        const int64_t seg_hi = (int64_t)a.start[bin + 1] < hi ? (int64_t)a.start[bin + 1] : hi;
+        int rem = bin, o[3] = {0, 0, 0};
+        for (int q = D - 1; q >= 0; --q) {
+            o[q] = (rem % t.nt[q]) * t.T[q];
+            rem /= t.nt[q];
+        }
+        for (int i = threadIdx.x; i < tcells; i += kInterpThreads) {
+            const int l2 = i % e2, l1 = (i / e2) % e1, l0 = i / (e2 * e1);
+            int g0 = o[0] + l0, g1 = o[1] + l1, g2 = o[2] + l2;
+            if (g0 >= t.nf[0]) g0 -= t.nf[0];
+            if (D > 1 && g1 >= t.nf[1]) g1 -= t.nf[1];
+            if (D > 2 && g2 >= t.nf[2]) g2 -= t.nf[2];
+            const int64_t gi = D == 1 ? g0 : (D == 2 ? (int64_t)g0 * t.nf[1] + g1 : ((int64_t)g0 * t.nf[1] + g1) * t.nf[2] + g2);
+            if (CPLX) lc[i] = F[gi];
+            else lds[i] = F[gi].x;
+        }
+        __syncthreads();
+        for (int64_t n = cur + threadIdx.x; n < seg_hi; n += kInterpThreads) {
+            double v0[W], v1[W], v2[W];
+            int f0 = 0, f1 = 0, f2 = 0;
+            {
+                double Xw[3] = {0.0, 0.0, 0.0};
+                Xw[0] = fold(t.scale[0] * (a.xs[n * D + 0] - t.xcen[0]), (double)t.nf[0]);
+                if (D > 1) Xw[1] = fold(t.scale[1] * (a.xs[n * D + 1] - t.xcen[1]), (double)t.nf[1]);
+                if (D > 2) Xw[2] = fold(t.scale[2] * (a.xs[n * D + 2] - t.xcen[2]), (double)t.nf[2]);
+                window_eval<D, W>(a.coef, a.degree, Xw, t.nf[0], t.nf[1], t.nf[2], f0, f1, f2, v0, v1, v2);
+                f0 -= o[0];
+                if (D > 1) f1 -= o[1];
+                if (D > 2) f2 -= o[2];
+            }
+            double ar = 0.0, ai = 0.0;
+            if (D == 1) {
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    if (CPLX) {
+                        const double2 c = lc[f0 + j];
+                        ar = fma(v0[j], c.x, ar);
+                        ai = fma(v0[j], c.y, ai);
+                    } else {
+                        ar = fma(v0[j], lds[f0 + j], ar);
+                    }
+                }
+            } else if (D == 2) {
+#pragma unroll
+                for (int j0 = 0; j0 < W; ++j0) {
+                    const int rowi = (f0 + j0) * e1 + f1;
+                    double rr = 0.0, ri = 0.0;
+#pragma unroll
+                    for (int j1 = 0; j1 < W; ++j1) {
+                        if (CPLX) {
+                            const double2 c = lc[rowi + j1];
+                            rr = fma(v1[j1], c.x, rr);
+                            ri = fma(v1[j1], c.y, ri);
+                        } else {
+                            rr = fma(v1[j1], lds[rowi + j1], rr);
+                        }
+                    }
+                    ar = fma(v0[j0], rr, ar);
+                    if (CPLX) ai = fma(v0[j0], ri, ai);
+                }
+            } else {
+                for (int j0 = 0; j0 < W; ++j0) {
+                    double r0r = 0.0, r0i = 0.0;
+                    for (int j1 = 0; j1 < W; ++j1) {
+                        const int rowi = ((f0 + j0) * e1 + (f1 + j1)) * e2 + f2;
+                        double rr = 0.0, ri = 0.0;
+#pragma unroll
+                        for (int j2 = 0; j2 < W; ++j2) {
+                            if (CPLX) {
+                                const double2 c = lc[rowi + j2];
+                                rr = fma(v2[j2], c.x, rr);
+                                ri = fma(v2[j2], c.y, ri);
+                            } else {
+                                rr = fma(v2[j2], lds[rowi + j2], rr);
+                            }
+                        }
+                        r0r = fma(v1[j1], rr, r0r);
+                        if (CPLX) r0i = fma(v1[j1], ri, r0i);
+                    }
+                    ar = fma(v0[j0], r0r, ar);
+                    if (CPLX) ai = fma(v0[j0], r0i, ai);
+                }
+            }
+            const int64_t dst = (int64_t)batch * a.npts + a.order[n];
+            if (CPLX) reinterpret_cast<double2*>(a.out)[dst] = make_double2(ar, ai);
+            else reinterpret_cast<double*>(a.out)[dst] = ar;
+        }
+        __syncthreads();
+        cur = seg_hi;
+    }
+}
+
+template <int D>
+static hipError_t launch_interp_tile_d(int W, bool cplx, dim3 grid, size_t lds_bytes, hipStream_t s, const TileInterpArgs& a) {
+    switch (W) {
+#define EFGP_CASE(w_)                                                                                               \
+    case w_: {                                                                                                      \
+        auto kc = interp_tile_kernel<D, w_, true>;                                                                  \
+        auto kr = interp_tile_kernel<D, w_, false>;                                                                 \
+        if (lds_bytes > 65536) {                                                                                    \
+            hipError_t e = hipFuncSetAttribute(cplx ? (const void*)kc : (const void*)kr,                            \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);         \
+            if (e != hipSuccess) return e;                                                                          \
+        }                                                                                                           \
+        if (cplx) hipLaunchKernelGGL(kc, grid, dim3(kInterpThreads), lds_bytes, s, a);                              \
+        else hipLaunchKernelGGL(kr, grid, dim3(kInterpThreads), lds_bytes, s, a);                                   \
+        return hipGetLastError();                                                                                   \
+    }
         EFGP_CASE(2) EFGP_CASE(3) EFGP_CASE(4) EFGP_CASE(5) EFGP_CASE(6) EFGP_CASE(7) EFGP_CASE(8) EFGP_CASE(9)
         EFGP_CASE(10) EFGP_CASE(11) EFGP_CASE(12) EFGP_CASE(13) EFGP_CASE(14) EFGP_CASE(15) EFGP_CASE(16)
 #undef EFGP_CASE
@@ -2259,6 +2422,41 @@ static int type2_impl(efgp_nufft_t* plan, const void* f, const void* mode_scale,
     const bool use_halo = !cplx && halo_cells * sizeof(double) <= (size_t)ctx->max_lds && std::getenv("EFGP_NO_HALO") == nullptr;
     if (use_halo) lds_bytes = halo_cells * sizeof(double);
     const bool use_lds = lds_bytes <= (size_t)ctx->max_lds;
+    // grids beyond LDS: tile-sorted points + LDS tiles (the binning is shared with the tiled spreader when the
+    // tile geometry coincides, and cached in the plan otherwise)
+    TileGeom tg;
+    if (!use_lds && plan->npts >= 32768 && std::getenv("EFGP_NO_TILES") == nullptr &&
+        make_tile_geom(plan, w, cplx ? 2 : 1, (size_t)ctx->max_lds - 4096, &tg)) {
+        BinSet* bins = nullptr;
+        rc = get_bins(plan, tg, cplx ? 2 : 1, stream, &bins);
+        if (rc != EFGP_OK) return rc;
+        TileInterpArgs ta;
+        ta.t = tg;
+        ta.xs = bins->xs;
+        ta.order = bins->order;
+        ta.start = bins->start;
+        ta.npts = plan->npts;
+        ta.chunk = std::max<int64_t>(4096, (plan->npts + 4 * ctx->num_cu - 1) / (4 * (int64_t)ctx->num_cu));
+        ta.coef = w->d_coef;
+        ta.degree = w->p.degree;
+        ta.fine = fine;
+        ta.cells = g.cells;
+        ta.out = out;
+        const size_t tile_lds = (size_t)(cplx ? 2 : 1) * tg.ext[0] * tg.ext[1] * tg.ext[2] * sizeof(double);
+        dim3 tgrid((unsigned)((plan->npts + ta.chunk - 1) / ta.chunk), nbatch);
+        hipError_t te;
+        {
+            KernelTimer timer("interp", stream);
+            if (plan->dim == 1) te = launch_interp_tile_d<1>(w->p.w, cplx, tgrid, tile_lds, stream, ta);
+            else if (plan->dim == 2) te = launch_interp_tile_d<2>(w->p.w, cplx, tgrid, tile_lds, stream, ta);
+            else te = launch_interp_tile_d<3>(w->p.w, cplx, tgrid, tile_lds, stream, ta);
+        }
+        if (te != hipSuccess) {
+            set_error("tiled interp kernel launch failed: %s", hipGetErrorString(te));
+            return EFGP_EHIP;
+        }
+        return EFGP_OK;
+    }
     InterpArgs a;
     a.x = plan->x;
     a.npts = plan->npts;

@@ -43,7 +43,8 @@ def test_type1_vs_exact(d, nm, tol, complex_c):
     assert _rel(out, ref) < 5 * tol + 1e-13
 
 
-@pytest.mark.parametrize("d,nm,tol", [(1, 35, 1e-6), (2, 23, 1e-4), (2, 45, 6e-8), (3, 11, 1e-5), (2, 141, 1e-9)])
+@pytest.mark.parametrize("d,nm,tol", [(1, 35, 1e-6), (2, 23, 1e-4), (2, 45, 6e-8), (3, 11, 1e-5), (2, 141, 1e-9), (2, 24, 1e-6),
+                                      (1, 8, 1e-8)])
 @pytest.mark.parametrize("real_only", [False, True])
 def test_type2_vs_exact(d, nm, tol, real_only):
     from efgp_hip import NufftPlan
@@ -195,3 +196,30 @@ def test_type1_cell_sorted_register_path(nm, tol, N, monkeypatch):
     ref_v = O.nudft_type1(x, 0.346, torch.ones(N, dtype=torch.float64), (nm, nm))
     assert _rel(v, ref_v) < 5 * tol + 1e-13
     assert _rel(cplx, (1 - 2j) * Fy) < 5 * tol + 1e-12
+
+
+@pytest.mark.parametrize("d,nm,tol", [(3, 21, 1e-9), (3, 23, 1e-6), (2, 141, 1e-7), (3, 12, 1e-5)])
+@pytest.mark.parametrize("real_only", [False, True])
+def test_type2_tiled_gather_beyond_lds(d, nm, tol, real_only, monkeypatch):
+    """Fine grids that do not fit LDS with many points: tile-sorted points + LDS tiles (interp_tile_kernel) against
+    the exact transform on a subset and against the untiled L2 gather on every point."""
+    from efgp_hip import NufftPlan
+    from oracle import efgp_oracle as O
+    N = 60000
+    x = _points(N, d, 40 + d, -2.0, 3.0)
+    h = 0.17
+    g = torch.Generator().manual_seed(9)
+    f = torch.complex(torch.randn(2, nm ** d, generator=g, dtype=torch.float64),
+                      torch.randn(2, nm ** d, generator=g, dtype=torch.float64))
+    plan = NufftPlan(x.cuda(), h, tol)
+    out = plan.type2(f.cuda(), (nm,) * d, real_only=real_only)
+    assert out.shape == (2, N)
+    sub = torch.arange(0, N, 97)
+    ref = torch.stack([O.nudft_type2(x[sub], h, f[b], (nm,) * d) for b in range(2)])
+    if real_only:
+        ref = ref.real
+    assert _rel(out[:, sub.cuda()], ref) < 5 * tol + 1e-13
+    monkeypatch.setenv("EFGP_NO_TILES", "1")
+    plan2 = NufftPlan(x.cuda(), h, tol)
+    out2 = plan2.type2(f.cuda(), (nm,) * d, real_only=real_only)
+    assert _rel(out, out2) < 1e-12
