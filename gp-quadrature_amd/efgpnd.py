@@ -272,7 +272,7 @@ class _Grid:
 
 
 def _domain_length(xd: torch.Tensor, shards: PointShards) -> float:
-    lo, hi = xd.min(dim=0).values, xd.max(dim=0).values
+    lo, hi = torch.aminmax(xd, dim=0)
     lo, hi = shards.minmax(lo, hi)
     return float((hi - lo).max())
 
@@ -303,14 +303,17 @@ def efgpnd_gradient_batched(
         use_trace_cg_preconditioner: bool = True,
         log_marginal_probes=100, log_marginal_steps=25,
         probes_Z: Optional[torch.Tensor] = None, probes_V: Optional[torch.Tensor] = None,
-        shards: Optional[PointShards] = None, trace_mode: str = "adjoint", probe_seed: Optional[int] = None):
+        shards: Optional[PointShards] = None, trace_mode: str = "adjoint", probe_seed: Optional[int] = None,
+        domain_length: Optional[float] = None):
     """d(negative log marginal likelihood)/d(kernel hypers..., sigma^2) = (term1 - term2)/2 with
     Hutchinson trace estimates (data-space probes Z for non-variance kernel hypers, feature-space
     probes V for the noise) and CG solves.  ``x0, x1`` are ignored as in the reference (:72-73).
 
     Extra keyword arguments (not in the reference): ``probes_Z`` (T,N) / ``probes_V`` (T,M) inject the
     +-1 probes (the reference draws them from torch's generator at :179-182 and :199-202), and
-    ``shards`` sums the gridded partials / N-length scalars over point shards.
+    ``shards`` sums the gridded partials / N-length scalars over point shards; ``domain_length`` passes the box
+    length max_a(max x_a - min x_a) when the caller already knows it (EFGPND caches it: the two N-length min/max
+    reductions cost 6.6 ms per step at N = 5e6, d = 3).
     Stage timers (seconds) are written to ``stats_out['stage_sec']`` with the reference's stage names (host
     clock; with ``do_profiling=True`` the device is synchronised at every stage boundary so they are exact).
 
@@ -349,7 +352,7 @@ def efgpnd_gradient_batched(
     yd = y.detach().to(device=dev, dtype=torch.float64).contiguous()
     N_local, d = xd.shape
     N = int(shards.sum_scalars([N_local], dev)[0]) if shards.active else N_local
-    L = _domain_length(xd, shards)
+    L = float(domain_length) if domain_length is not None else _domain_length(xd, shards)
     sig = float(sigmasq.detach()) if torch.is_tensor(sigmasq) else float(sigmasq)
     if noise_floor is not None:
         sig = max(sig, float(noise_floor))
@@ -807,7 +810,7 @@ class EFGPND(nn.Module):
             use_mean_cg_preconditioner=self.opts.get("mean_cg_preconditioner", True),
             use_trace_cg_preconditioner=self.opts.get("trace_cg_preconditioner", True),
             compute_log_marginal=compute_log_marginal, log_marginal_probes=log_marginal_probes,
-            log_marginal_steps=log_marginal_steps, shards=self._shards, **kwargs)
+            log_marginal_steps=log_marginal_steps, shards=self._shards, domain_length=dd["L"], **kwargs)
         self._last_gradient_beta = stats.pop("mean_beta", None)
         self.last_gradient_stats = stats
         grads, log_marginal = res if compute_log_marginal else (res, None)

@@ -15,9 +15,16 @@ from kernels.squared_exponential import SquaredExponential  # noqa: E402
 dev = torch.device("cuda", 0)
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-x, y = bench.synth(N, 2, 1000, dev)
-kern = SquaredExponential(dimension=2, init_lengthscale=bench.LS, init_variance=bench.VAR)
-model = EFGPND(x, y, kern, sigmasq=bench.SIG2, eps=bench.EPS, estimate_params=False)
+D = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+if D == 2:
+    x, y = bench.synth(N, 2, 1000, dev)
+    kern = SquaredExponential(dimension=2, init_lengthscale=bench.LS, init_variance=bench.VAR)
+    model = EFGPND(x, y, kern, sigmasq=bench.SIG2, eps=bench.EPS, estimate_params=False)
+else:      # BASELINE configs[4]: 3-D Matern-3/2, hyper-gradient step
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from sweep_bench import CASES, synth
+    x, y = synth(N, 3, 103, dev)
+    model = EFGPND(x, y, CASES[3]["kernel"](), sigmasq=CASES[3]["sig"], eps=1e-3, estimate_params=False)
 for _ in range(3):
     model.compute_gradients(trace_samples=T, cg_tol=1e-3)
 torch.cuda.synchronize()
