@@ -71,11 +71,22 @@ void* scratch(DeviceCtx* ctx, Slot slot, size_t bytes) {
     return p;
 }
 
+// A long hyper-parameter optimisation visits many grid sizes; rocFFT plans own device work buffers, so the cache
+// is bounded and evicts the least recently used plan (hipfftDestroy frees its buffers behind an implicit sync).
+constexpr size_t kMaxFftPlans = 32;
+
 int fft_plan(DeviceCtx* ctx, int rank, const int64_t* n, int64_t batch, hipStream_t stream, hipfftHandle* out) {
     auto key = std::make_tuple(rank, n[0], rank > 1 ? n[1] : 0, rank > 2 ? n[2] : 0, batch);
     auto it = ctx->fft_plans.find(key);
     hipfftHandle h;
     if (it == ctx->fft_plans.end()) {
+        if (ctx->fft_plans.size() >= kMaxFftPlans) {
+            auto victim = ctx->fft_plans.begin();
+            for (auto jt = ctx->fft_plans.begin(); jt != ctx->fft_plans.end(); ++jt)
+                if (jt->second.stamp < victim->second.stamp) victim = jt;
+            (void)hipfftDestroy(victim->second.handle);
+            ctx->fft_plans.erase(victim);
+        }
         int dims[3];
         int64_t dist = 1;
         for (int a = 0; a < rank; ++a) {
@@ -86,9 +97,10 @@ int fft_plan(DeviceCtx* ctx, int rank, const int64_t* n, int64_t batch, hipStrea
         size_t work = 0;
         EFGP_FFT_CHECK(hipfftMakePlanMany(h, rank, dims, nullptr, 1, (int)dist, nullptr, 1, (int)dist, HIPFFT_Z2Z,
                                           (int)batch, &work));
-        ctx->fft_plans[key] = h;
+        ctx->fft_plans[key] = DeviceCtx::FftEntry{h, ++ctx->fft_clock};
     } else {
-        h = it->second;
+        h = it->second.handle;
+        it->second.stamp = ++ctx->fft_clock;
     }
     EFGP_FFT_CHECK(hipfftSetStream(h, stream));
     *out = h;
@@ -119,6 +131,7 @@ void* pool_alloc(DeviceCtx* ctx, size_t bytes) {
     if (it != ctx->pool.end() && !it->second.empty()) {
         void* p = it->second.back();
         it->second.pop_back();
+        ctx->pool_bytes -= sz;
         return p;
     }
     void* p = nullptr;
@@ -129,9 +142,19 @@ void* pool_alloc(DeviceCtx* ctx, size_t bytes) {
     return p;
 }
 
+// Blocks go back to per-size free lists; the lists together are capped (changing grid sizes would otherwise park
+// one block per size forever): beyond the cap the block is released to the runtime instead.
+constexpr size_t kPoolCapBytes = size_t(256) << 20;
+
 void pool_free(DeviceCtx* ctx, void* p, size_t bytes) {
     if (!p) return;
-    ctx->pool[pool_round(bytes)].push_back(p);
+    const size_t sz = pool_round(bytes);
+    if (ctx->pool_bytes + sz > kPoolCapBytes) {
+        (void)hipFree(p);          // implicit device synchronisation: nothing queued can still be using it
+        return;
+    }
+    ctx->pool[sz].push_back(p);
+    ctx->pool_bytes += sz;
 }
 
 void release_ctx(int device) {
@@ -146,7 +169,7 @@ void release_ctx(int device) {
         (void)hipGetDevice(&prev);
         (void)hipSetDevice(c->device);
         (void)hipDeviceSynchronize();
-        for (auto& kv : c->fft_plans) (void)hipfftDestroy(kv.second);
+        for (auto& kv : c->fft_plans) (void)hipfftDestroy(kv.second.handle);
         for (int s = 0; s < SLOT_COUNT; ++s)
             if (c->buf[s]) (void)hipFree(c->buf[s]);
         if (c->host_pinned) (void)hipHostFree(c->host_pinned);

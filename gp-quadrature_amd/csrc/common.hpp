@@ -65,12 +65,18 @@ struct DeviceCtx {
     void* buf[SLOT_COUNT] = {nullptr};
     size_t cap[SLOT_COUNT] = {0};
     // key: rank, n0, n1, n2, batch
-    std::map<std::tuple<int, int64_t, int64_t, int64_t, int64_t>, hipfftHandle> fft_plans;
+    struct FftEntry {
+        hipfftHandle handle;
+        unsigned long long stamp;   // last use (monotone counter): the least recently used plan is evicted
+    };
+    std::map<std::tuple<int, int64_t, int64_t, int64_t, int64_t>, FftEntry> fft_plans;
+    unsigned long long fft_clock = 0;
     int* host_pinned = nullptr;   // small pinned host buffer for status read-back
     size_t host_pinned_bytes = 0;
     // free lists of small device blocks (size -> pointers) so that per-fit objects (Toeplitz spectra,
     // twiddle tables) do not pay hipMalloc/hipFree each time
     std::map<size_t, std::vector<void*>> pool;
+    size_t pool_bytes = 0;      // bytes parked in the free lists (bounded: see pool_free)
     // cached spreading-window data, owned by the NUFFT translation unit (opaque here)
     std::vector<void*> window_cache;
     // cached FFT twiddle tables of the persistent CG: length -> device table
