@@ -369,6 +369,228 @@ __global__ __launch_bounds__(kVecThreads) void cg_axpy_kernel(CgArgs a) {
     }
 }
 
+// ==========================================================================================================
+// Fused line-FFT iteration for 2-D grids beyond one CU's LDS (F = 128..512 per dimension).
+//   The generic iteration above spends 11 launches (pad, 2x2 rocFFT passes, multiply, update kernels) and moves
+//   the whole padded F x F grid through HBM five times although only n of its F rows are non-zero on the way in
+//   and only n rows / columns are kept on the way out.  Here a matvec is three launches of batched in-LDS line
+//   transforms with the pruning built in:
+//     cg_rows_fwd_kernel : (deferred p update) ws .* p, zero-padded, forward FFT along dim 1 of the n rows -> B1[n][F]
+//     cg_cols_mid_kernel : per group of columns: forward FFT along dim 0 (n non-zero inputs), .* vhat, inverse FFT,
+//                          rows of the crop window -> B2[n][F]
+//     cg_rows_inv_kernel : inverse FFT along dim 1 of the n window rows, crop, A p, <p, A p> (two-level reduction)
+//   followed by cg_axpy_kernel.  Lines are transformed with a Stockham autosort FFT (radix 4, one radix-2 stage
+//   for odd log2 F) in two LDS ping-pong buffers; twiddles come from the per-length table exp(-2 pi i q / F).
+// ==========================================================================================================
+constexpr int kLineThreads = 256;
+constexpr int kLinesPerBlock = 4;
+
+__device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
+
+// forward FFT of `nl` lines of length F (a power of two) held in A (line l at A + l*ld); result in the returned
+// buffer (A or B).  `tw` = exp(-2 pi i q / F), q < F, in LDS.
+__device__ __forceinline__ double2* line_fft(double2* A, double2* B, int F, int ld, int nl, const double2* tw) {
+    double2* x = A;
+    double2* y = B;
+    int Ns = 1;
+    while (Ns < F) {
+        const int R = ((F / Ns) & 3) == 0 ? 4 : 2;
+        const int per = F / R;                       // butterflies per line (a power of two)
+        const int lper = ilog2(per);
+        const int mult = F / (Ns * R);               // twiddle index step: angle = -2 pi r k / (Ns R)
+        for (int w = threadIdx.x; w < (nl << lper); w += kLineThreads) {
+            const int l = w >> lper, j = w & (per - 1);
+            const int k = j & (Ns - 1);
+            const double2* xl = x + l * ld;
+            double2* yl = y + l * ld;
+            const int j0 = (j - k) * R + k;
+            if (R == 4) {
+                double2 v0 = xl[j], v1 = xl[j + per], v2 = xl[j + 2 * per], v3 = xl[j + 3 * per];
+                if (Ns > 1) {
+                    const int q = k * mult;          // 3 q < F: no wrap
+                    v1 = cmul(v1, tw[q]);
+                    v2 = cmul(v2, tw[2 * q]);
+                    v3 = cmul(v3, tw[3 * q]);
+                }
+                const double2 t0 = make_double2(v0.x + v2.x, v0.y + v2.y), t1 = make_double2(v0.x - v2.x, v0.y - v2.y);
+                const double2 t2 = make_double2(v1.x + v3.x, v1.y + v3.y);
+                const double2 t3 = make_double2(v1.y - v3.y, v3.x - v1.x);          // -i (v1 - v3)
+                yl[j0] = make_double2(t0.x + t2.x, t0.y + t2.y);
+                yl[j0 + Ns] = make_double2(t1.x + t3.x, t1.y + t3.y);
+                yl[j0 + 2 * Ns] = make_double2(t0.x - t2.x, t0.y - t2.y);
+                yl[j0 + 3 * Ns] = make_double2(t1.x - t3.x, t1.y - t3.y);
+            } else {
+                double2 v0 = xl[j], v1 = xl[j + per];
+                if (Ns > 1) v1 = cmul(v1, tw[k * mult]);
+                yl[j0] = make_double2(v0.x + v1.x, v0.y + v1.y);
+                yl[j0 + Ns] = make_double2(v0.x - v1.x, v0.y - v1.y);
+            }
+        }
+        __syncthreads();
+        double2* t = x;
+        x = y;
+        y = t;
+        Ns *= R;
+    }
+    return x;
+}
+
+// cooperative copy of a twiddle table into LDS (visible after the caller's next barrier)
+__device__ __forceinline__ void load_twiddles(double2* dst, const double2* __restrict__ src, int F) {
+    for (int i = threadIdx.x; i < F; i += kLineThreads) dst[i] = src[i];
+}
+
+struct LineArgs {
+    CgArgs c;
+    const double2* vhat;      // [F0][F1], already divided by F0*F1
+    const double2* tw0;       // exp(-2 pi i q / F0)
+    const double2* tw1;
+    double2* b1;              // [slots][n0][F1]
+    double2* b2;              // [slots][n0][F1]
+    int nblk_rows;            // row blocks per system = ceil(n0 / kLinesPerBlock): partial sums of <p, A p>
+};
+
+__global__ __launch_bounds__(kLineThreads) void cg_rows_fwd_kernel(LineArgs a) {
+    extern __shared__ double2 lsm[];
+    const CgArgs& c = a.c;
+    const int slot = blockIdx.y;
+    const int row = c.rows ? c.rows[slot] : slot;
+    if (row < 0) return;
+    const CgRowScalars sc = c.sc[row];
+    if (!sc.active) return;
+    const int n0 = (int)c.g.n[0], n1 = (int)c.g.n[1], F1 = (int)c.g.F[1], ld = F1 + 1;
+    const int r0 = blockIdx.x * kLinesPerBlock;
+    const int nl = min(kLinesPerBlock, n0 - r0);
+    double2* A = lsm;
+    double2* B = lsm + kLinesPerBlock * ld;
+    double2* tws = B + kLinesPerBlock * ld;
+    load_twiddles(tws, a.tw1, F1);
+    const int64_t base = (int64_t)row * c.g.M;
+    for (int w = threadIdx.x; w < nl * F1; w += kLineThreads) {
+        const int l = w / F1, i1 = w - l * F1;
+        double2 v = make_double2(0.0, 0.0);
+        if (i1 < n1) {
+            const int t = (r0 + l) * n1 + i1;
+            double2 pv = c.p[base + t];
+            if (sc.do_p) {                                       // deferred p <- r/diag + beta p
+                double2 zv = c.r[base + t];
+                if (c.diag) {
+                    zv.x /= c.diag[t];
+                    zv.y /= c.diag[t];
+                }
+                pv = make_double2(zv.x + sc.beta * pv.x, zv.y + sc.beta * pv.y);
+                c.p[base + t] = pv;
+            }
+            v = cmul(pv, c.ws[t]);
+        }
+        A[l * ld + i1] = v;
+    }
+    __syncthreads();
+    const double2* X = line_fft(A, B, F1, ld, nl, tws);
+    double2* out = a.b1 + ((int64_t)slot * n0 + r0) * F1;
+    for (int w = threadIdx.x; w < nl * F1; w += kLineThreads) {
+        const int l = w / F1, i1 = w - l * F1;
+        out[(int64_t)l * F1 + i1] = X[l * ld + i1];
+    }
+}
+
+__global__ __launch_bounds__(kLineThreads) void cg_cols_mid_kernel(LineArgs a) {
+    extern __shared__ double2 lsm[];
+    const CgArgs& c = a.c;
+    const int slot = blockIdx.y;
+    const int row = c.rows ? c.rows[slot] : slot;
+    if (row < 0) return;
+    if (!c.sc[row].active) return;
+    const int n0 = (int)c.g.n[0], F0 = (int)c.g.F[0], F1 = (int)c.g.F[1], ld = F0 + 1;
+    const int c0 = blockIdx.x * kLinesPerBlock;                  // first column of this block (F1 % 8 == 0)
+    double2* A = lsm;
+    double2* B = lsm + kLinesPerBlock * ld;
+    double2* tws = B + kLinesPerBlock * ld;
+    load_twiddles(tws, a.tw0, F0);
+    const double2* in = a.b1 + (int64_t)slot * n0 * F1;
+    // line l = column c0 + l; consecutive threads read consecutive columns of one row (128-B segments)
+    for (int w = threadIdx.x; w < kLinesPerBlock * F0; w += kLineThreads) {
+        const int i0 = w / kLinesPerBlock, l = w - i0 * kLinesPerBlock;
+        A[l * ld + i0] = i0 < n0 ? in[(int64_t)i0 * F1 + c0 + l] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    double2* X = line_fft(A, B, F0, ld, kLinesPerBlock, tws);
+    double2* Y = X == A ? B : A;
+    // .* vhat, conjugate: the inverse transform is conj(FFT(conj(.)))
+    for (int w = threadIdx.x; w < kLinesPerBlock * F0; w += kLineThreads) {
+        const int i0 = w / kLinesPerBlock, l = w - i0 * kLinesPerBlock;
+        const double2 m = cmul(X[l * ld + i0], a.vhat[(int64_t)i0 * F1 + c0 + l]);
+        X[l * ld + i0] = make_double2(m.x, -m.y);
+    }
+    __syncthreads();
+    const double2* Z = line_fft(X, Y, F0, ld, kLinesPerBlock, tws);
+    double2* out = a.b2 + (int64_t)slot * n0 * F1;
+    for (int w = threadIdx.x; w < kLinesPerBlock * n0; w += kLineThreads) {
+        const int j = w / kLinesPerBlock, l = w - j * kLinesPerBlock;
+        const double2 z = Z[l * ld + (n0 - 1) + j];               // crop window rows [n0-1, 2 n0-1)
+        out[(int64_t)j * F1 + c0 + l] = make_double2(z.x, -z.y);
+    }
+}
+
+__global__ __launch_bounds__(kLineThreads) void cg_rows_inv_kernel(LineArgs a) {
+    extern __shared__ double2 lsm[];
+    __shared__ double red[kLineThreads / 64];
+    __shared__ int flag;
+    const CgArgs& c = a.c;
+    const int slot = blockIdx.y;
+    const int row = c.rows ? c.rows[slot] : slot;
+    if (row < 0) return;
+    if (!c.sc[row].active) return;
+    const int n0 = (int)c.g.n[0], n1 = (int)c.g.n[1], F1 = (int)c.g.F[1], ld = F1 + 1;
+    const int r0 = blockIdx.x * kLinesPerBlock;
+    const int nl = min(kLinesPerBlock, n0 - r0);
+    double2* A = lsm;
+    double2* B = lsm + kLinesPerBlock * ld;
+    double2* tws = B + kLinesPerBlock * ld;
+    load_twiddles(tws, a.tw1, F1);
+    const double2* in = a.b2 + ((int64_t)slot * n0 + r0) * F1;
+    for (int w = threadIdx.x; w < nl * F1; w += kLineThreads) {
+        const int l = w / F1, i1 = w - l * F1;
+        const double2 v = in[(int64_t)l * F1 + i1];
+        A[l * ld + i1] = make_double2(v.x, -v.y);
+    }
+    __syncthreads();
+    const double2* X = line_fft(A, B, F1, ld, nl, tws);
+    const int64_t base = (int64_t)row * c.g.M;
+    double pAp = 0.0;
+    for (int w = threadIdx.x; w < nl * n1; w += kLineThreads) {
+        const int l = w / n1, i1 = w - l * n1;
+        const int t = (r0 + l) * n1 + i1;
+        const double2 z = X[l * ld + (n1 - 1) + i1];
+        const double2 pv = c.p[base + t];
+        const double2 Ap = apply_A(c, c.ws[t], make_double2(z.x, -z.y), pv);
+        c.ap[base + t] = Ap;
+        pAp += pv.x * Ap.x + pv.y * Ap.y;
+    }
+    pAp = block_sum(pAp, red);
+    double* part = c.partial + (int64_t)row * 3 * kCgBlocksMax;
+    if (threadIdx.x == 0) part[blockIdx.x] = pAp;
+    // arrival counter 0 with this kernel's own block count
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int prev = atomicAdd(&c.counter[2 * row], 1);
+        flag = prev == a.nblk_rows - 1;
+        if (flag) c.counter[2 * row] = 0;
+    }
+    __syncthreads();
+    if (!flag) return;
+    __threadfence();
+    __shared__ double fin[kCgBlocksMax];
+    if (threadIdx.x < a.nblk_rows) fin[threadIdx.x] = load_agent(&part[threadIdx.x]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < a.nblk_rows; ++i) t += fin[i];
+        c.sc[row].pAp = t + kDivEps;
+    }
+}
+
 template <bool AC, bool BC>
 __global__ void vdot_real_kernel(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
                                  double* __restrict__ partial) {
@@ -408,6 +630,7 @@ struct efgp_toeplitz_s {
     double2* vhat = nullptr;
     double2* tw[3] = {nullptr, nullptr, nullptr};   // exp(-2 pi i q / F[a]) tables for the persistent CG
     bool persistent_ok = false;
+    bool lines_ok = false;       // 2-D, power-of-two F in [128, 512]: fused line-FFT CG iteration
 };
 
 namespace efgp {
@@ -490,7 +713,12 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
         return rc;
     }
     op->persistent_ok = persistent_cg_eligible(op->g);
-    if (op->persistent_ok) {
+    op->lines_ok = dim == 2;
+    for (int a = 0; a < dim && op->lines_ok; ++a) {
+        const int64_t F = op->g.F[a];
+        op->lines_ok = F >= 128 && F <= 512 && (F & (F - 1)) == 0;
+    }
+    if (op->persistent_ok || op->lines_ok) {
         for (int a = 0; a < dim; ++a) {
             const int64_t n = op->g.F[a];
             auto it = ctx->twiddles.find(n);
@@ -510,6 +738,7 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
                 hipStreamSynchronize(stream) != hipSuccess) {
                 if (dtw) (void)hipFree(dtw);
                 op->persistent_ok = false;
+                op->lines_ok = false;
                 break;
             }
             ctx->twiddles[n] = dtw;
@@ -676,6 +905,23 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         int last_active_it = 0;       // number of iterations in which at least one row was active
         const int poll_every = 8;
         std::vector<CgRowScalars> hsc(rows);
+        // 2-D mid-size grids: three launches of pruned in-LDS line transforms instead of pad + rocFFT + multiply
+        const bool use_lines = op->lines_ok && std::getenv("EFGP_NO_CG_LINES") == nullptr;
+        LineArgs la;
+        size_t lds_rows = 0, lds_cols = 0;
+        if (use_lines) {
+            la.vhat = op->vhat;
+            la.tw0 = op->tw[0];
+            la.tw1 = op->tw[1];
+            la.b1 = pad;                                                     // [rows][n0][F1] fits: Ftot >= 2 n0 F1
+            la.b2 = pad + (int64_t)rows * g.n[0] * g.F[1];
+            la.nblk_rows = (int)((g.n[0] + kLinesPerBlock - 1) / kLinesPerBlock);
+            lds_rows = ((size_t)2 * kLinesPerBlock * (size_t)(g.F[1] + 1) + (size_t)g.F[1]) * sizeof(double2);   // + twiddles
+            lds_cols = ((size_t)2 * kLinesPerBlock * (size_t)(g.F[0] + 1) + (size_t)g.F[0]) * sizeof(double2);
+            EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg_rows_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
+            EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg_rows_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
+            EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg_cols_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));
+        }
         bool use_graph = !timing_enabled() && std::getenv("EFGP_NO_CG_GRAPH") == nullptr;
         hipGraphExec_t graph_exec = nullptr;
         int graph_slots = -1;
@@ -693,6 +939,16 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
             // costs the host ~300 us per iteration (measured, 3-D 64^3), far more than the GPU needs.  A full burst is
             // therefore captured ONCE into a hipGraph per (slots, row map) state and replayed with one launch.
             auto enqueue_iteration = [&]() -> int {
+                if (use_lines) {
+                    la.c = a;
+                    hipLaunchKernelGGL(cg_rows_fwd_kernel, dim3(la.nblk_rows, slots), dim3(kLineThreads), lds_rows, stream, la);
+                    hipLaunchKernelGGL(cg_cols_mid_kernel, dim3((unsigned)(g.F[1] / kLinesPerBlock), slots), dim3(kLineThreads),
+                                       lds_cols, stream, la);
+                    hipLaunchKernelGGL(cg_rows_inv_kernel, dim3(la.nblk_rows, slots), dim3(kLineThreads), lds_rows, stream, la);
+                    hipLaunchKernelGGL(cg_axpy_kernel, dim3(a.nblk, slots), dim3(kVecThreads), 0, stream, a);
+                    EFGP_HIP_CHECK(hipGetLastError());
+                    return EFGP_OK;
+                }
                 hipLaunchKernelGGL(cg_pad_kernel, grid_for(g.Ftot, slots, kVecThreads), dim3(kVecThreads), 0, stream, a);
                 EFGP_HIP_CHECK(hipGetLastError());
                 int rcc = circulant(op, pad, slots, stream);

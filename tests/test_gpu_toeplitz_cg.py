@@ -145,3 +145,41 @@ def test_fused_mean_system_matches_general_solve(d, mtot, precond):
     xo, ito = O.cg_single(O.make_A_mean(ws, T, sig2), rhs, torch.zeros_like(rhs), 1e-8, diag=diag)
     assert abs(int(lazy) - ito) <= (0 if ito < 100 else 1 + ito // 200) and _rel(beta, xo) < 1e-7
     assert beta.shape == fy.shape
+
+
+@pytest.mark.parametrize("mtot", [41, 71, 131])
+def test_line_fft_iteration_matches_generic_and_oracle(mtot, monkeypatch):
+    """2-D grids beyond one CU (F = 128, 256, 512): the fused line-FFT iteration (three launches of pruned in-LDS
+    transforms) against the generic pad + rocFFT iteration (single and batched systems, both operators) and, at
+    the smallest size, the oracle CG.  The Toeplitz vector is a synthetic Hermitian one (an exact conv vector at
+    mtot = 131 would dominate the test time on the CPU)."""
+    from efgp_hip import ToeplitzOp, cg_solve
+    from oracle import efgp_oracle as O
+    g = torch.Generator().manual_seed(12)
+    L = 2 * mtot - 1
+    v = torch.complex(torch.randn(L, L, generator=g, dtype=torch.float64), torch.randn(L, L, generator=g, dtype=torch.float64))
+    v = (v + v.flip(0, 1).conj()) / 2
+    v[mtot - 1, mtot - 1] = 3.0 * L                       # diagonally dominant: positive definite T
+    M = mtot * mtot
+    ws = torch.exp(-2.0 * torch.rand(M, generator=g, dtype=torch.float64)).to(torch.complex128)
+    sig2 = 0.5
+    B = 3
+    b = torch.complex(torch.randn(B, M, generator=g, dtype=torch.float64), torch.randn(B, M, generator=g, dtype=torch.float64))
+    diag = O.jacobi_diag(ws, sig2, 3.0 * L)
+    op = ToeplitzOp(v.cuda())
+    assert op.fft_shape[0] in (128, 256, 512)
+    res = {}
+    for mode in ("lines", "generic"):
+        if mode == "generic":
+            monkeypatch.setenv("EFGP_NO_CG_LINES", "1")
+        else:
+            monkeypatch.delenv("EFGP_NO_CG_LINES", raising=False)
+        res[mode] = cg_solve(op, ws.cuda(), sig2, 0, b.cuda(), torch.zeros_like(b).cuda(), 1e-9, diag=diag.cuda())
+        res[mode + "_var"] = cg_solve(op, ws.cuda(), sig2, 1, b[1].cuda(), 0.1 * b[0].cuda(), 1e-9, batched=False)
+    assert abs(res["lines"][1] - res["generic"][1]) <= 1 and _rel(res["lines"][0], res["generic"][0]) < 1e-8
+    assert abs(res["lines_var"][1] - res["generic_var"][1]) <= 1 and _rel(res["lines_var"][0], res["generic_var"][0]) < 1e-8
+    assert res["lines"][1] < 2 * M                        # converged, not capped
+    if mtot == 41:
+        T = O.Toeplitz(v)
+        xo, ito = O.cg_batched(O.make_A_mean(ws, T, sig2), b, torch.zeros_like(b), 1e-9, diag=diag)
+        assert abs(res["lines"][1] - ito) <= 1 and _rel(res["lines"][0], xo) < 1e-7
