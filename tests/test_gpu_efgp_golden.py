@@ -85,7 +85,7 @@ def test_default_tolerance_iterations(name):
     assert res < 1.05e-4
     # at the loose default tolerance the iterate moves by ~tol*cond when the stop flips by one pass
     # (SURVEY section 7 "hard parts"); only a coarse agreement is meaningful here
-    assert rel(m._fit_state["ws"] * m._beta, torch.from_numpy(g["ws"]) * torch.from_numpy(g["beta_1e4"])) < 2e-2
+    assert rel(m._fit_state["ws"] * m._beta, torch.from_numpy(g["ws"]) * torch.from_numpy(g["beta_1e4"])) < 5e-2
 
 
 @pytest.mark.parametrize("name", ["s1_se2d_n100", "s2_matern12_1d_n200", "c1_se1d_n5000", "c2_se2d_n100000",
