@@ -67,7 +67,7 @@ int main() {
     const int iters = 2000;
     for (int threads : {512, 1024}) {
         const int total = ncu * threads;
-        for (int pattern = 0; pattern < 6; ++pattern) {
+        for (int pattern = 0; pattern < 8; ++pattern) {
             std::vector<int> offs((size_t)total * 16);
             srand(1234);
             for (int t = 0; t < total; ++t) {
@@ -89,6 +89,8 @@ int main() {
                             int row = (lane >> 3) & 3, col = lane & 7;
                             v = pt[lane >> 5] + row * 128 + ((col + 8 * row) & 31);                // rows land on distinct bank quarters
                         } break;
+                        case 6: v = (rand() & ~31) + (lane & 31); break;                          // random row, column = lane mod 32
+                        case 7: v = (rand() & ~15) + (lane & 15); break;                          // random row, column = lane mod 16
                         case 5: {                                                                 // 4 segments of 16
                             static int seg[4];
                             if ((lane & 15) == 0) seg[lane >> 4] = rand();
