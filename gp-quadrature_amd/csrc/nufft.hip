@@ -188,6 +188,7 @@ struct SpreadArgs {
     double* slabs;            // [batch][nslab][channels][cells]  (int64 fixed point when USE_LDS)
     int nslab;
     const double* scale;      // [0] = power-of-two fixed-point scale S, [1] = 1/S   (USE_LDS only)
+    const int* order;         // spread_pad_kernel: per-plan bank-balanced processing order (null: balance per chunk)
 };
 
 // LDS accumulation is done in exact 64-bit fixed point: a contribution v is added as round(v*S) with
@@ -310,6 +311,73 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
 // needs no wrap arithmetic and its atomics use immediate offsets from one address per stencil row (PMC on the
 // plain kernel: 1365 VALU instructions per point, most of them address / wrap / fixed-point bookkeeping).
 // RAW48: see lds_add_raw.  The halo columns are folded back when the tile is flushed to the slab.
+// Per-plan processing order for spread_pad_kernel.  An LDS atomic wave-instruction is served in groups of 16
+// consecutive lanes and is conflict free when their 8-byte cells differ mod 16 (tools/lds_atomic_bench.hip,
+// patterns 6/7: 22 instead of 12 lane-atomics per ns per CU, whatever the rows).  All lanes walk the same stencil
+// offsets, so this is a property of the points' first cells: class = (padded linear index of the first cell)
+// mod 16.  Within windows of kOrderWindow points of a workgroup's range the points are arranged round-robin
+// over the classes (r-th point of class c at sum_c' min(cnt[c'], r) + #{c' < c: cnt[c'] > r}): 16 consecutive
+// positions hold 16 different classes until the rarest class runs out (~86 % of a 4096-point window).
+// The window keeps the gather of x and the strengths inside ~100 KB.  Depends only on (x, fine grid, W, launch
+// geometry): built once per plan and reused by every pass.
+constexpr int kOrderWindow = 4096;
+
+template <int D>
+__global__ __launch_bounds__(kSpreadThreads) void class_order_kernel(GridGeom g, int W, const double* __restrict__ x, int64_t npts,
+                                                                    int64_t per, int* __restrict__ order) {
+    __shared__ int cnt[16], rank_next[16];
+    const int64_t lo = (int64_t)blockIdx.x * per;
+    const int64_t hi = lo + per < npts ? lo + per : npts;
+    const int nl = (int)g.nf[D - 1];
+    const int pl = nl + W - 1;
+    constexpr int kPer = kOrderWindow / kSpreadThreads;
+    for (int64_t wbase = lo; wbase < hi; wbase += kOrderWindow) {
+        if (threadIdx.x < 16) {
+            cnt[threadIdx.x] = 0;
+            rank_next[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        int cls[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int64_t n = wbase + threadIdx.x + (int64_t)u * kSpreadThreads;
+            cls[u] = -1;
+            if (n < hi) {
+                int lin = 0;
+#pragma unroll
+                for (int q = 0; q < D; ++q) {
+                    const int nfq = (int)g.nf[q];
+                    const double Xq = fold(g.scale[q] * (x[n * D + q] - g.xcen[q]), (double)nfq);
+                    int fq = (int)ceil(Xq - 0.5 * W);
+                    if (fq < 0) fq += nfq;
+                    lin = lin * (q == D - 1 ? pl : nfq) + fq;
+                }
+                cls[u] = lin & 15;
+                atomicAdd(&cnt[cls[u]], 1);
+            }
+        }
+        __syncthreads();
+        int c16[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) c16[c] = cnt[c];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            if (cls[u] < 0) continue;
+            const int64_t n = wbase + threadIdx.x + (int64_t)u * kSpreadThreads;
+            const int c = cls[u];
+            const int r = atomicAdd(&rank_next[c], 1);
+            int pos = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                pos += min(c16[q], r);
+                if (q < c && c16[q] > r) ++pos;
+            }
+            order[wbase + pos] = (int)n;
+        }
+        __syncthreads();
+    }
+}
+
 template <int D, int W, bool RAW48>
 __global__ __launch_bounds__(kSpreadThreads) void spread_pad_kernel(SpreadArgs a) {
     extern __shared__ double lds[];
@@ -341,7 +409,13 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_pad_kernel(SpreadArgs a
     constexpr bool kBalance = D >= 2;          // 1-D has only W atomics per point: the bookkeeping does not pay
     for (int64_t cbase = lo; cbase < hi; cbase += kSpreadThreads) {
       int src = -1;
-      if (!kBalance) {
+      int64_t n_ord = -1;
+      if (a.order) {
+        if (cbase + threadIdx.x < hi) {
+            n_ord = a.order[cbase + threadIdx.x];
+            src = 0;
+        }
+      } else if (!kBalance) {
         if (cbase + threadIdx.x < hi) src = threadIdx.x;
       } else {
         if (threadIdx.x < 32) cls_cnt[threadIdx.x] = 0;
@@ -388,7 +462,7 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_pad_kernel(SpreadArgs a
         __syncthreads();                       // lists are rebuilt by the next chunk
       }
         if (src < 0) continue;
-        const int64_t n = cbase + src;
+        const int64_t n = n_ord >= 0 ? n_ord : cbase + src;
         double c0, c1;
         fetch_strength(a.src, batch, n, c0, c1);
         c0 *= S;
@@ -1376,6 +1450,14 @@ struct WindowSet {          // device copies of the window data for one (toleran
     int64_t nf[3] = {0, 0, 0};
 };
 
+struct ClassOrder {         // see class_order_kernel
+    int64_t nf[3];
+    int W;
+    int nwg;
+    int* order = nullptr;
+    size_t bytes = 0;
+};
+
 struct BinSet {             // points counting-sorted by fine-grid tile (see spread_tile_kernel)
     TileGeom t;
     int channels = 0;
@@ -1399,6 +1481,7 @@ struct efgp_nufft_s {
     double tol = 1e-6;
     DeviceCtx* ctx = nullptr;
     std::vector<efgp::BinSet*> bins;     // tile-sorted copies of the points, per (fine grid, W, tile) geometry
+    std::vector<efgp::ClassOrder*> orders;   // bank-balanced processing orders of spread_pad_kernel, per (fine grid, W, launch)
 };
 
 namespace efgp {
@@ -2132,6 +2215,34 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     a.slabs = slabs;
     a.nslab = nslab;
     a.scale = d_scale;
+    a.order = nullptr;
+    // per-plan bank-balanced order (d >= 2, enough points for the one-off pass to pay)
+    if (use_pad && plan->dim >= 2 && plan->npts >= (int64_t)kOrderWindow * 64 && std::getenv("EFGP_NO_CLASS_ORDER") == nullptr) {
+        ClassOrder* co = nullptr;
+        for (ClassOrder* o : plan->orders)
+            if (o->W == w->p.w && o->nwg == nwg && o->nf[0] == g.nf[0] && o->nf[1] == g.nf[1] && o->nf[2] == g.nf[2]) co = o;
+        if (!co) {
+            co = new ClassOrder();
+            for (int q = 0; q < 3; ++q) co->nf[q] = g.nf[q];
+            co->W = w->p.w;
+            co->nwg = nwg;
+            co->bytes = (size_t)plan->npts * sizeof(int);
+            co->order = (int*)pool_alloc(ctx, co->bytes);
+            if (!co->order) {
+                delete co;
+                return EFGP_ENOMEM;
+            }
+            if (plan->dim == 2)
+                hipLaunchKernelGGL((class_order_kernel<2>), dim3(nwg), dim3(kSpreadThreads), 0, stream, g, w->p.w, plan->x, plan->npts, per,
+                                   co->order);
+            else
+                hipLaunchKernelGGL((class_order_kernel<3>), dim3(nwg), dim3(kSpreadThreads), 0, stream, g, w->p.w, plan->x, plan->npts, per,
+                                   co->order);
+            EFGP_HIP_CHECK(hipGetLastError());
+            plan->orders.push_back(co);
+        }
+        a.order = co->order;
+    }
     dim3 grid(nwg, nbatch);
     hipError_t e = hipSuccess;
     if (plan->npts > 0 && use_pad) {
@@ -2213,6 +2324,10 @@ int efgp_nufft_destroy(efgp_nufft_t* plan) {
     if (!plan) return EFGP_OK;
     DeviceGuard guard(plan->device);
     for (BinSet* b : plan->bins) free_binset(plan->ctx, b);
+    for (efgp::ClassOrder* o : plan->orders) {
+        pool_free(plan->ctx, o->order, o->bytes);
+        delete o;
+    }
     delete plan;
     return EFGP_OK;
 }
