@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
         __syncthreads();
     }
     double* acc = USE_LDS ? lds : slab;
-    const double S = USE_LDS ? a.scale[0] : 1.0;
+    const double S = USE_LDS ? a.scale[0] : 1.0, S1 = USE_LDS ? a.scale[2] : 1.0;
 
     // contiguous chunk of points per workgroup (streaming, coalesced)
     const int64_t per = (a.npts + gridDim.x - 1) / gridDim.x;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
         fetch_strength(a.src, batch, n, c0, c1);
         if (USE_LDS) {
             c0 *= S;
-            c1 *= S;
+            c1 *= S1;
         }
         double v0[W], v1[W], v2[W];
         int f0 = 0, f1 = 0, f2 = 0;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_pad_kernel(SpreadArgs a
     double* slab = a.slabs + ((int64_t)batch * a.nslab + blockIdx.x) * C * cells;
     for (int i = threadIdx.x; i < C * plane; i += kSpreadThreads) lds[i] = 0.0;
     __syncthreads();
-    const double S = a.scale[0];
+    const double S = a.scale[0], S1 = a.scale[2];
     const int64_t per = (a.npts + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < a.npts ? lo + per : a.npts;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_pad_kernel(SpreadArgs a
         double c0, c1;
         fetch_strength(a.src, batch, n, c0, c1);
         c0 *= S;
-        c1 *= S;
+        c1 *= S1;
         double v0[W], v1[W], v2[W];
         int f0 = 0, f1 = 0, f2 = 0;
         {
@@ -557,22 +557,51 @@ __global__ __launch_bounds__(1024) void maxabs_kernel(const double* __restrict__
     }
 }
 
-// scale[0] = S = largest power of two with  max|c| * S <= 2^min(50,sum_bits)  and  points_per_wg * max|c| * S <= 2^sum_bits
+// Fixed-point scales, one per channel: scale[0] = S0 (channel 0), [1] = 1/S0, [2] = S1 (channel 1), [3] = 1/S1,
+// [4] = the factor the channel-0 result still has to be multiplied by (1 unless the channel is carried normalised).
+//   S = largest power of two with  max|c| * S <= 2^min(50,sum_bits)  and  points_per_wg * max|c| * S <= 2^sum_bits.
+//   Channel 0 follows the data maximum.  Channel 1 follows it too unless it is the implicit all-ones channel of the
+//   fused fit pass (ones_channel != 0): that one always has magnitude 1 -- sharing the scale of a large |y| would
+//   quantise the Toeplitz vector at max|y| * 2^-46 (y ~ 1e6 already costs its 6e-8 accuracy; y ~ 1e60 zeroes it).
 // Consumes the max|c| accumulator and resets it to zero for the next transform (no memset launch per call).
-__global__ void fixed_scale_kernel(unsigned long long* __restrict__ cmax_bits, double floor_bound, int64_t per,
-                                   double* __restrict__ scale, int sum_bits) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double cmax = cmax_bits ? __longlong_as_double((long long)*cmax_bits) : 0.0;
-    if (cmax_bits) *cmax_bits = 0ull;
-    cmax = fmax(cmax, floor_bound);         // the implicit all-ones channel has magnitude 1
+__device__ __forceinline__ double fixed_scale_for(double cmax, int64_t per, int sum_bits) {
     if (!(cmax > 0.0) || !isfinite(cmax)) cmax = 1.0;
     // every value below 2^50 (or 2^(sum_bits)) and every per-workgroup sum below 2^sum_bits
     const double lim = fmin(ldexp(1.0, sum_bits < 50 ? sum_bits : 50), ldexp(1.0, sum_bits) / (double)(per > 1 ? per : 1));
     int e = 0;
     frexp(lim / cmax, &e);                  // lim/cmax = f * 2^e, f in [0.5, 1)
-    const double S = ldexp(1.0, e - 1);     // largest power of two <= lim/cmax
-    scale[0] = S;
-    scale[1] = 1.0 / S;
+    return ldexp(1.0, e - 1);               // largest power of two <= lim/cmax
+}
+__global__ void fixed_scale_kernel(unsigned long long* __restrict__ cmax_bits, double floor_bound, int ones_channel,
+                                   int64_t per, double* __restrict__ scale, int sum_bits) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double cmax = cmax_bits ? __longlong_as_double((long long)*cmax_bits) : 0.0;
+    if (cmax_bits) *cmax_bits = 0ull;
+    if (!ones_channel) {
+        const double S0 = fixed_scale_for(fmax(cmax, floor_bound), per, sum_bits);
+        scale[0] = S0;
+        scale[1] = 1.0 / S0;
+        scale[2] = S0;
+        scale[3] = 1.0 / S0;
+        scale[4] = 1.0;
+        return;
+    }
+    // Fused (y, ones) pass: the two real channels share ONE complex FFT and are separated afterwards by Hermitian
+    // symmetry, so the transform's rounding error of the larger channel leaks into the smaller one (measured: |y| ~
+    // 1e60 destroyed the Toeplitz vector, |y| ~ 1e-60 would destroy F*y).  Channel 0 is therefore carried
+    // NORMALISED by norm0 = the power of two >= max|y| (exact), and deconvolve_pair_kernel multiplies F*y back.
+    int e0 = 0;
+    double norm0 = 1.0;
+    if (cmax > 0.0 && isfinite(cmax)) {
+        frexp(cmax, &e0);                   // cmax = f * 2^e0, f in [0.5, 1)
+        norm0 = ldexp(1.0, e0);             // >= cmax
+    }
+    const double Sn = fixed_scale_for(1.0, per, sum_bits);      // both normalised channels have magnitude <= 1
+    scale[0] = Sn / norm0;
+    scale[1] = 1.0 / Sn;
+    scale[2] = Sn;
+    scale[3] = 1.0 / Sn;
+    scale[4] = norm0;
 }
 
 // sum the slabs of one batch row into the complex fine grid: fine = ch0 + i*ch1 (ch1 = 0 if absent).
@@ -613,8 +642,7 @@ __global__ __launch_bounds__(512) void reduce_slabs_kernel(const double* __restr
                 a += ipart[0][g][lane_cell];
                 b += ipart[1][g][lane_cell];
             }
-            const double inv = scale[1];
-            fine[(int64_t)batch * cells + cell] = make_double2((double)a * inv, (double)b * inv);
+            fine[(int64_t)batch * cells + cell] = make_double2((double)a * scale[1], (double)b * scale[3]);
         }
     } else {
         part[0][grp][lane_cell] = re;
@@ -768,7 +796,7 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_tile_kernel(TileSpreadA
     const int64_t lo = (int64_t)blockIdx.x * a.chunk;
     const int64_t hi = lo + a.chunk < a.npts ? lo + a.chunk : a.npts;
     if (lo >= hi) return;
-    const double S = a.scale[0];
+    const double S = a.scale[0], S1 = a.scale[2];
     long long* gacc = a.gacc + (int64_t)batch * C * a.cells;
     // first tile that contains sorted position `lo` (binary search by one lane)
     if (threadIdx.x == 0) {
@@ -798,7 +826,7 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_tile_kernel(TileSpreadA
             double c0, c1;
             fetch_strength(a.src, batch, a.src.mode == STR_ONES ? 0 : (int64_t)a.order[n], c0, c1);
             c0 *= S;
-            c1 *= S;
+            c1 *= S1;
             double v0[W], v1[W], v2[W];
             int f0 = 0, f1 = 0, f2 = 0;
             {
@@ -1199,9 +1227,20 @@ __global__ void deconvolve_kernel(const double2* __restrict__ fine, int64_t cell
 }
 // the fit-time pair in one launch: blockIdx.y = 0 -> part 1 into out_a on box ma, 1 -> part 2 into out_b on box mb
 __global__ void deconvolve_pair_kernel(const double2* __restrict__ fine, int64_t cells, ModeGeom ma, double2* __restrict__ out_a,
-                                       ModeGeom mb, double2* __restrict__ out_b) {
-    if (blockIdx.y == 0) deconvolve_body(fine, cells, ma, 1, out_a, 0);
-    else deconvolve_body(fine, cells, mb, 2, out_b, 0);
+                                       ModeGeom mb, double2* __restrict__ out_b, const double* __restrict__ scale) {
+    if (blockIdx.y == 0) {
+        deconvolve_body(fine, cells, ma, 1, out_a, 0);
+        const double norm0 = scale ? scale[4] : 1.0;              // channel 0 was carried normalised (fixed_scale_kernel)
+        if (norm0 != 1.0) {
+            // every thread rescales exactly the elements it wrote (same loop shape as deconvolve_body)
+            for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ma.total; t += (int64_t)gridDim.x * blockDim.x) {
+                out_a[t].x *= norm0;
+                out_a[t].y *= norm0;
+            }
+        }
+    } else {
+        deconvolve_body(fine, cells, mb, 2, out_b, 0);
+    }
 }
 
 // type 2: fine[b][k mod nf] = fac * f[b][slot] (* mul[slot] when given), zero outside the mode box: every
@@ -2009,7 +2048,7 @@ static hipError_t launch_cell(int W, int channels, int degree, dim3 grid, hipStr
     return hipErrorInvalidValue;
 }
 
-// 64-byte block: [0] S, [1] 1/S (doubles), [4] max|c| bit pattern.  Zeroed when first allocated; afterwards
+// 64-byte block of doubles: [0..3] S0, 1/S0, S1, 1/S1, [4] channel-0 norm, [7] max|c| bit pattern.  Zeroed when first allocated; afterwards
 // fixed_scale_kernel leaves the accumulator at zero.
 static char* scale_slot(DeviceCtx* ctx, hipStream_t stream) {
     char* misc = (char*)scratch(ctx, SLOT_SCALE, 64);
@@ -2022,9 +2061,11 @@ static char* scale_slot(DeviceCtx* ctx, hipStream_t stream) {
 
 // spread + reduce + FFT; leaves the transformed fine grids in SLOT_FINE
 static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int mode, int nbatch, int isign,
-                          hipStream_t stream, double2** fine_out, unsigned long long seed = 0, int64_t index_offset = 0) {
+                          hipStream_t stream, double2** fine_out, unsigned long long seed = 0, int64_t index_offset = 0,
+                          const double** scale_out = nullptr) {
     DeviceCtx* ctx = plan->ctx;
     const GridGeom g = make_geom(plan, w);
+    if (scale_out) *scale_out = nullptr;
     const int channels = (mode == STR_COMPLEX || mode == STR_REAL_AND_ONES || mode == STR_REAL_PAIR || mode == STR_RNG_PAIR) ? 2 : 1;
     // strengths read from memory need a max|c| pass for the fixed-point scale; generated / implicit ones are +-1
     const bool need_max = (mode == STR_REAL || mode == STR_COMPLEX || mode == STR_REAL_AND_ONES || mode == STR_REAL_PAIR);
@@ -2112,7 +2153,8 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         char* misc = scale_slot(ctx, stream);
         if (!gacc || !fine || !misc) return EFGP_ENOMEM;
         double* d_scale = (double*)misc;
-        unsigned long long* d_cmax = (unsigned long long*)(misc + 32);
+        unsigned long long* d_cmax = (unsigned long long*)(misc + 56);
+        if (scale_out) *scale_out = d_scale;
         EFGP_HIP_CHECK(hipMemsetAsync(gacc, 0, acc_bytes, stream));
         if (need_max) {
             const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nvals + 8191) / 8192, 256));
@@ -2122,7 +2164,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         // the global int64 grid sums over ALL points: bound the scale with N instead of points per workgroup
         hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream,
                            need_max ? d_cmax : (unsigned long long*)nullptr,
-                           floor_bound, plan->npts, d_scale, 61);
+                           floor_bound, mode == STR_REAL_AND_ONES ? 1 : 0, plan->npts, d_scale, 61);
         EFGP_HIP_CHECK(hipGetLastError());
         TileSpreadArgs ta;
         ta.t = tg;
@@ -2180,8 +2222,8 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     double2* fine = (double2*)scratch(ctx, SLOT_FINE, (size_t)nbatch * (size_t)g.cells * sizeof(double2));
     char* misc = scale_slot(ctx, stream);
     if (!slabs || !fine || !misc) return EFGP_ENOMEM;
-    double* d_scale = (double*)misc;                                  // [0] S, [1] 1/S
-    unsigned long long* d_cmax = (unsigned long long*)(misc + 32);
+    double* d_scale = (double*)misc;                                  // [0] S0, [1] 1/S0, [2] S1, [3] 1/S1
+    unsigned long long* d_cmax = (unsigned long long*)(misc + 56);
     if (!use_lds) EFGP_HIP_CHECK(hipMemsetAsync(slabs, 0, slab_bytes, stream));
 
     const int64_t per = (plan->npts + nwg - 1) / std::max(nwg, 1);
@@ -2192,6 +2234,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     const bool use_pad = use_lds && pad_bytes + 4608 <= (size_t)ctx->max_lds && std::getenv("EFGP_NO_PAD") == nullptr;   // + class lists
     const bool raw48 = use_pad && (double)per * std::ldexp(1.0, -47) <= 0.01 * plan->tol && std::getenv("EFGP_NO_RAW48") == nullptr;
     if (use_lds) {
+        if (scale_out) *scale_out = d_scale;
         // fixed-point scale from max |c| (device side, no host round trip)
         if (need_max) {
             const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nvals + 8191) / 8192, 256));
@@ -2200,7 +2243,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         }
         hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream,
                            need_max ? d_cmax : (unsigned long long*)nullptr,
-                           floor_bound, per, d_scale, raw48 ? 46 : 61);
+                           floor_bound, mode == STR_REAL_AND_ONES ? 1 : 0, per, d_scale, raw48 ? 46 : 61);
         EFGP_HIP_CHECK(hipGetLastError());
     }
 
@@ -2452,7 +2495,8 @@ int efgp_nufft_type1_pair(efgp_nufft_t* plan, const double* y, const int64_t* n_
     if (rc != EFGP_OK) return rc;
     int mode = (out_y && out_ones) ? STR_REAL_AND_ONES : (out_y ? STR_REAL : STR_ONES);
     double2* fine = nullptr;
-    rc = spread_and_fft(plan, w, y, mode, 1, -1, stream, &fine);
+    const double* pair_scale = nullptr;
+    rc = spread_and_fft(plan, w, y, mode, 1, -1, stream, &fine, 0, 0, &pair_scale);
     if (rc != EFGP_OK) return rc;
     // correction factors were built for `box`; a smaller centred box indexes them with an offset
     auto sub = [&](const int64_t* nm, int part, void* out) -> int {
@@ -2478,7 +2522,7 @@ int efgp_nufft_type1_pair(efgp_nufft_t* plan, const double* y, const int64_t* n_
         const int64_t most = std::max(ma.total, mb.total);
         const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((most + 255) / 256, 2048));
         hipLaunchKernelGGL(deconvolve_pair_kernel, dim3(blocks, 2), dim3(256), 0, stream, (const double2*)fine, cells, ma,
-                           (double2*)out_y, mb, (double2*)out_ones);
+                           (double2*)out_y, mb, (double2*)out_ones, pair_scale);
         EFGP_HIP_CHECK(hipGetLastError());
         return EFGP_OK;
     }

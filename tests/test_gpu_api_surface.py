@@ -262,3 +262,52 @@ def test_weighted_toeplitz_and_circulant_preconditioners():
         assert _rel(A(xp), b) < 5e-9
         r2 = torch.randn(2, mtot * mtot, generator=g, dtype=torch.float64).to(torch.complex128).cuda()
         assert Minv(r2).shape == r2.shape and _rel(Minv(r2)[1], Minv(r2[1])) < 1e-12
+
+
+def test_edge_inputs():
+    """Empty / single prediction sets, duplicate and lattice points, zero, huge and tiny targets, strided inputs."""
+    from efgpnd import EFGPND
+    from kernels.squared_exponential import SquaredExponential
+    from oracle import efgp_oracle as O
+    x, y = _data(4000, 2, seed=9)
+    k = lambda: SquaredExponential(dimension=2, init_lengthscale=0.3, init_variance=1.2)  # noqa: E731
+    opts = {"cg_tolerance": 1e-10}
+    m = EFGPND(x.cuda(), y.cuda(), k(), sigmasq=0.2, eps=1e-4, nufft_eps=1e-9, estimate_params=False, opts=opts)
+    # no prediction points / one prediction point
+    mean0, var0 = m.predict(torch.zeros(0, 2, dtype=torch.float64).cuda(), return_variance=False)
+    assert mean0.shape == (0,) and var0.shape == (0,)
+    xn = torch.tensor([[0.1, -0.4]], dtype=torch.float64)
+    mean1, _ = m.predict(xn.cuda(), return_variance=False)
+    ko = O.KernelSpec("se", 2, 0.3, 1.2)
+    fit = O.fit(x, y, ko, 0.2, 1e-4, cg_tol=1e-10)
+    assert abs(float(mean1[0]) - float(O.predict_mean(fit, xn)[0])) < 1e-8 * max(1.0, abs(float(mean1[0])))
+    # strided (non-contiguous) inputs give the same fit
+    xs = torch.zeros(4000, 4, dtype=torch.float64)
+    xs[:, ::2] = x
+    ms = EFGPND(xs.cuda()[:, ::2], y.cuda(), k(), sigmasq=0.2, eps=1e-4, nufft_eps=1e-9, estimate_params=False, opts=opts)
+    assert _rel(ms.predict(xn.cuda(), return_variance=False)[0], mean1) < 1e-12
+    # duplicate points and points on a lattice that coincides with fine-grid cell boundaries
+    lat = torch.cartesian_prod(torch.linspace(-1, 1, 33, dtype=torch.float64), torch.linspace(-1, 1, 33, dtype=torch.float64))
+    xd = torch.cat([lat, lat[:200], lat[:50]])
+    g = torch.Generator().manual_seed(3)
+    yd = torch.sin(2 * xd[:, 0]) + 0.1 * torch.randn(xd.shape[0], generator=g, dtype=torch.float64)
+    md = EFGPND(xd.cuda(), yd.cuda(), k(), sigmasq=0.2, eps=1e-4, nufft_eps=1e-9, estimate_params=False, opts=opts)
+    fd = O.fit(xd, yd, ko, 0.2, 1e-4, cg_tol=1e-10)
+    xq = _data(64, 2, seed=10)[0]
+    assert _rel(md.predict(xq.cuda(), return_variance=False)[0], O.predict_mean(fd, xq)) < 1e-7
+    # targets: all zero, huge, tiny (the spreader's fixed-point scale follows max|y|)
+    # (tiny targets are limited by the reference's own div_eps = 1e-16 in <p, A p> + eps, cg.py:57)
+    for scale in (0.0, 1e60, 1e6, 0.125):            # each channel of the fused pass has its own scale / normalisation
+        mz = EFGPND(x.cuda(), (y * scale).cuda(), k(), sigmasq=0.2, eps=1e-4, nufft_eps=1e-9, estimate_params=False, opts=opts)
+        mq = mz.predict(xq.cuda(), return_variance=False)[0]
+        assert torch.isfinite(mq).all()
+        if scale == 0.0:
+            assert float(mq.abs().max()) < 1e-20        # rounding leakage of the ones channel in the fused pair
+        else:
+            ref = m.predict(xq.cuda(), return_variance=False)[0] * scale
+            assert _rel(mq, ref) < 1e-7
+    # wrong shapes are rejected like the reference does (N, d = x.shape)
+    with pytest.raises(ValueError):
+        m.predict(torch.zeros(5, 3, dtype=torch.float64).cuda(), return_variance=False)
+    with pytest.raises(ValueError):
+        m.predict(None)
