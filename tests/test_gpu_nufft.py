@@ -223,3 +223,26 @@ def test_type2_tiled_gather_beyond_lds(d, nm, tol, real_only, monkeypatch):
     plan2 = NufftPlan(x.cuda(), h, tol)
     out2 = plan2.type2(f.cuda(), (nm,) * d, real_only=real_only)
     assert _rel(out, out2) < 1e-12
+
+
+@pytest.mark.parametrize("d,nm,N", [(2, 23, 300_001), (2, 45, 524_288), (3, 9, 400_000)])
+def test_bank_balanced_order_is_bitwise_neutral(d, nm, N, monkeypatch):
+    """The per-plan processing order of the LDS spreader (class_order_kernel) only permutes exact integer sums:
+    results are bit-identical with and without it, for strengths from memory, the fused pair and in-kernel probes."""
+    from efgp_hip import NufftPlan
+    x = _points(N, d, 77)
+    g = torch.Generator().manual_seed(13)
+    y = torch.randn(N, generator=g, dtype=torch.float64).cuda()
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("EFGP_NO_CLASS_ORDER", "1")
+        else:
+            monkeypatch.delenv("EFGP_NO_CLASS_ORDER", raising=False)
+        plan = NufftPlan(x.cuda(), 0.31, 1e-7)
+        Fy, v = plan.type1_pair(y, (nm,) * d, (2 * nm - 1,) * d)
+        Zf = plan.type1_rademacher(11, 3, (nm,) * d)
+        c = plan.type1(torch.complex(y, 0.5 * y.flip(0)), (nm,) * d)
+        res.append((Fy, v, Zf, c))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
