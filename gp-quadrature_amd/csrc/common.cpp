@@ -144,7 +144,7 @@ void* pool_alloc(DeviceCtx* ctx, size_t bytes) {
 
 // Blocks go back to per-size free lists; the lists together are capped (changing grid sizes would otherwise park
 // one block per size forever): beyond the cap the block is released to the runtime instead.
-constexpr size_t kPoolCapBytes = size_t(256) << 20;
+constexpr size_t kPoolCapBytes = size_t(4) << 30;      // small next to 288 GB of HBM; large plans park several 100-MB blocks
 
 void pool_free(DeviceCtx* ctx, void* p, size_t bytes) {
     if (!p) return;

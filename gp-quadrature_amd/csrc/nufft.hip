@@ -768,6 +768,93 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(TileGeom t, const dou
     }
 }
 
+// Bank-balanced order inside every tile (the tiled counterpart of class_order_kernel): a tile's points are in
+// arbitrary order after the counting sort, so they may be permuted freely.  Class = (linear cell index of the first
+// covered cell inside the tile's LDS image) mod 16; within windows of kOrderWindow sorted positions of one tile the
+// points are laid out round-robin over the classes, so that 16 consecutive positions -- the 16 lanes of an LDS
+// atomic group in spread_tile_kernel -- hit 16 different 8-byte columns.  Out-of-place.
+template <int D>
+__global__ __launch_bounds__(kSpreadThreads) void tile_class_order_kernel(TileGeom t, const double* __restrict__ xs_in,
+                                                                         const int* __restrict__ order_in,
+                                                                         const int* __restrict__ start, int64_t npts,
+                                                                         double* __restrict__ xs_out, int* __restrict__ order_out) {
+    __shared__ int cnt[16], rank_next[16];
+    __shared__ int s_bin;
+    // one workgroup per window of kOrderWindow sorted positions; a window that spans several tiles lays out each
+    // tile's segment separately
+    const int64_t wlo = (int64_t)blockIdx.x * kOrderWindow;
+    const int64_t whi = wlo + kOrderWindow < npts ? wlo + kOrderWindow : npts;
+    if (threadIdx.x == 0) {
+        int l = 0, r = t.nbins;            // invariant: start[l] <= wlo < start[r]
+        while (r - l > 1) {
+            const int m = (l + r) >> 1;
+            if ((int64_t)start[m] <= wlo) l = m;
+            else r = m;
+        }
+        s_bin = l;
+    }
+    __syncthreads();
+    int bin = s_bin;
+    constexpr int kPer = kOrderWindow / kSpreadThreads;
+    int64_t cur = wlo;
+    while (cur < whi) {
+        while ((int64_t)start[bin + 1] <= cur) ++bin;            // skip empty tiles
+        const int64_t lo = cur;
+        const int64_t hi = (int64_t)start[bin + 1] < whi ? (int64_t)start[bin + 1] : whi;
+        int rem = bin, o[3] = {0, 0, 0};
+        for (int q = D - 1; q >= 0; --q) {
+            o[q] = (rem % t.nt[q]) * t.T[q];
+            rem /= t.nt[q];
+        }
+        if (threadIdx.x < 16) {
+            cnt[threadIdx.x] = 0;
+            rank_next[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        int cls[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int64_t n = lo + threadIdx.x + (int64_t)u * kSpreadThreads;
+            cls[u] = -1;
+            if (n < hi) {
+                int lin = 0;
+#pragma unroll
+                for (int q = 0; q < D; ++q) {
+                    const double Xq = fold(t.scale[q] * (xs_in[n * D + q] - t.xcen[q]), (double)t.nf[q]);
+                    int fq = (int)ceil(Xq - 0.5 * t.W);
+                    if (fq < 0) fq += t.nf[q];
+                    lin = lin * t.ext[q] + (fq - o[q]);
+                }
+                cls[u] = lin & 15;
+                atomicAdd(&cnt[cls[u]], 1);
+            }
+        }
+        __syncthreads();
+        int c16[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) c16[c] = cnt[c];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            if (cls[u] < 0) continue;
+            const int64_t n = lo + threadIdx.x + (int64_t)u * kSpreadThreads;
+            const int c = cls[u];
+            const int r = atomicAdd(&rank_next[c], 1);
+            int pos = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                pos += min(c16[q], r);
+                if (q < c && c16[q] > r) ++pos;
+            }
+            const int64_t dst = lo + pos;
+#pragma unroll
+            for (int q = 0; q < D; ++q) xs_out[dst * D + q] = xs_in[n * D + q];
+            order_out[dst] = order_in[n];
+        }
+        __syncthreads();
+        cur = hi;
+    }
+}
+
 struct TileSpreadArgs {
     TileGeom t;
     const double* xs;         // tile-sorted coordinates
@@ -1504,6 +1591,8 @@ struct BinSet {             // points counting-sorted by fine-grid tile (see spr
     int* order = nullptr;
     int* start = nullptr;       // nbins + 1
     size_t xs_bytes = 0, order_bytes = 0, start_bytes = 0;
+    int uses = 0;               // passes served so far
+    bool balanced = false;      // tile_class_order_kernel applied
 };
 
 }  // namespace efgp
@@ -1953,11 +2042,47 @@ static void free_binset(DeviceCtx* ctx, BinSet* b) {
     delete b;
 }
 
+// Bank-balanced order inside the tiles (tile_class_order_kernel); tiles proper only: the single-cell bins of the
+// cell-sorted spreader have one class.  Costs one out-of-place pass over the sorted points.
+static int balance_tiles(efgp_nufft_s* plan, BinSet* b, hipStream_t stream) {
+    DeviceCtx* ctx = plan->ctx;
+    const TileGeom& t = b->t;
+    if (b->balanced) return EFGP_OK;
+    b->balanced = true;
+    if (!(t.T[0] > 1 && plan->dim >= 2 && plan->npts >= (int64_t)kOrderWindow * 16 && std::getenv("EFGP_NO_CLASS_ORDER") == nullptr))
+        return EFGP_OK;
+    double* xs2 = (double*)pool_alloc(ctx, b->xs_bytes);
+    int* order2 = (int*)pool_alloc(ctx, b->order_bytes);
+    if (xs2 && order2) {
+        const unsigned nwin = (unsigned)((plan->npts + kOrderWindow - 1) / kOrderWindow);
+        if (plan->dim == 2)
+            hipLaunchKernelGGL((tile_class_order_kernel<2>), dim3(nwin), dim3(kSpreadThreads), 0, stream, t, (const double*)b->xs,
+                               (const int*)b->order, (const int*)b->start, plan->npts, xs2, order2);
+        else
+            hipLaunchKernelGGL((tile_class_order_kernel<3>), dim3(nwin), dim3(kSpreadThreads), 0, stream, t, (const double*)b->xs,
+                               (const int*)b->order, (const int*)b->start, plan->npts, xs2, order2);
+        EFGP_HIP_CHECK(hipGetLastError());
+        // the old copies may still be read by the kernel just queued: park them in the pool (stream-ordered reuse)
+        pool_free(ctx, b->xs, b->xs_bytes);
+        pool_free(ctx, b->order, b->order_bytes);
+        b->xs = xs2;
+        b->order = order2;
+    } else {
+        if (xs2) pool_free(ctx, xs2, b->xs_bytes);
+        if (order2) pool_free(ctx, order2, b->order_bytes);
+    }
+    return EFGP_OK;
+}
+
 static int get_bins(efgp_nufft_s* plan, const TileGeom& t, int channels, hipStream_t stream, BinSet** out) {
     for (BinSet* b : plan->bins) {
         bool same = b->t.W == t.W && b->t.nbins == t.nbins;
         for (int a = 0; a < plan->dim && same; ++a) same = b->t.nf[a] == t.nf[a] && b->t.T[a] == t.T[a];
         if (same) {
+            if (++b->uses >= 1 && !b->balanced) {          // second pass over this binning: the reordering now pays
+                int rcb = balance_tiles(plan, b, stream);
+                if (rcb != EFGP_OK) return rcb;
+            }
             *out = b;
             return EFGP_OK;
         }
@@ -2001,6 +2126,11 @@ static int get_bins(efgp_nufft_s* plan, const TileGeom& t, int channels, hipStre
     else { EFGP_BIN_LAUNCH(3) }
 #undef EFGP_BIN_LAUNCH
     EFGP_HIP_CHECK(hipGetLastError());
+    // 3-D stencils (W^3 LDS atomics per point) repay the reordering pass at once; 2-D tiles on the second pass
+    if (plan->dim == 3) {
+        int rcb = balance_tiles(plan, b, stream);
+        if (rcb != EFGP_OK) return rcb;
+    }
     plan->bins.push_back(b);
     *out = b;
     return EFGP_OK;

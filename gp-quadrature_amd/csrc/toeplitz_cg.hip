@@ -591,6 +591,217 @@ __global__ __launch_bounds__(kLineThreads) void cg_rows_inv_kernel(LineArgs a) {
     }
 }
 
+// ==========================================================================================================
+// The same for 3-D grids (F = 64..256 per dimension): five launches of pruned batched line transforms.
+//   fwd2 : (deferred p update) ws .* p, FFT along dim 2 of the n0*n1 non-zero lines            -> B1[n0][n1][F2]
+//   fwd1 : per (i0, group of t2): FFT along dim 1 of n1 non-zero inputs                        -> B2[n0][F1][F2]
+//   mid0 : per (t1, group of t2): FFT along dim 0 of n0 non-zero inputs, .* vhat, inverse FFT,
+//          crop-window rows, in place                                                           -> B2[n0][F1][F2]
+//   inv1 : per (j0, group of t2): inverse FFT along dim 1, crop-window rows                    -> B1[n0][n1][F2]
+//   inv2 : inverse FFT along dim 2 of the n0*n1 window lines, crop, A p, <p, A p>
+//   The generic iteration moves the full F^3 grid (4 MB at 64^3) through ~12 passes per matvec; these kernels touch
+//   n0 F1 F2 elements at most (1.5 MB) four times.  `lpb` lines per workgroup (a power of two chosen by the host).
+// ==========================================================================================================
+struct Line3Args {
+    CgArgs c;
+    const double2* vhat;      // [F0][F1][F2], already divided by F0*F1*F2
+    const double2* tw[3];     // exp(-2 pi i q / F[a])
+    double2* b1;              // [slots][n0][n1][F2]
+    double2* b2;              // [slots][n0][F1][F2]
+    int lpb_c;                // lines per workgroup, contiguous kernels (fwd2, inv2)
+    int lpb_s;                // adjacent t2 columns per workgroup, strided kernels (fwd1, mid0, inv1)
+    int nblk_lines;           // workgroups of inv2 per system: partial sums of <p, A p>
+};
+
+__global__ __launch_bounds__(kLineThreads) void cg3_fwd2_kernel(Line3Args a) {
+    extern __shared__ double2 lsm[];
+    const CgArgs& c = a.c;
+    const int slot = blockIdx.y;
+    const int row = c.rows ? c.rows[slot] : slot;
+    if (row < 0) return;
+    const CgRowScalars sc = c.sc[row];
+    if (!sc.active) return;
+    const int n0 = (int)c.g.n[0], n1 = (int)c.g.n[1], n2 = (int)c.g.n[2], F2 = (int)c.g.F[2], ld = F2 + 1;
+    const int nlines = n0 * n1;
+    const int l0 = blockIdx.x * a.lpb_c;
+    const int nl = min(a.lpb_c, nlines - l0);
+    double2* A = lsm;
+    double2* B = lsm + a.lpb_c * ld;
+    double2* tws = B + a.lpb_c * ld;
+    load_twiddles(tws, a.tw[2], F2);
+    const int64_t base = (int64_t)row * c.g.M;
+    for (int w = threadIdx.x; w < nl * F2; w += kLineThreads) {
+        const int l = w / F2, i2 = w - l * F2;
+        double2 v = make_double2(0.0, 0.0);
+        if (i2 < n2) {
+            const int t = (l0 + l) * n2 + i2;                     // flat block index: line = i0*n1 + i1
+            double2 pv = c.p[base + t];
+            if (sc.do_p) {                                       // deferred p <- r/diag + beta p
+                double2 zv = c.r[base + t];
+                if (c.diag) {
+                    zv.x /= c.diag[t];
+                    zv.y /= c.diag[t];
+                }
+                pv = make_double2(zv.x + sc.beta * pv.x, zv.y + sc.beta * pv.y);
+                c.p[base + t] = pv;
+            }
+            v = cmul(pv, c.ws[t]);
+        }
+        A[l * ld + i2] = v;
+    }
+    __syncthreads();
+    const double2* X = line_fft(A, B, F2, ld, nl, tws);
+    double2* out = a.b1 + ((int64_t)slot * nlines + l0) * F2;
+    for (int w = threadIdx.x; w < nl * F2; w += kLineThreads) {
+        const int l = w / F2, i2 = w - l * F2;
+        out[(int64_t)l * F2 + i2] = X[l * ld + i2];
+    }
+}
+
+// MODE 0: forward along dim 1 (B1 -> B2);  MODE 1: inverse along dim 1 with crop (B2 -> B1)
+template <int MODE>
+__global__ __launch_bounds__(kLineThreads) void cg3_dim1_kernel(Line3Args a) {
+    extern __shared__ double2 lsm[];
+    const CgArgs& c = a.c;
+    const int slot = blockIdx.y;
+    const int row = c.rows ? c.rows[slot] : slot;
+    if (row < 0) return;
+    if (!c.sc[row].active) return;
+    const int n0 = (int)c.g.n[0], n1 = (int)c.g.n[1], F1 = (int)c.g.F[1], F2 = (int)c.g.F[2], ld = F1 + 1;
+    const int L = a.lpb_s;
+    const int groups = F2 / L;
+    const int i0 = blockIdx.x / groups, c0 = (blockIdx.x - i0 * groups) * L;      // plane i0 (or j0), first t2 column
+    double2* A = lsm;
+    double2* B = lsm + L * ld;
+    double2* tws = B + L * ld;
+    load_twiddles(tws, a.tw[1], F1);
+    const double2* b1 = a.b1 + (int64_t)slot * n0 * n1 * F2;
+    double2* b2 = a.b2 + (int64_t)slot * n0 * F1 * F2;
+    if (MODE == 0) {
+        for (int w = threadIdx.x; w < L * F1; w += kLineThreads) {
+            const int i1 = w / L, l = w - i1 * L;
+            A[l * ld + i1] = i1 < n1 ? b1[((int64_t)i0 * n1 + i1) * F2 + c0 + l] : make_double2(0.0, 0.0);
+        }
+    } else {
+        for (int w = threadIdx.x; w < L * F1; w += kLineThreads) {
+            const int t1 = w / L, l = w - t1 * L;
+            const double2 v = b2[((int64_t)i0 * F1 + t1) * F2 + c0 + l];
+            A[l * ld + t1] = make_double2(v.x, -v.y);
+        }
+    }
+    __syncthreads();
+    const double2* X = line_fft(A, B, F1, ld, L, tws);
+    if (MODE == 0) {
+        for (int w = threadIdx.x; w < L * F1; w += kLineThreads) {
+            const int t1 = w / L, l = w - t1 * L;
+            b2[((int64_t)i0 * F1 + t1) * F2 + c0 + l] = X[l * ld + t1];
+        }
+    } else {
+        double2* out = a.b1 + (int64_t)slot * n0 * n1 * F2;
+        for (int w = threadIdx.x; w < L * n1; w += kLineThreads) {
+            const int j1 = w / L, l = w - j1 * L;
+            const double2 z = X[l * ld + (n1 - 1) + j1];
+            out[((int64_t)i0 * n1 + j1) * F2 + c0 + l] = make_double2(z.x, -z.y);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kLineThreads) void cg3_mid0_kernel(Line3Args a) {
+    extern __shared__ double2 lsm[];
+    const CgArgs& c = a.c;
+    const int slot = blockIdx.y;
+    const int row = c.rows ? c.rows[slot] : slot;
+    if (row < 0) return;
+    if (!c.sc[row].active) return;
+    const int n0 = (int)c.g.n[0], F0 = (int)c.g.F[0], F1 = (int)c.g.F[1], F2 = (int)c.g.F[2], ld = F0 + 1;
+    const int L = a.lpb_s;
+    const int groups = F2 / L;
+    const int t1 = blockIdx.x / groups, c0 = (blockIdx.x - t1 * groups) * L;
+    double2* A = lsm;
+    double2* B = lsm + L * ld;
+    double2* tws = B + L * ld;
+    load_twiddles(tws, a.tw[0], F0);
+    double2* b2 = a.b2 + (int64_t)slot * n0 * F1 * F2;
+    for (int w = threadIdx.x; w < L * F0; w += kLineThreads) {
+        const int i0 = w / L, l = w - i0 * L;
+        A[l * ld + i0] = i0 < n0 ? b2[((int64_t)i0 * F1 + t1) * F2 + c0 + l] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    double2* X = line_fft(A, B, F0, ld, L, tws);
+    double2* Y = X == A ? B : A;
+    for (int w = threadIdx.x; w < L * F0; w += kLineThreads) {
+        const int t0 = w / L, l = w - t0 * L;
+        const double2 m = cmul(X[l * ld + t0], a.vhat[((int64_t)t0 * F1 + t1) * F2 + c0 + l]);
+        X[l * ld + t0] = make_double2(m.x, -m.y);
+    }
+    __syncthreads();
+    const double2* Z = line_fft(X, Y, F0, ld, L, tws);
+    for (int w = threadIdx.x; w < L * n0; w += kLineThreads) {
+        const int j0 = w / L, l = w - j0 * L;
+        const double2 z = Z[l * ld + (n0 - 1) + j0];
+        b2[((int64_t)j0 * F1 + t1) * F2 + c0 + l] = make_double2(z.x, -z.y);
+    }
+}
+
+__global__ __launch_bounds__(kLineThreads) void cg3_inv2_kernel(Line3Args a) {
+    extern __shared__ double2 lsm[];
+    __shared__ double red[kLineThreads / 64];
+    __shared__ int flag;
+    const CgArgs& c = a.c;
+    const int slot = blockIdx.y;
+    const int row = c.rows ? c.rows[slot] : slot;
+    if (row < 0) return;
+    if (!c.sc[row].active) return;
+    const int n0 = (int)c.g.n[0], n1 = (int)c.g.n[1], n2 = (int)c.g.n[2], F2 = (int)c.g.F[2], ld = F2 + 1;
+    const int nlines = n0 * n1;
+    const int l0 = blockIdx.x * a.lpb_c;
+    const int nl = min(a.lpb_c, nlines - l0);
+    double2* A = lsm;
+    double2* B = lsm + a.lpb_c * ld;
+    double2* tws = B + a.lpb_c * ld;
+    load_twiddles(tws, a.tw[2], F2);
+    const double2* in = a.b1 + ((int64_t)slot * nlines + l0) * F2;
+    for (int w = threadIdx.x; w < nl * F2; w += kLineThreads) {
+        const int l = w / F2, i2 = w - l * F2;
+        const double2 v = in[(int64_t)l * F2 + i2];
+        A[l * ld + i2] = make_double2(v.x, -v.y);
+    }
+    __syncthreads();
+    const double2* X = line_fft(A, B, F2, ld, nl, tws);
+    const int64_t base = (int64_t)row * c.g.M;
+    double pAp = 0.0;
+    for (int w = threadIdx.x; w < nl * n2; w += kLineThreads) {
+        const int l = w / n2, i2 = w - l * n2;
+        const int t = (l0 + l) * n2 + i2;
+        const double2 z = X[l * ld + (n2 - 1) + i2];
+        const double2 pv = c.p[base + t];
+        const double2 Ap = apply_A(c, c.ws[t], make_double2(z.x, -z.y), pv);
+        c.ap[base + t] = Ap;
+        pAp += pv.x * Ap.x + pv.y * Ap.y;
+    }
+    pAp = block_sum(pAp, red);
+    double* part = c.partial + (int64_t)row * 3 * kCgBlocksMax;
+    if (threadIdx.x == 0) part[blockIdx.x] = pAp;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int prev = atomicAdd(&c.counter[2 * row], 1);
+        flag = prev == a.nblk_lines - 1;
+        if (flag) c.counter[2 * row] = 0;
+    }
+    __syncthreads();
+    if (!flag) return;
+    __threadfence();
+    __shared__ double fin[kCgBlocksMax];
+    if (threadIdx.x < a.nblk_lines) fin[threadIdx.x] = load_agent(&part[threadIdx.x]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < a.nblk_lines; ++i) t += fin[i];
+        c.sc[row].pAp = t + kDivEps;
+    }
+}
+
 template <bool AC, bool BC>
 __global__ void vdot_real_kernel(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
                                  double* __restrict__ partial) {
@@ -631,6 +842,7 @@ struct efgp_toeplitz_s {
     double2* tw[3] = {nullptr, nullptr, nullptr};   // exp(-2 pi i q / F[a]) tables for the persistent CG
     bool persistent_ok = false;
     bool lines_ok = false;       // 2-D, power-of-two F in [128, 512]: fused line-FFT CG iteration
+    bool lines3_ok = false;      // 3-D, power-of-two F in [64, 256]: the same with five pruned line passes
 };
 
 namespace efgp {
@@ -718,7 +930,12 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
         const int64_t F = op->g.F[a];
         op->lines_ok = F >= 128 && F <= 512 && (F & (F - 1)) == 0;
     }
-    if (op->persistent_ok || op->lines_ok) {
+    op->lines3_ok = dim == 3;
+    for (int a = 0; a < dim && op->lines3_ok; ++a) {
+        const int64_t F = op->g.F[a];
+        op->lines3_ok = F >= 64 && F <= 256 && (F & (F - 1)) == 0;
+    }
+    if (op->persistent_ok || op->lines_ok || op->lines3_ok) {
         for (int a = 0; a < dim; ++a) {
             const int64_t n = op->g.F[a];
             auto it = ctx->twiddles.find(n);
@@ -739,6 +956,7 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
                 if (dtw) (void)hipFree(dtw);
                 op->persistent_ok = false;
                 op->lines_ok = false;
+                op->lines3_ok = false;
                 break;
             }
             ctx->twiddles[n] = dtw;
@@ -922,6 +1140,28 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
             EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg_rows_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
             EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg_cols_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));
         }
+        const bool use_lines3 = op->lines3_ok && std::getenv("EFGP_NO_CG_LINES") == nullptr;
+        Line3Args l3;
+        size_t lds3_c = 0, lds3_s[3] = {0, 0, 0};
+        if (use_lines3) {
+            l3.vhat = op->vhat;
+            for (int q = 0; q < 3; ++q) l3.tw[q] = op->tw[q];
+            l3.b1 = pad;
+            l3.b2 = pad + (int64_t)rows * g.n[0] * g.n[1] * g.F[2];
+            const int64_t nlines = g.n[0] * g.n[1];
+            int lpb = 16;
+            while ((nlines + lpb - 1) / lpb > kCgBlocksMax) lpb <<= 1;
+            l3.lpb_c = lpb;
+            l3.lpb_s = 16;
+            l3.nblk_lines = (int)((nlines + lpb - 1) / lpb);
+            lds3_c = ((size_t)2 * lpb * (size_t)(g.F[2] + 1) + (size_t)g.F[2]) * sizeof(double2);
+            for (int q = 0; q < 2; ++q) lds3_s[q] = ((size_t)2 * l3.lpb_s * (size_t)(g.F[q] + 1) + (size_t)g.F[q]) * sizeof(double2);
+            EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg3_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3_c));
+            EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg3_inv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3_c));
+            EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg3_dim1_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3_s[1]));
+            EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg3_dim1_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3_s[1]));
+            EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg3_mid0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3_s[0]));
+        }
         bool use_graph = !timing_enabled() && std::getenv("EFGP_NO_CG_GRAPH") == nullptr;
         hipGraphExec_t graph_exec = nullptr;
         int graph_slots = -1;
@@ -939,6 +1179,18 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
             // costs the host ~300 us per iteration (measured, 3-D 64^3), far more than the GPU needs.  A full burst is
             // therefore captured ONCE into a hipGraph per (slots, row map) state and replayed with one launch.
             auto enqueue_iteration = [&]() -> int {
+                if (use_lines3) {
+                    l3.c = a;
+                    const unsigned gs = (unsigned)(g.F[2] / l3.lpb_s);
+                    hipLaunchKernelGGL(cg3_fwd2_kernel, dim3(l3.nblk_lines, slots), dim3(kLineThreads), lds3_c, stream, l3);
+                    hipLaunchKernelGGL((cg3_dim1_kernel<0>), dim3((unsigned)g.n[0] * gs, slots), dim3(kLineThreads), lds3_s[1], stream, l3);
+                    hipLaunchKernelGGL(cg3_mid0_kernel, dim3((unsigned)g.F[1] * gs, slots), dim3(kLineThreads), lds3_s[0], stream, l3);
+                    hipLaunchKernelGGL((cg3_dim1_kernel<1>), dim3((unsigned)g.n[0] * gs, slots), dim3(kLineThreads), lds3_s[1], stream, l3);
+                    hipLaunchKernelGGL(cg3_inv2_kernel, dim3(l3.nblk_lines, slots), dim3(kLineThreads), lds3_c, stream, l3);
+                    hipLaunchKernelGGL(cg_axpy_kernel, dim3(a.nblk, slots), dim3(kVecThreads), 0, stream, a);
+                    EFGP_HIP_CHECK(hipGetLastError());
+                    return EFGP_OK;
+                }
                 if (use_lines) {
                     la.c = a;
                     hipLaunchKernelGGL(cg_rows_fwd_kernel, dim3(la.nblk_rows, slots), dim3(kLineThreads), lds_rows, stream, la);

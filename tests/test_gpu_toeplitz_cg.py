@@ -183,3 +183,39 @@ def test_line_fft_iteration_matches_generic_and_oracle(mtot, monkeypatch):
         T = O.Toeplitz(v)
         xo, ito = O.cg_batched(O.make_A_mean(ws, T, sig2), b, torch.zeros_like(b), 1e-9, diag=diag)
         assert abs(res["lines"][1] - ito) <= 1 and _rel(res["lines"][0], xo) < 1e-7
+
+
+@pytest.mark.parametrize("mtot", [17, 23, 35])
+def test_line_fft_iteration_3d(mtot, monkeypatch):
+    """3-D grids (F = 64, 64, 128): five pruned line-transform launches per matvec against the generic pad + rocFFT
+    iteration (single and batched systems, both operators) and, at the smallest size, the oracle CG."""
+    from efgp_hip import ToeplitzOp, cg_solve
+    from oracle import efgp_oracle as O
+    g = torch.Generator().manual_seed(31)
+    L = 2 * mtot - 1
+    v = torch.complex(torch.randn(L, L, L, generator=g, dtype=torch.float64), torch.randn(L, L, L, generator=g, dtype=torch.float64))
+    v = (v + v.flip(0, 1, 2).conj()) / 2
+    v[mtot - 1, mtot - 1, mtot - 1] = 6.0 * L ** 1.5          # dominant diagonal: positive definite T
+    M = mtot ** 3
+    ws = torch.exp(-2.0 * torch.rand(M, generator=g, dtype=torch.float64)).to(torch.complex128)
+    sig2 = 0.5
+    B = 3
+    b = torch.complex(torch.randn(B, M, generator=g, dtype=torch.float64), torch.randn(B, M, generator=g, dtype=torch.float64))
+    diag = O.jacobi_diag(ws, sig2, 6.0 * L ** 1.5)
+    op = ToeplitzOp(v.cuda())
+    assert op.fft_shape[0] in (64, 128)
+    res = {}
+    for mode in ("lines", "generic"):
+        if mode == "generic":
+            monkeypatch.setenv("EFGP_NO_CG_LINES", "1")
+        else:
+            monkeypatch.delenv("EFGP_NO_CG_LINES", raising=False)
+        res[mode] = cg_solve(op, ws.cuda(), sig2, 0, b.cuda(), torch.zeros_like(b).cuda(), 1e-9, diag=diag.cuda())
+        res[mode + "_var"] = cg_solve(op, ws.cuda(), sig2, 1, b[1].cuda(), 0.1 * b[0].cuda(), 1e-9, batched=False)
+    assert abs(res["lines"][1] - res["generic"][1]) <= 1 and _rel(res["lines"][0], res["generic"][0]) < 1e-8
+    assert abs(res["lines_var"][1] - res["generic_var"][1]) <= 1 and _rel(res["lines_var"][0], res["generic_var"][0]) < 1e-8
+    assert res["lines"][1] < 2 * M
+    if mtot == 17:
+        T = O.Toeplitz(v)
+        xo, ito = O.cg_batched(O.make_A_mean(ws, T, sig2), b, torch.zeros_like(b), 1e-9, diag=diag)
+        assert abs(res["lines"][1] - ito) <= 1 and _rel(res["lines"][0], xo) < 1e-7
