@@ -383,7 +383,6 @@ __global__ __launch_bounds__(kVecThreads) void cg_axpy_kernel(CgArgs a) {
 //   for odd log2 F) in two LDS ping-pong buffers; twiddles come from the per-length table exp(-2 pi i q / F).
 // ==========================================================================================================
 constexpr int kLineThreads = 256;
-constexpr int kLinesPerBlock = 4;
 
 __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
 
@@ -447,7 +446,8 @@ struct LineArgs {
     const double2* tw1;
     double2* b1;              // [slots][n0][F1]
     double2* b2;              // [slots][n0][F1]
-    int nblk_rows;            // row blocks per system = ceil(n0 / kLinesPerBlock): partial sums of <p, A p>
+    int nblk_rows;            // row blocks per system = ceil(n0 / lpb): partial sums of <p, A p>
+    int lpb;                  // lines per workgroup (a power of two; larger for batched solves: fewer reduction arrivals)
 };
 
 __global__ __launch_bounds__(kLineThreads) void cg_rows_fwd_kernel(LineArgs a) {
@@ -459,11 +459,11 @@ __global__ __launch_bounds__(kLineThreads) void cg_rows_fwd_kernel(LineArgs a) {
     const CgRowScalars sc = c.sc[row];
     if (!sc.active) return;
     const int n0 = (int)c.g.n[0], n1 = (int)c.g.n[1], F1 = (int)c.g.F[1], ld = F1 + 1;
-    const int r0 = blockIdx.x * kLinesPerBlock;
-    const int nl = min(kLinesPerBlock, n0 - r0);
+    const int r0 = blockIdx.x * a.lpb;
+    const int nl = min(a.lpb, n0 - r0);
     double2* A = lsm;
-    double2* B = lsm + kLinesPerBlock * ld;
-    double2* tws = B + kLinesPerBlock * ld;
+    double2* B = lsm + a.lpb * ld;
+    double2* tws = B + a.lpb * ld;
     load_twiddles(tws, a.tw1, F1);
     const int64_t base = (int64_t)row * c.g.M;
     for (int w = threadIdx.x; w < nl * F1; w += kLineThreads) {
@@ -502,31 +502,31 @@ __global__ __launch_bounds__(kLineThreads) void cg_cols_mid_kernel(LineArgs a) {
     if (row < 0) return;
     if (!c.sc[row].active) return;
     const int n0 = (int)c.g.n[0], F0 = (int)c.g.F[0], F1 = (int)c.g.F[1], ld = F0 + 1;
-    const int c0 = blockIdx.x * kLinesPerBlock;                  // first column of this block (F1 % 8 == 0)
+    const int c0 = blockIdx.x * a.lpb;                  // first column of this block (F1 % 8 == 0)
     double2* A = lsm;
-    double2* B = lsm + kLinesPerBlock * ld;
-    double2* tws = B + kLinesPerBlock * ld;
+    double2* B = lsm + a.lpb * ld;
+    double2* tws = B + a.lpb * ld;
     load_twiddles(tws, a.tw0, F0);
     const double2* in = a.b1 + (int64_t)slot * n0 * F1;
     // line l = column c0 + l; consecutive threads read consecutive columns of one row (128-B segments)
-    for (int w = threadIdx.x; w < kLinesPerBlock * F0; w += kLineThreads) {
-        const int i0 = w / kLinesPerBlock, l = w - i0 * kLinesPerBlock;
+    for (int w = threadIdx.x; w < a.lpb * F0; w += kLineThreads) {
+        const int i0 = w / a.lpb, l = w - i0 * a.lpb;
         A[l * ld + i0] = i0 < n0 ? in[(int64_t)i0 * F1 + c0 + l] : make_double2(0.0, 0.0);
     }
     __syncthreads();
-    double2* X = line_fft(A, B, F0, ld, kLinesPerBlock, tws);
+    double2* X = line_fft(A, B, F0, ld, a.lpb, tws);
     double2* Y = X == A ? B : A;
     // .* vhat, conjugate: the inverse transform is conj(FFT(conj(.)))
-    for (int w = threadIdx.x; w < kLinesPerBlock * F0; w += kLineThreads) {
-        const int i0 = w / kLinesPerBlock, l = w - i0 * kLinesPerBlock;
+    for (int w = threadIdx.x; w < a.lpb * F0; w += kLineThreads) {
+        const int i0 = w / a.lpb, l = w - i0 * a.lpb;
         const double2 m = cmul(X[l * ld + i0], a.vhat[(int64_t)i0 * F1 + c0 + l]);
         X[l * ld + i0] = make_double2(m.x, -m.y);
     }
     __syncthreads();
-    const double2* Z = line_fft(X, Y, F0, ld, kLinesPerBlock, tws);
+    const double2* Z = line_fft(X, Y, F0, ld, a.lpb, tws);
     double2* out = a.b2 + (int64_t)slot * n0 * F1;
-    for (int w = threadIdx.x; w < kLinesPerBlock * n0; w += kLineThreads) {
-        const int j = w / kLinesPerBlock, l = w - j * kLinesPerBlock;
+    for (int w = threadIdx.x; w < a.lpb * n0; w += kLineThreads) {
+        const int j = w / a.lpb, l = w - j * a.lpb;
         const double2 z = Z[l * ld + (n0 - 1) + j];               // crop window rows [n0-1, 2 n0-1)
         out[(int64_t)j * F1 + c0 + l] = make_double2(z.x, -z.y);
     }
@@ -542,11 +542,11 @@ __global__ __launch_bounds__(kLineThreads) void cg_rows_inv_kernel(LineArgs a) {
     if (row < 0) return;
     if (!c.sc[row].active) return;
     const int n0 = (int)c.g.n[0], n1 = (int)c.g.n[1], F1 = (int)c.g.F[1], ld = F1 + 1;
-    const int r0 = blockIdx.x * kLinesPerBlock;
-    const int nl = min(kLinesPerBlock, n0 - r0);
+    const int r0 = blockIdx.x * a.lpb;
+    const int nl = min(a.lpb, n0 - r0);
     double2* A = lsm;
-    double2* B = lsm + kLinesPerBlock * ld;
-    double2* tws = B + kLinesPerBlock * ld;
+    double2* B = lsm + a.lpb * ld;
+    double2* tws = B + a.lpb * ld;
     load_twiddles(tws, a.tw1, F1);
     const double2* in = a.b2 + ((int64_t)slot * n0 + r0) * F1;
     for (int w = threadIdx.x; w < nl * F1; w += kLineThreads) {
@@ -1102,7 +1102,8 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         int* d_rows = a.status + 16;
         a.counter = (int*)(scb + off_counter);
         a.partial = (double*)(scb + off_partial);
-        a.nblk = (int)std::max<int64_t>(1, std::min<int64_t>(kCgBlocksMax, (g.M + kVecThreads - 1) / kVecThreads));
+        a.nblk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(kCgBlocksMax, (g.M + kVecThreads - 1) / kVecThreads),
+                                                            std::max<int64_t>(1, 1024 / rows)));
         EFGP_HIP_CHECK(hipMemsetAsync(a.status, 0, off_partial - off_status, stream));      // status, map, counters
 
         // r0 = b - A x0
@@ -1133,9 +1134,18 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
             la.tw1 = op->tw[1];
             la.b1 = pad;                                                     // [rows][n0][F1] fits: Ftot >= 2 n0 F1
             la.b2 = pad + (int64_t)rows * g.n[0] * g.F[1];
-            la.nblk_rows = (int)((g.n[0] + kLinesPerBlock - 1) / kLinesPerBlock);
-            lds_rows = ((size_t)2 * kLinesPerBlock * (size_t)(g.F[1] + 1) + (size_t)g.F[1]) * sizeof(double2);   // + twiddles
-            lds_cols = ((size_t)2 * kLinesPerBlock * (size_t)(g.F[0] + 1) + (size_t)g.F[0]) * sizeof(double2);
+            // every workgroup of the reducing kernels pays a device-scope fence (an L2 write-back, ~2 us each, serialised
+            // per XCD): few systems -> many small workgroups for parallelism, many systems -> few large ones
+            const int64_t Fmax = std::max(g.F[0], g.F[1]);
+            int lpb = 4;
+            if (rows > 8) {
+                const int64_t fit = ((int64_t)ctx->max_lds / (int64_t)sizeof(double2) - Fmax) / (2 * (Fmax + 1));
+                while (lpb * 2 <= fit && lpb < 32) lpb <<= 1;
+            }
+            la.lpb = lpb;
+            la.nblk_rows = (int)((g.n[0] + lpb - 1) / lpb);
+            lds_rows = ((size_t)2 * lpb * (size_t)(g.F[1] + 1) + (size_t)g.F[1]) * sizeof(double2);   // + twiddles
+            lds_cols = ((size_t)2 * lpb * (size_t)(g.F[0] + 1) + (size_t)g.F[0]) * sizeof(double2);
             EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg_rows_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
             EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg_rows_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
             EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg_cols_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));
@@ -1151,6 +1161,10 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
             const int64_t nlines = g.n[0] * g.n[1];
             int lpb = 16;
             while ((nlines + lpb - 1) / lpb > kCgBlocksMax) lpb <<= 1;
+            if (rows > 8) {                               // batched: fewer, larger workgroups (fewer reduction fences)
+                const int64_t fit = ((int64_t)ctx->max_lds / (int64_t)sizeof(double2) - g.F[2]) / (2 * (g.F[2] + 1));
+                while (lpb * 2 <= fit && lpb < 64) lpb <<= 1;
+            }
             l3.lpb_c = lpb;
             l3.lpb_s = 16;
             l3.nblk_lines = (int)((nlines + lpb - 1) / lpb);
@@ -1194,7 +1208,7 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
                 if (use_lines) {
                     la.c = a;
                     hipLaunchKernelGGL(cg_rows_fwd_kernel, dim3(la.nblk_rows, slots), dim3(kLineThreads), lds_rows, stream, la);
-                    hipLaunchKernelGGL(cg_cols_mid_kernel, dim3((unsigned)(g.F[1] / kLinesPerBlock), slots), dim3(kLineThreads),
+                    hipLaunchKernelGGL(cg_cols_mid_kernel, dim3((unsigned)(g.F[1] / la.lpb), slots), dim3(kLineThreads),
                                        lds_cols, stream, la);
                     hipLaunchKernelGGL(cg_rows_inv_kernel, dim3(la.nblk_rows, slots), dim3(kLineThreads), lds_rows, stream, la);
                     hipLaunchKernelGGL(cg_axpy_kernel, dim3(a.nblk, slots), dim3(kVecThreads), 0, stream, a);

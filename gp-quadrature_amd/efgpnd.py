@@ -263,7 +263,10 @@ class _Grid:
         # Small grids: evaluate the spectral density on the host (one upload instead of several launches).  Large
         # grids (3-D): on the device -- torch's CPU reductions switch to their threaded path above 32768 elements,
         # which costs tens of milliseconds per call on a many-core host (measured: 89 ms for M = 12167, d = 3).
-        where = self.xis if self.M * d <= 16384 else self.xis.to(dev)
+        # The same host pathology hits torch.pow with a real exponent even on a few hundred elements (12 ms per call
+        # measured on the 256-thread host): Matern densities always go to the device.
+        host_ok = self.M * d <= 16384 and type(kernel).__name__ != "Matern"
+        where = self.xis if host_ok else self.xis.to(dev)
         S = kernel.spectral_density(where).to(torch.float64)
         self.ws = torch.sqrt(S.to(torch.complex128) * self.h ** d).to(dev)       # (M,) complex, imag 0
         self.dprime = None
