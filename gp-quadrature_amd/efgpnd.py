@@ -307,7 +307,7 @@ def efgpnd_gradient_batched(
         log_marginal_probes=100, log_marginal_steps=25,
         probes_Z: Optional[torch.Tensor] = None, probes_V: Optional[torch.Tensor] = None,
         shards: Optional[PointShards] = None, trace_mode: str = "adjoint", probe_seed: Optional[int] = None,
-        domain_length: Optional[float] = None):
+        domain_length: Optional[float] = None, y_norm_sq: Optional[float] = None):
     """d(negative log marginal likelihood)/d(kernel hypers..., sigma^2) = (term1 - term2)/2 with
     Hutchinson trace estimates (data-space probes Z for non-variance kernel hypers, feature-space
     probes V for the noise) and CG solves.  ``x0, x1`` are ignored as in the reference (:72-73).
@@ -316,7 +316,9 @@ def efgpnd_gradient_batched(
     +-1 probes (the reference draws them from torch's generator at :179-182 and :199-202), and
     ``shards`` sums the gridded partials / N-length scalars over point shards; ``domain_length`` passes the box
     length max_a(max x_a - min x_a) when the caller already knows it (EFGPND caches it: the two N-length min/max
-    reductions cost 6.6 ms per step at N = 5e6, d = 3).
+    reductions cost 6.6 ms per step at N = 5e6, d = 3); ``y_norm_sq`` likewise the global sum of y^2.  In the
+    adjoint mode nothing is read back to the host before the gradient is complete (solves through the asynchronous
+    entry points, scalars kept as 0-dim device tensors).
     Stage timers (seconds) are written to ``stats_out['stage_sec']`` with the reference's stage names (host
     clock; with ``do_profiling=True`` the device is synchronised at every stage boundary so they are exact).
 
@@ -389,8 +391,12 @@ def efgpnd_gradient_batched(
     rhs = ws * Fy
     warm = mean_cg_init is not None and tuple(mean_cg_init.shape) == tuple(rhs.shape)
     b0 = mean_cg_init.detach().to(device=dev, dtype=torch.complex128) if warm else torch.zeros_like(rhs)
-    beta, mean_iters, _ = cg_solve(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping,
-                                   diag=diag if use_mean_cg_preconditioner else None, batched=False)
+    res_m = cg_solve_async(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping,
+                           diag=diag if use_mean_cg_preconditioner else None, batched=False)
+    if res_m is None:
+        res_m = cg_solve(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping,
+                         diag=diag if use_mean_cg_preconditioner else None, batched=False)[:2]
+    beta, mean_iters = res_m
     beta_raw = beta.clone()
     beta_s = ws * beta                                        # g = D beta
     Tg = top.apply(beta_s)
@@ -404,9 +410,9 @@ def efgpnd_gradient_batched(
     term2_kernel = torch.stack([vdot_m(fadj_alpha, Dp[:, i] * fadj_alpha) for i in range(kernel_hyper_count)]) \
         if kernel_hyper_count else torch.zeros(0, dtype=torch.float64, device=dev)
     if adjoint:
-        yy = shards.sum_scalars([vdot_real(yd, yd)], dev)[0]
-        y_z = float(vdot_m(Fy, beta_s))                        # Re sum_n y_n z_n
-        z_z = float(vdot_m(beta_s, Tg))                        # |F g|^2 = <g, T g>
+        yy = float(y_norm_sq) if y_norm_sq is not None else shards.sum_scalars([vdot_real(yd, yd)], dev)[0]
+        y_z = vdot_m(Fy, beta_s)                               # Re sum_n y_n z_n          (0-dim device tensors:
+        z_z = vdot_m(beta_s, Tg)                               # |F g|^2 = <g, T g>         no host round trip)
         a_norm = (yy - 2.0 * y_z + z_z) / (sig * sig)
         y_alpha = (yy - y_z) / sig
     else:
@@ -414,7 +420,7 @@ def efgpnd_gradient_batched(
     if variance_idx is not None:
         variance_scalar = float(kernel.get_hyper("variance"))
         term2_kernel[variance_idx] = (y_alpha - sig * a_norm) / variance_scalar
-    term2 = torch.cat((term2_kernel, torch.tensor([a_norm], dtype=torch.float64, device=dev)))
+    term2 = torch.cat((term2_kernel, torch.as_tensor(a_norm, dtype=torch.float64, device=dev).reshape(1)))
     lap("5_compute_term2")
 
     # 6) Monte-Carlo trace probes ---------------------------------------------------------------
@@ -452,9 +458,12 @@ def efgpnd_gradient_batched(
     lap("6_monte_carlo_trace")
 
     # 7) batched CG -----------------------------------------------------------------------------
-    Beta_all, trace_iters, _ = cg_solve(top, ws, sig, 0, B_all, torch.zeros_like(B_all), cg_tol,
-                                        early_stop=early_stopping,
-                                        diag=diag if use_trace_cg_preconditioner else None, batched=True)
+    res_t = cg_solve_async(top, ws, sig, 0, B_all, torch.zeros_like(B_all), cg_tol, early_stop=early_stopping,
+                           diag=diag if use_trace_cg_preconditioner else None, batched=True)
+    if res_t is None:
+        res_t = cg_solve(top, ws, sig, 0, B_all, torch.zeros_like(B_all), cg_tol, early_stop=early_stopping,
+                         diag=diag if use_trace_cg_preconditioner else None, batched=True)[:2]
+    Beta_all, trace_iters = res_t
     lap("7_batch_cg_solve")
 
     # 7.5) term 1 -------------------------------------------------------------------------------
@@ -464,7 +473,7 @@ def efgpnd_gradient_batched(
         if adjoint:
             # sum_n Z (F(D'F*Z) - F(ws beta))/sigma^2 = Re <F*Z, D'F*Z - ws beta> / sigma^2   (F*Z is already global)
             diff = (DFZ - ws * Beta_k).reshape(K, T, M)
-            sums = [float((FZ.conj() * diff[slot]).sum().real) / sig for slot in range(K)]
+            sums = [(FZ.conj() * diff[slot]).sum().real / sig for slot in range(K)]
         else:
             fwdB = plan_p.type2(ws * Beta_k, grid.shape, batched=True)
             Alpha = (rhs_k - fwdB) / sig                                            # (K*T, N)
@@ -472,7 +481,7 @@ def efgpnd_gradient_batched(
             sums = shards.sum_scalars(sums, dev)
         for slot, ki in enumerate(trace_idx):
             term1[ki] = sums[slot] / T
-    t1_noise = N / sig - float(((Vc.conj() * Beta_n).sum(dim=1).real / sig).mean())
+    t1_noise = N / sig - ((Vc.conj() * Beta_n).sum(dim=1).real / sig).mean()
     if variance_idx is not None:
         term1[variance_idx] = (N - sig * t1_noise) / float(kernel.get_hyper("variance"))
     term1[-1] = t1_noise
@@ -502,7 +511,7 @@ def efgpnd_gradient_batched(
     if compute_log_marginal:
         det_term = logdet_slq(ws, sig, top, probes=log_marginal_probes, steps=log_marginal_steps,
                               dtype=torch.float64, device=dev, n=N)
-        log_marginal = torch.tensor(-0.5 * y_alpha - 0.5 * det_term - 0.5 * N * math.log(TWO_PI), dtype=rdtype)
+        log_marginal = torch.tensor(-0.5 * float(y_alpha) - 0.5 * det_term - 0.5 * N * math.log(TWO_PI), dtype=rdtype)
         lap("9_log_marginal_likelihood")
 
     if do_profiling:
@@ -789,7 +798,8 @@ class EFGPND(nn.Module):
             if L <= 1e-9:
                 L = 1.0
             n_glob = int(self._shards.sum_scalars([xd.shape[0]], dev)[0]) if self._shards.active else xd.shape[0]
-            self._devdata = dict(dev=dev, x=xd, y=yd, L=L, N=n_glob)
+            yy = self._shards.sum_scalars([vdot_real(yd, yd)], dev)[0]          # global sum of y^2 (gradient, once)
+            self._devdata = dict(dev=dev, x=xd, y=yd, L=L, N=n_glob, yy=yy)
         return self._devdata
 
     # -- gradient -----------------------------------------------------------------------------------
@@ -818,7 +828,8 @@ class EFGPND(nn.Module):
             use_mean_cg_preconditioner=self.opts.get("mean_cg_preconditioner", True),
             use_trace_cg_preconditioner=self.opts.get("trace_cg_preconditioner", True),
             compute_log_marginal=compute_log_marginal, log_marginal_probes=log_marginal_probes,
-            log_marginal_steps=log_marginal_steps, shards=self._shards, domain_length=dd["L"], **kwargs)
+            log_marginal_steps=log_marginal_steps, shards=self._shards, domain_length=dd["L"], y_norm_sq=dd["yy"],
+            **kwargs)
         self._last_gradient_beta = stats.pop("mean_beta", None)
         self.last_gradient_stats = stats
         grads, log_marginal = res if compute_log_marginal else (res, None)
