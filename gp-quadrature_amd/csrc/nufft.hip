@@ -396,11 +396,12 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_pad_kernel(SpreadArgs a
     const int64_t per = (a.npts + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < a.npts ? lo + per : a.npts;
-    // Bank-balanced lane assignment.  All lanes walk the same stencil offsets, so an atomic wave-instruction
-    // meets no LDS bank conflict inside a 32-lane group when the lanes' first cells differ mod 32 (8-byte
-    // cells over 64 four-byte banks).  Each chunk of 1024 points is counting-sorted by that class in LDS;
-    // lane L of group G takes the G-th point of class L, surplus points of over-full classes fill the lanes
-    // of under-full ones (one pass, every lane busy).  PMC before: 67 % of LDS-active cycles were conflicts.
+    // Bank-balanced lane assignment -- fallback when the plan carries no precomputed order (a.order == nullptr: small
+    // N, or EFGP_NO_CLASS_ORDER).  All lanes walk the same stencil offsets, so an atomic wave-instruction is conflict
+    // free when the first cells of the 16 lanes of an LDS lane group differ mod 16 (see class_order_kernel).  Each
+    // chunk of 1024 points is counting-sorted in LDS by (first cell mod 32) -- a refinement of that class; lane L of
+    // group G takes the G-th point of class L, surplus points of over-full classes fill the lanes of under-full ones
+    // (one pass, every lane busy).  PMC before: 67 % of LDS-active cycles were conflicts, with it 44 %.
     __shared__ int cls_cnt[32];
     __shared__ int cls_free[33];
     __shared__ int left_cnt;
