@@ -2341,7 +2341,9 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     int nwg = 1;
     if (use_lds) {
         int per_cu = std::max(1, std::min(2, (int)((size_t)ctx->max_lds / std::max<size_t>(lds_bytes, 1))));
-        int64_t want = (plan->npts + 4 * kSpreadThreads - 1) / (4 * kSpreadThreads);
+        // LDS-atomic bound: spread the points over as many CUs as there are full 1024-point chunks (each workgroup also
+        // pays a 147-KB zero + flush, ~5 us, so not below one point per thread)
+        int64_t want = (plan->npts + kSpreadThreads - 1) / kSpreadThreads;
         nwg = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->num_cu * per_cu, want));
     } else {
         int64_t want = (plan->npts + kSpreadThreads - 1) / kSpreadThreads;
