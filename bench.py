@@ -56,7 +56,7 @@ def cpu_baseline(seed):
     # a one-GPU box owns a 16-core share of the host; more threads only oversubscribe it
     ncores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(ncores)
-    Ns = 100_000
+    Ns = N_PER_GPU                  # the whole workload: the separable exact NUDFT takes a few seconds at N = 1e6
     x, y = synth(Ns, DIM, seed, "cpu")
     kern = O.KernelSpec("se", DIM, LS, VAR)
     t0 = time.perf_counter()
@@ -70,14 +70,10 @@ def cpu_baseline(seed):
     t3 = time.perf_counter()
     _, its = O.cg_single(A, fit.rhs, torch.zeros_like(fit.rhs), 1e-30, max_iter=200, diag=diag)
     t4 = time.perf_counter()
-    t_sample = t2 - t0
-    # the N-scale part (exact NUDFT passes) scales linearly with N, the CG part does not
-    t_cg = (t4 - t3) / max(its, 1) * fit.iters
-    t_full = (t_sample - t_cg) * (N_PER_GPU / Ns) + t_cg
     return {
-        "value": 1.0 / t_full, "unit": "GP-fits/s (N=1e6, extrapolated from the sample)", "cores": ncores, "kind": "port",
-        "sample": f"N={Ns} of 1e6, same kernel/eps: fit {t1 - t0:.2f}s + mean at N points {t2 - t1:.2f}s "
-                  f"(exact-NUDFT oracle, torch CPU, {ncores} threads); N-scale part scaled x{N_PER_GPU // Ns}",
+        "value": 1.0 / (t2 - t0), "unit": "GP-fits/s (fit + mean at the N points, N=1e6)", "cores": ncores, "kind": "port",
+        "sample": f"the full N={Ns} workload, same kernel/eps, one step: fit {t1 - t0:.2f}s ({fit.iters} CG iterations) + mean at "
+                  f"N points {t2 - t1:.2f}s (exact-NUDFT oracle, torch CPU, {ncores} threads)",
         "cg_iters_per_s": its / (t4 - t3),
     }
 
