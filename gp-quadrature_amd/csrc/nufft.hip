@@ -319,20 +319,20 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
 // over the classes (r-th point of class c at sum_c' min(cnt[c'], r) + #{c' < c: cnt[c'] > r}): 16 consecutive
 // positions hold 16 different classes until the rarest class runs out (~86 % of a 4096-point window).
 // The window keeps the gather of x and the strengths inside ~100 KB.  Depends only on (x, fine grid, W, launch
-// geometry): built once per plan and reused by every pass.
+// geometry): built once per plan and reused by every pass.  (32 classes over 32-lane groups measured no better.)
 constexpr int kOrderWindow = 4096;
 
-template <int D>
+template <int D, int NC>
 __global__ __launch_bounds__(kSpreadThreads) void class_order_kernel(GridGeom g, int W, const double* __restrict__ x, int64_t npts,
                                                                     int64_t per, int* __restrict__ order) {
-    __shared__ int cnt[16], rank_next[16];
+    __shared__ int cnt[NC], rank_next[NC];
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < npts ? lo + per : npts;
     const int nl = (int)g.nf[D - 1];
     const int pl = nl + W - 1;
     constexpr int kPer = kOrderWindow / kSpreadThreads;
     for (int64_t wbase = lo; wbase < hi; wbase += kOrderWindow) {
-        if (threadIdx.x < 16) {
+        if (threadIdx.x < NC) {
             cnt[threadIdx.x] = 0;
             rank_next[threadIdx.x] = 0;
         }
@@ -352,14 +352,14 @@ __global__ __launch_bounds__(kSpreadThreads) void class_order_kernel(GridGeom g,
                     if (fq < 0) fq += nfq;
                     lin = lin * (q == D - 1 ? pl : nfq) + fq;
                 }
-                cls[u] = lin & 15;
+                cls[u] = lin & (NC - 1);
                 atomicAdd(&cnt[cls[u]], 1);
             }
         }
         __syncthreads();
-        int c16[16];
+        int c16[NC];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) c16[c] = cnt[c];
+        for (int c = 0; c < NC; ++c) c16[c] = cnt[c];
 #pragma unroll
         for (int u = 0; u < kPer; ++u) {
             if (cls[u] < 0) continue;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kSpreadThreads) void class_order_kernel(GridGeom g,
             const int r = atomicAdd(&rank_next[c], 1);
             int pos = 0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < NC; ++q) {
                 pos += min(c16[q], r);
                 if (q < c && c16[q] > r) ++pos;
             }
@@ -2414,10 +2414,10 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
                 return EFGP_ENOMEM;
             }
             if (plan->dim == 2)
-                hipLaunchKernelGGL((class_order_kernel<2>), dim3(nwg), dim3(kSpreadThreads), 0, stream, g, w->p.w, plan->x, plan->npts, per,
+                hipLaunchKernelGGL((class_order_kernel<2, 16>), dim3(nwg), dim3(kSpreadThreads), 0, stream, g, w->p.w, plan->x, plan->npts, per,
                                    co->order);
             else
-                hipLaunchKernelGGL((class_order_kernel<3>), dim3(nwg), dim3(kSpreadThreads), 0, stream, g, w->p.w, plan->x, plan->npts, per,
+                hipLaunchKernelGGL((class_order_kernel<3, 16>), dim3(nwg), dim3(kSpreadThreads), 0, stream, g, w->p.w, plan->x, plan->npts, per,
                                    co->order);
             EFGP_HIP_CHECK(hipGetLastError());
             plan->orders.push_back(co);
@@ -2792,10 +2792,10 @@ static int type2_impl(efgp_nufft_t* plan, const void* f, const void* mode_scale,
             }
             const unsigned nwin = (unsigned)((plan->npts + kOrderWindow - 1) / kOrderWindow);
             if (plan->dim == 2)
-                hipLaunchKernelGGL((class_order_kernel<2>), dim3(nwin), dim3(kSpreadThreads), 0, stream, g, w->p.w, plan->x, plan->npts,
+                hipLaunchKernelGGL((class_order_kernel<2, 16>), dim3(nwin), dim3(kSpreadThreads), 0, stream, g, w->p.w, plan->x, plan->npts,
                                    (int64_t)kOrderWindow, co->order);
             else
-                hipLaunchKernelGGL((class_order_kernel<3>), dim3(nwin), dim3(kSpreadThreads), 0, stream, g, w->p.w, plan->x, plan->npts,
+                hipLaunchKernelGGL((class_order_kernel<3, 16>), dim3(nwin), dim3(kSpreadThreads), 0, stream, g, w->p.w, plan->x, plan->npts,
                                    (int64_t)kOrderWindow, co->order);
             EFGP_HIP_CHECK(hipGetLastError());
             plan->orders.push_back(co);
