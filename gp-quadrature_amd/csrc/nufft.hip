@@ -163,7 +163,9 @@ __device__ __forceinline__ void window_eval(const double* __restrict__ coef_gene
 }
 
 __device__ __forceinline__ double fold(double X, double nf) {
-    X -= nf * floor(X / nf);
+    // reciprocal instead of an fp64 division per coordinate (1/nf is loop invariant); a quotient that lands one
+    // unit off next to an integer leaves X within rounding of 0 or nf, which the guards below fold back
+    X -= nf * floor(X * (1.0 / nf));
     // guard against X == nf after rounding
     if (X >= nf) X -= nf;
     if (X < 0.0) X = 0.0;
