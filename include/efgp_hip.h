@@ -74,7 +74,10 @@ int efgp_nufft_destroy(efgp_nufft_t* plan);
  * at efgpnd.py:1496-1499:
  *     out[b, k] = sum_n c[b, n] exp(isign * i * k . phi_n)
  * c: (nbatch, npts), complex if c_is_complex else real (the reference casts real y / ones / +-1
- * probes to complex, efgpnd.py:1467-1468; the real entry avoids that traffic).
+ * probes to complex, efgpnd.py:1467-1468; the real entry avoids that traffic).  Real rows are transformed two per
+ * complex grid (rows 2g, 2g+1) and separated by Hermitian symmetry: rows of one pair should have comparable
+ * magnitude -- the smaller row inherits a relative error of ~1e-16 x the magnitude ratio (probes and the batches of
+ * the EFGP path are +-1 or same-scale; efgp_nufft_type1_pair normalises its y channel for exactly this reason).
  * out: (nbatch, prod n_modes) complex, modes per dimension in CMCL order
  * -(n/2)..(n-1)/2 when modeord == 0, FFT order 0..,-.. when modeord == 1; last dimension fastest.
  * n_modes: d host int64. */
