@@ -134,7 +134,7 @@ def main():
     elapsed = time.perf_counter() - t0
     spread_ms, spread_n = kernel_timing_read("spread")
     interp_ms, interp_n = kernel_timing_read("interp")
-    cgit_ms, cgit_n = kernel_timing_read("cg_iteration")
+    cgs_ms, cgs_n = kernel_timing_read("cg_solve")
     kernel_timing(False)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -206,6 +206,10 @@ def main():
             except Exception:
                 traffic = None
         interp_bytes = N * (8 * DIM + 8) + 16 * mtot ** DIM          # real-only output
+        ftot = 1
+        for _ in range(DIM):
+            ftot *= 1 << (4 * m + 1 - 1).bit_length()
+        cg_bytes = 16 * (ftot + 8 * mtot ** DIM) * mean_iters        # fused-ideal bytes per iteration
         rec = {
             "metric": "GP-fits/sec (fit + posterior mean at the N training points), N=1e6 d=2 SE kernel",
             "value": fits_per_s * world,
@@ -230,7 +234,14 @@ def main():
                          "achieved_vs_unfused_survey_figure": unfused_bytes / spread_avg_s / 1e9 if spread_n else None},
             "interp": {"avg_launch_us": 1e3 * interp_ms / max(interp_n, 1),
                        "achieved_GBs": interp_bytes / (1e-3 * interp_ms / max(interp_n, 1)) / 1e9 if interp_n else None},
-            "cg_iteration_group_us": 1e3 * cgit_ms / max(cgit_n, 1),
+            # the mean solve is ONE persistent launch (one CU): largest share of the step, latency/VALU bound by design,
+            # priced here against the survey's per-iteration bytes 16*(F_tot + 8M) x the iterations of the launch
+            "cg_solve": {"kernel": "cg_persistent_2d64_kernel (whole mean solve, one launch)",
+                         "avg_launch_us": 1e3 * cgs_ms / max(cgs_n, 1), "iterations": mean_iters,
+                         "bytes_per_launch": cg_bytes,
+                         "achieved_GBs": cg_bytes / (1e-3 * cgs_ms / max(cgs_n, 1)) / 1e9 if cgs_n else None,
+                         "frac_hbm": cg_bytes / (1e-3 * cgs_ms / max(cgs_n, 1)) / 1e9 / HBM_PEAK_GBS if cgs_n else None,
+                         "share_of_step": (cgs_ms / max(cgs_n, 1)) / ms_per_step if cgs_n else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(1000)

@@ -1038,9 +1038,11 @@ int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, con
             }
             attr64 = true;
         }
+        KernelTimer timer("cg_solve", stream);
         hipLaunchKernelGGL(cg_persistent_2d64_kernel, dim3(rows), dim3(kThreads), (size_t)2 * s64::BUF * sizeof(double2),
                            stream, a);
     } else {
+        KernelTimer timer("cg_solve", stream);
         hipLaunchKernelGGL(cg_persistent_kernel, dim3(rows), dim3(kThreads), lds, stream, a);
     }
     hipError_t e = hipGetLastError();

@@ -13,12 +13,15 @@ double es_window(double z, double beta) {
     return std::exp(beta * (std::sqrt(q) - 1.0));
 }
 
+static const double kSigmaCalibrated = 3.0;   // upper end of the upsampling ratios the width formula was fitted on
+
 int es_width_for_tol(double tol, double sigma) {
     // Measured l2 error of this window is ~5 exp(-pi w sqrt(1-1/sigma)) (calibrated against the
     // exact transform for sigma in [1.25, 3]); invert it for w.
     if (!(tol > 0.0)) tol = 1e-16;
     if (tol < 1e-16) tol = 1e-16;
     if (sigma < 1.1) sigma = 1.1;
+    if (sigma > kSigmaCalibrated) sigma = kSigmaCalibrated;
     double rate = M_PI * std::sqrt(1.0 - 1.0 / sigma);
     int w = (int)std::ceil((std::log(1.0 / tol) + 1.5) / rate);
     return std::min(kMaxWidth, std::max(2, w));
@@ -84,6 +87,10 @@ double fit_error(const EsParams& p) {
 int es_make_params(double tol, double sigma, EsParams* p) {
     if (!p) return -1;
     std::memset(p, 0, sizeof(*p));
+    // Tiny mode boxes sit on the 32-cell minimum grid (sigma up to ~10), outside the range the error model was
+    // calibrated on: design the window as for sigma = 3 (a finer grid than assumed only moves the aliases further
+    // out).  Found by tools/fuzz_nufft.py: 3-D, 4 modes per axis, tol 1e-7 gave 1.2e-6 with the sigma = 8 window.
+    if (sigma > kSigmaCalibrated) sigma = kSigmaCalibrated;
     p->w = es_width_for_tol(tol, sigma);
     p->beta = 0.976 * M_PI * p->w * (1.0 - 1.0 / (2.0 * sigma));
     const int stride = kMaxDegree + 1;
