@@ -793,6 +793,88 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
     if (tid == 0) a.iters[row] = it;
 }
 
+// Spectrum of the Toeplitz vector for the 64 x 64 circulant grid in ONE launch (efgpnd.py:1283-1290: pad to the FFT
+// box, forward fftn): `factor * v` zero-padded into LDS, four radix-8 Stockham stages as in the solver above, result
+// in natural order.  Replaces pad_scale_kernel + two rocFFT launches (~14 us of dependent 4-5 us launches per fit).
+__global__ __launch_bounds__(kThreads) void toeplitz_vhat_2d64_kernel(const double2* __restrict__ v, int L0, int L1,
+                                                                      double factor, double2* __restrict__ vhat) {
+    using namespace s64;
+    extern __shared__ double2 lds2[];
+    double2* const bufA = lds2;
+    double2* const bufB = lds2 + BUF;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < F * F; t += kThreads) {
+        const int i0 = t >> 6, i1 = t & 63;
+        double2 x = make_double2(0.0, 0.0);
+        if (i0 < L0 && i1 < L1) {
+            x = v[i0 * L1 + i1];
+            x.x *= factor;
+            x.y *= factor;
+        }
+        bufA[i0 * LD + i1] = x;
+    }
+    const int c = tid & 63, j = tid >> 6;      // line (row, then column) and butterfly within the line
+    double2 tw[7];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) {
+        double sn, cs;
+        sincospi(-(double)(j * t) / 32.0, &sn, &cs);      // exp(-2 pi i j t / 64)
+        tw[t - 1] = make_double2(cs, sn);
+    }
+    __syncthreads();
+    double2 x[8];
+    // dimension 1 (contiguous), all 64 rows: lane = row
+    load8_all<8>(bufA + c * LD + j, x);
+    dft_fwd<8>(x);
+    store8_all<1>(bufB + c * LD + j * 8, x);
+    __syncthreads();
+    load8_all<8>(bufB + c * LD + j, x);
+    twiddle8(x, tw);
+    dft_fwd<8>(x);
+    store8_all<8>(bufA + c * LD + j, x);
+    __syncthreads();
+    // dimension 0: lane = column
+    load8_all<8 * LD>(bufA + j * LD + c, x);
+    dft_fwd<8>(x);
+    store8_all<LD>(bufB + j * 8 * LD + c, x);
+    __syncthreads();
+    load8_all<8 * LD>(bufB + j * LD + c, x);
+    twiddle8(x, tw);
+    dft_fwd<8>(x);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) vhat[(j + 8 * t) * F + c] = x[t];
+}
+
+}  // namespace pcg
+
+bool toeplitz_vhat_fused_eligible(const ToepGeom& g) {
+    return g.d == 2 && g.F[0] == 64 && g.F[1] == 64 && std::getenv("EFGP_NO_VHAT64") == nullptr;
+}
+
+int toeplitz_vhat_fused_launch(const double2* v, int L0, int L1, double factor, double2* vhat, hipStream_t stream) {
+    using namespace pcg;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)toeplitz_vhat_2d64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 256);
+        if (e != hipSuccess) {
+            set_error("Toeplitz spectrum (64x64): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return EFGP_EHIP;
+        }
+        attr = true;
+    }
+    hipLaunchKernelGGL(toeplitz_vhat_2d64_kernel, dim3(1), dim3(kThreads), (size_t)2 * s64::BUF * sizeof(double2), stream,
+                       v, L0, L1, factor, vhat);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("Toeplitz spectrum (64x64) launch failed: %s", hipGetErrorString(e));
+        return EFGP_EHIP;
+    }
+    return EFGP_OK;
+}
+
+namespace pcg {
+
 #ifdef EFGP_CG_STAMPS
 static long long* g_last_stamps = nullptr;
 #endif

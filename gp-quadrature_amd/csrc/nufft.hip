@@ -611,18 +611,21 @@ __global__ void fixed_scale_kernel(unsigned long long* __restrict__ cmax_bits, d
 // FIXED: slabs hold int64 fixed-point sums (exact, order independent), rescaled by inv_scale.
 // Block = 64 cells x 8 slab groups; every slab row segment read is 512 contiguous bytes.
 template <bool FIXED>
-__global__ __launch_bounds__(512) void reduce_slabs_kernel(const double* __restrict__ slabs, int nslab, int channels,
-                                                           int64_t cells, const double* __restrict__ scale,
-                                                           double2* __restrict__ fine) {
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const double* __restrict__ slabs, int nslab, int channels,
+                                                            int64_t cells, const double* __restrict__ scale,
+                                                            double2* __restrict__ fine) {
+    // 8 (512 threads) or 16 (1024 threads) slab groups per 64 cells: the many-slab integer reduction is a chain of
+    // dependent-latency loads, so it takes the wider block (12.9 -> see DESIGN us for 245 slabs of 96 x 96 x 2)
     __shared__ double part[2][8][64];
     const int batch = blockIdx.y;
-    const int lane_cell = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int lane_cell = threadIdx.x & 63, grp = threadIdx.x >> 6, ngrp = blockDim.x >> 6;
     const int64_t cell = (int64_t)blockIdx.x * 64 + lane_cell;
     const double* base = slabs + (int64_t)batch * nslab * channels * cells;
     double re = 0.0, im = 0.0;
     long long ire = 0, iim = 0;
     if (cell < cells) {
-        for (int s = grp; s < nslab; s += 8) {
+#pragma unroll 4
+        for (int s = grp; s < nslab; s += ngrp) {
             const double* p = base + (int64_t)s * channels * cells;
             if (FIXED) {
                 ire += reinterpret_cast<const long long*>(p)[cell];
@@ -635,13 +638,13 @@ __global__ __launch_bounds__(512) void reduce_slabs_kernel(const double* __restr
     }
     if (FIXED) {
         // exact integer partial sums; combine groups in integer too
-        __shared__ long long ipart[2][8][64];
+        __shared__ long long ipart[2][16][64];
         ipart[0][grp][lane_cell] = ire;
         ipart[1][grp][lane_cell] = iim;
         __syncthreads();
         if (grp == 0 && cell < cells) {
             long long a = 0, b = 0;
-            for (int g = 0; g < 8; ++g) {
+            for (int g = 0; g < ngrp; ++g) {
                 a += ipart[0][g][lane_cell];
                 b += ipart[1][g][lane_cell];
             }
@@ -2448,8 +2451,8 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     {
         const int blocks = (int)((g.cells + 63) / 64);
         if (use_lds && plan->npts > 0)
-            hipLaunchKernelGGL((reduce_slabs_kernel<true>), dim3(blocks, nbatch), dim3(512), 0, stream, slabs, nslab,
-                               channels, g.cells, (const double*)d_scale, fine);
+            hipLaunchKernelGGL((reduce_slabs_kernel<true>), dim3(blocks, nbatch), dim3(nslab >= 64 ? 1024 : 512), 0, stream,
+                               slabs, nslab, channels, g.cells, (const double*)d_scale, fine);
         else
             hipLaunchKernelGGL((reduce_slabs_kernel<false>), dim3(blocks, nbatch), dim3(512), 0, stream, slabs, nslab,
                                channels, g.cells, (const double*)d_scale, fine);

@@ -903,21 +903,28 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
         gv.n[a] = op->Ls[a];
         gv.M *= gv.n[a];
     }
-    hipLaunchKernelGGL(pad_scale_kernel, grid_for(op->g.Ftot, 1, kVecThreads), dim3(kVecThreads), 0, stream, gv,
-                       (const double2*)v, gv.M, (const double2*)nullptr, (const int*)nullptr, (const int*)nullptr,
-                       op->vhat, 1.0 / (double)op->g.Ftot);   // the inverse transform's 1/Ftot, folded in before the FFT
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        pool_free(ctx, op->vhat, (size_t)op->g.Ftot * sizeof(double2));
-        delete op;
-        set_error("efgp_toeplitz_create: pad launch failed: %s", hipGetErrorString(e));
-        return EFGP_EHIP;
-    }
-    hipfftHandle fh;
-    int rc = fft_plan(ctx, dim, op->g.F, 1, stream, &fh);
-    if (rc == EFGP_OK && hipfftExecZ2Z(fh, (hipfftDoubleComplex*)op->vhat, (hipfftDoubleComplex*)op->vhat, HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
-        set_error("efgp_toeplitz_create: FFT of the Toeplitz vector failed");
-        rc = EFGP_EHIP;
+    int rc = EFGP_OK;
+    if (toeplitz_vhat_fused_eligible(op->g)) {
+        rc = toeplitz_vhat_fused_launch((const double2*)v, (int)op->Ls[0], (int)op->Ls[1], 1.0 / (double)op->g.Ftot, op->vhat,
+                                        stream);
+    } else {
+        hipLaunchKernelGGL(pad_scale_kernel, grid_for(op->g.Ftot, 1, kVecThreads), dim3(kVecThreads), 0, stream, gv,
+                           (const double2*)v, gv.M, (const double2*)nullptr, (const int*)nullptr, (const int*)nullptr,
+                           op->vhat, 1.0 / (double)op->g.Ftot);   // the inverse transform's 1/Ftot, folded in before the FFT
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            pool_free(ctx, op->vhat, (size_t)op->g.Ftot * sizeof(double2));
+            delete op;
+            set_error("efgp_toeplitz_create: pad launch failed: %s", hipGetErrorString(e));
+            return EFGP_EHIP;
+        }
+        hipfftHandle fh;
+        rc = fft_plan(ctx, dim, op->g.F, 1, stream, &fh);
+        if (rc == EFGP_OK &&
+            hipfftExecZ2Z(fh, (hipfftDoubleComplex*)op->vhat, (hipfftDoubleComplex*)op->vhat, HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
+            set_error("efgp_toeplitz_create: FFT of the Toeplitz vector failed");
+            rc = EFGP_EHIP;
+        }
     }
     if (rc != EFGP_OK) {
         pool_free(ctx, op->vhat, (size_t)op->g.Ftot * sizeof(double2));

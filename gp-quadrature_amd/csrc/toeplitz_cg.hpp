@@ -21,4 +21,8 @@ int persistent_cg_launch(const ToepGeom& g, const double2* const* twiddles, cons
                          int max_iter, const double2* b, double2* x, int rows, int* d_iters, hipStream_t stream,
                          const double* diag_scale = nullptr, int b_times_ws = 0, int zero_x0 = 0);
 
+// spectrum of the Toeplitz vector on the 64 x 64 circulant grid in one launch (cg_persistent.hip)
+bool toeplitz_vhat_fused_eligible(const ToepGeom& g);
+int toeplitz_vhat_fused_launch(const double2* v, int L0, int L1, double factor, double2* vhat, hipStream_t stream);
+
 }  // namespace efgp
