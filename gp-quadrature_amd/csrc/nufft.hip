@@ -537,29 +537,6 @@ __global__ void rademacher_fill_kernel(unsigned long long seed, int64_t npts, in
         out[(int64_t)row * npts + n] = efgp_rademacher(seed, row, n + index_offset);
 }
 
-// max |c| over n doubles as an ordered bit pattern (non-negative doubles compare like integers).
-// One atomic per workgroup (block-level reduction first): thousands of same-address atomics serialise.
-__global__ __launch_bounds__(1024) void maxabs_kernel(const double* __restrict__ c, int64_t n,
-                                                       unsigned long long* __restrict__ out) {
-    __shared__ double part[16];
-    double m = 0.0;
-    const int64_t n2 = n >> 1;
-    const double2* c2 = reinterpret_cast<const double2*>(c);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
-        const double2 v = c2[i];
-        m = fmax(m, fmax(fabs(v.x), fabs(v.y)));
-    }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) m = fmax(m, fabs(c[n - 1]));
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t = fmax(t, part[i]);
-        if (t > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(t));
-    }
-}
-
 // Fixed-point scales, one per channel: scale[0] = S0 (channel 0), [1] = 1/S0, [2] = S1 (channel 1), [3] = 1/S1,
 // [4] = the factor the channel-0 result still has to be multiplied by (1 unless the channel is carried normalised).
 //   S = largest power of two with  max|c| * S <= 2^min(50,sum_bits)  and  points_per_wg * max|c| * S <= 2^sum_bits.
@@ -575,11 +552,15 @@ __device__ __forceinline__ double fixed_scale_for(double cmax, int64_t per, int 
     frexp(lim / cmax, &e);                  // lim/cmax = f * 2^e, f in [0.5, 1)
     return ldexp(1.0, e - 1);               // largest power of two <= lim/cmax
 }
-__global__ void fixed_scale_kernel(unsigned long long* __restrict__ cmax_bits, double floor_bound, int ones_channel,
-                                   int64_t per, double* __restrict__ scale, int sum_bits) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double cmax = cmax_bits ? __longlong_as_double((long long)*cmax_bits) : 0.0;
-    if (cmax_bits) *cmax_bits = 0ull;
+struct ScaleJob {            // what fixed_scale_write needs besides max|c|
+    double floor_bound;
+    int ones_channel;
+    int64_t per;
+    double* scale;
+    int sum_bits;
+};
+__device__ __forceinline__ void fixed_scale_write(double cmax, double floor_bound, int ones_channel, int64_t per,
+                                                  double* __restrict__ scale, int sum_bits) {
     if (!ones_channel) {
         const double S0 = fixed_scale_for(fmax(cmax, floor_bound), per, sum_bits);
         scale[0] = S0;
@@ -605,6 +586,45 @@ __global__ void fixed_scale_kernel(unsigned long long* __restrict__ cmax_bits, d
     scale[2] = Sn;
     scale[3] = 1.0 / Sn;
     scale[4] = norm0;
+}
+// stand-alone form for strengths that need no max|c| pass (implicit ones, generated +-1 probes)
+__global__ void fixed_scale_kernel(double floor_bound, int ones_channel, int64_t per, double* __restrict__ scale,
+                                   int sum_bits) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    fixed_scale_write(0.0, floor_bound, ones_channel, per, scale, sum_bits);
+}
+
+// max |c| over n doubles as an ordered bit pattern (non-negative doubles compare like integers).
+// One atomic per workgroup (block-level reduction first): thousands of same-address atomics serialise.
+// The last workgroup to arrive (device-scope ticket) consumes the maximum, resets the accumulator and the ticket
+// and writes the fixed-point scales: one launch instead of two dependent ones (~4.5 us each on this machine).
+__global__ __launch_bounds__(1024) void maxabs_kernel(const double* __restrict__ c, int64_t n,
+                                                       unsigned long long* __restrict__ out,
+                                                       unsigned int* __restrict__ ticket, ScaleJob job) {
+    __shared__ double part[16];
+    double m = 0.0;
+    const int64_t n2 = n >> 1;
+    const double2* c2 = reinterpret_cast<const double2*>(c);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+        const double2 v = c2[i];
+        m = fmax(m, fmax(fabs(v.x), fabs(v.y)));
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) m = fmax(m, fabs(c[n - 1]));
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t = fmax(t, part[i]);
+        if (t > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(t));
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            __threadfence();
+            const double cmax = __longlong_as_double((long long)atomicExch(out, 0ull));
+            *ticket = 0u;
+            fixed_scale_write(cmax, job.floor_bound, job.ones_channel, job.per, job.scale, job.sum_bits);
+        }
+    }
 }
 
 // sum the slabs of one batch row into the complex fine grid: fine = ch0 + i*ch1 (ch1 = 0 if absent).
@@ -2189,8 +2209,8 @@ static hipError_t launch_cell(int W, int channels, int degree, dim3 grid, hipStr
     return hipErrorInvalidValue;
 }
 
-// 64-byte block of doubles: [0..3] S0, 1/S0, S1, 1/S1, [4] channel-0 norm, [7] max|c| bit pattern.  Zeroed when first allocated; afterwards
-// fixed_scale_kernel leaves the accumulator at zero.
+// 64-byte block of doubles: [0..3] S0, 1/S0, S1, 1/S1, [4] channel-0 norm, [6] arrival ticket of maxabs_kernel, [7] max|c| bit pattern.
+// Zeroed when first allocated; afterwards maxabs_kernel's last workgroup leaves ticket and accumulator at zero.
 static char* scale_slot(DeviceCtx* ctx, hipStream_t stream) {
     char* misc = (char*)scratch(ctx, SLOT_SCALE, 64);
     if (misc && !ctx->scale_slot_ready) {
@@ -2297,15 +2317,16 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         unsigned long long* d_cmax = (unsigned long long*)(misc + 56);
         if (scale_out) *scale_out = d_scale;
         EFGP_HIP_CHECK(hipMemsetAsync(gacc, 0, acc_bytes, stream));
+        // the global int64 grid sums over ALL points: bound the scale with N instead of points per workgroup
+        const ScaleJob job{floor_bound, mode == STR_REAL_AND_ONES ? 1 : 0, plan->npts, d_scale, 61};
         if (need_max) {
             const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nvals + 8191) / 8192, 256));
-            hipLaunchKernelGGL(maxabs_kernel, dim3(blocks), dim3(1024), 0, stream, c, nvals, d_cmax);
-            EFGP_HIP_CHECK(hipGetLastError());
+            hipLaunchKernelGGL(maxabs_kernel, dim3(blocks), dim3(1024), 0, stream, c, nvals, d_cmax,
+                               (unsigned int*)(misc + 48), job);
+        } else {
+            hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream, job.floor_bound, job.ones_channel, job.per,
+                               job.scale, job.sum_bits);
         }
-        // the global int64 grid sums over ALL points: bound the scale with N instead of points per workgroup
-        hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream,
-                           need_max ? d_cmax : (unsigned long long*)nullptr,
-                           floor_bound, mode == STR_REAL_AND_ONES ? 1 : 0, plan->npts, d_scale, 61);
         EFGP_HIP_CHECK(hipGetLastError());
         TileSpreadArgs ta;
         ta.t = tg;
@@ -2379,14 +2400,15 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     if (use_lds) {
         if (scale_out) *scale_out = d_scale;
         // fixed-point scale from max |c| (device side, no host round trip)
+        const ScaleJob job{floor_bound, mode == STR_REAL_AND_ONES ? 1 : 0, per, d_scale, raw48 ? 46 : 61};
         if (need_max) {
             const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nvals + 8191) / 8192, 256));
-            hipLaunchKernelGGL(maxabs_kernel, dim3(blocks), dim3(1024), 0, stream, c, nvals, d_cmax);
-            EFGP_HIP_CHECK(hipGetLastError());
+            hipLaunchKernelGGL(maxabs_kernel, dim3(blocks), dim3(1024), 0, stream, c, nvals, d_cmax,
+                               (unsigned int*)(misc + 48), job);
+        } else {
+            hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream, job.floor_bound, job.ones_channel, job.per,
+                               job.scale, job.sum_bits);
         }
-        hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream,
-                           need_max ? d_cmax : (unsigned long long*)nullptr,
-                           floor_bound, mode == STR_REAL_AND_ONES ? 1 : 0, per, d_scale, raw48 ? 46 : 61);
         EFGP_HIP_CHECK(hipGetLastError());
     }
 
