@@ -2,6 +2,9 @@
 // and the host-only window entry points of the C ABI.
 #include "common.hpp"
 
+#include <chrono>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -195,6 +198,19 @@ static std::vector<TimingRec> g_recs;
 constexpr size_t kMaxTimingRecs = 1 << 16;
 
 bool timing_enabled() { return g_timing; }
+
+hipError_t stream_wait(hipStream_t stream) {
+    if (std::getenv("EFGP_BLOCKING_WAIT") == nullptr) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t e = hipStreamQuery(stream);
+            if (e != hipErrorNotReady) return e;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+        }
+        (void)hipGetLastError();     // hipErrorNotReady is not an error of ours
+    }
+    return hipStreamSynchronize(stream);
+}
 
 KernelTimer::KernelTimer(const char* name, hipStream_t s) : stream(s) {
     if (!g_timing || g_recs.size() >= kMaxTimingRecs) return;

@@ -100,6 +100,13 @@ void* pool_alloc(DeviceCtx* ctx, size_t bytes);
 void pool_free(DeviceCtx* ctx, void* p, size_t bytes);
 void release_ctx(int device);
 
+// Wait for `stream` by polling hipStreamQuery (for up to 50 ms, then hipStreamSynchronize).  The blocking wait of the
+// runtime sleeps on an interrupt once its short spin is over; on this platform that wake-up is missed every few calls and
+// the host then sleeps until a 100-ms tick (rocprofv3 trace: the GPU idle for 87-92 ms at instants exactly 100 ms apart,
+// inside the per-burst poll of the multi-kernel CG: a 2.3-ms fit took 93 ms on every third step).  Our waits are short
+// (a burst of CG iterations, a read-back of a few scalars), so polling is the cheaper and the reliable way.
+hipError_t stream_wait(hipStream_t stream);
+
 // Optional HIP-event timing of selected kernels (see efgp_kernel_timing in the C ABI).
 bool timing_enabled();
 struct KernelTimer {     // RAII: records start at construction, stop at destruction, on `stream`

@@ -11,7 +11,9 @@
 // The whole iteration state lives on the device; the host only launches kernels and polls a status
 // word every few iterations.  Per iteration and row: one pad+scale kernel, two batched FFTs, one
 // spectral multiply, one fused update kernel (crop, A p, <p,Ap>, x/r update, norms, p update).
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -22,6 +24,22 @@
 #include "toeplitz_cg.hpp"
 
 namespace efgp {
+
+// EFGP_CG_TRACE=1: report host-side spans of the multi-kernel solve that take longer than 2 ms (stderr)
+struct TraceSpan {
+    const char* what;
+    std::chrono::steady_clock::time_point t0;
+    bool on;
+    explicit TraceSpan(const char* w) : what(w), on(std::getenv("EFGP_CG_TRACE") != nullptr) {
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    ~TraceSpan() {
+        if (!on) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > 2.0) std::fprintf(stderr, "[efgp cg trace] %s: %.1f ms\n", what, ms);
+    }
+};
+
 
 constexpr int kVecThreads = 256;
 constexpr int kCgThreads = 512;
@@ -1043,7 +1061,7 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         }
         if (rc != EFGP_OK) return rc;
         EFGP_HIP_CHECK(hipMemcpyAsync(host, d_iters, (size_t)nbatch * sizeof(int), hipMemcpyDeviceToHost, stream));
-        EFGP_HIP_CHECK(hipStreamSynchronize(stream));
+        EFGP_HIP_CHECK(stream_wait(stream));
         int mx = 0;
         for (int i = 0; i < nbatch; ++i) {
             mx = std::max(mx, host[i]);
@@ -1238,6 +1256,7 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
                     graph_exec = nullptr;
                 }
                 if (!graph_exec) {
+                    TraceSpan span_build("graph build (plan + capture + instantiate)");
                     hipGraph_t graph = nullptr;
                     // make sure the FFT plan exists and is bound to the stream before capturing
                     hipfftHandle fh_unused;
@@ -1262,6 +1281,7 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
                     }
                 }
                 if (graph_exec) {
+                    TraceSpan span_launch("hipGraphLaunch");
                     EFGP_HIP_CHECK(hipGraphLaunch(graph_exec, stream));
                     launched = true;
                 }
@@ -1274,8 +1294,14 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
                 }
             }
             it += burst;
-            EFGP_HIP_CHECK(hipMemcpyAsync(hsc.data(), a.sc, (size_t)rows * sizeof(CgRowScalars), hipMemcpyDeviceToHost, stream));
-            EFGP_HIP_CHECK(hipStreamSynchronize(stream));
+            {
+                TraceSpan span_poll("poll (D2H scalars + stream synchronize)");
+                // into the context's PINNED buffer: a pageable destination makes the runtime pin / stage it per call,
+                // which stalled for 50-90 ms every few solves (EFGP_CG_TRACE; 3-D 64^3 fit 10 -> 80 ms on those steps)
+                EFGP_HIP_CHECK(hipMemcpyAsync(host, a.sc, (size_t)rows * sizeof(CgRowScalars), hipMemcpyDeviceToHost, stream));
+                EFGP_HIP_CHECK(stream_wait(stream));
+                std::memcpy(hsc.data(), host, (size_t)rows * sizeof(CgRowScalars));
+            }
             int new_active = 0;
             for (int i = 0; i < rows; ++i) {
                 if (hsc[i].active) active_rows[new_active++] = i;
@@ -1290,20 +1316,23 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
                     for (int i = 0; i < new_active; ++i) map[i] = active_rows[i];
                     std::memcpy(host, map.data(), nslots * sizeof(int));
                     EFGP_HIP_CHECK(hipMemcpyAsync(d_rows, host, nslots * sizeof(int), hipMemcpyHostToDevice, stream));
-                    EFGP_HIP_CHECK(hipStreamSynchronize(stream));
+                    EFGP_HIP_CHECK(stream_wait(stream));
                     a.rows = d_rows;
                     compacted = true;
                 }
             }
             n_active = new_active;
         }
-        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (graph_exec) {
+            TraceSpan span_destroy("hipGraphExecDestroy");
+            (void)hipGraphExecDestroy(graph_exec);
+        }
         // iteration counts (cg.py:152 single; cg.py:193-199,243 batched: +1 for the terminating pass)
         int group_iters;
         if (!batched_semantics) {
             group_iters = hsc.empty() ? 0 : hsc[0].iters;
             if (it == 0) {   // max_iter == 0 or nothing ran
-                EFGP_HIP_CHECK(hipStreamSynchronize(stream));
+                EFGP_HIP_CHECK(stream_wait(stream));
             }
         } else {
             group_iters = last_active_it;
@@ -1381,7 +1410,7 @@ int efgp_vdot_real(int device, const void* a, int a_is_complex, const void* b, i
         hipLaunchKernelGGL((vdot_real_kernel<false, false>), dim3(blocks), dim3(kVecThreads), 0, stream, pa, pb, count, partial);
     EFGP_HIP_CHECK(hipGetLastError());
     EFGP_HIP_CHECK(hipMemcpyAsync(host, partial, (size_t)blocks * sizeof(double), hipMemcpyDeviceToHost, stream));
-    EFGP_HIP_CHECK(hipStreamSynchronize(stream));
+    EFGP_HIP_CHECK(stream_wait(stream));
     double acc = 0.0;
     for (int i = 0; i < blocks; ++i) acc += host[i];
     *out_host = acc;

@@ -17,6 +17,7 @@ solve (D T D + sigma^2 I) beta = D F* y  (D = diag ws) by Jacobi-preconditioned 
 from __future__ import annotations
 
 import math
+import os
 import time
 from math import prod
 from typing import Dict, Optional, Tuple, Union
@@ -247,12 +248,44 @@ def create_jacobi_precond(ws, sigmasq_scalar, diag_scale=1.0):
 # ======================================================================================
 # shared pieces of fit / gradient
 # ======================================================================================
+class _PinnedStage:
+    """Two reusable pinned staging buffers per device (grown on demand), each guarded by the event of its last copy."""
+
+    def __init__(self):
+        self.bufs = [None, None]
+        self.events = [None, None]
+        self.turn = 0
+
+    def upload(self, t: torch.Tensor, dev: torch.device) -> torch.Tensor:
+        src = t.contiguous()
+        raw = src.reshape(-1).view(torch.uint8)
+        nbytes = raw.numel()
+        k = self.turn
+        self.turn ^= 1
+        if self.events[k] is not None:
+            self.events[k].synchronize()          # the copy issued two uploads ago: long finished in steady state
+        if self.bufs[k] is None or self.bufs[k].numel() < nbytes:
+            self.bufs[k] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8).pin_memory()
+        self.bufs[k][:nbytes].copy_(raw)
+        out = torch.empty(src.shape, dtype=src.dtype, device=dev)
+        out.reshape(-1).view(torch.uint8).copy_(self.bufs[k][:nbytes], non_blocking=True)
+        if self.events[k] is None:
+            self.events[k] = torch.cuda.Event()
+        self.events[k].record(torch.cuda.current_stream(dev))
+        return out
+
+
+_STAGES: Dict[int, _PinnedStage] = {}
+
+
 def _upload(t: torch.Tensor, dev: torch.device) -> torch.Tensor:
     """Host -> device copy that does not stall the host: a pageable-memory copy makes the host wait until the stream
     has drained (measured: the weights' upload at the top of every fit exposed ~50 us of launch gaps per step at
-    N = 1e6); staged through torch's cached pinned pool the copy is just another stream-ordered operation."""
-    if t.device.type == "cpu" and dev.type == "cuda":
-        return t.pin_memory().to(dev, non_blocking=True)
+    N = 1e6).  Staged through a persistent pinned buffer the copy is just another stream-ordered operation
+    (`Tensor.pin_memory()` per call is no alternative: 14 ms per call measured for a 292-KB grid)."""
+    if t.device.type == "cpu" and dev.type == "cuda" and t.numel() > 0 and not os.environ.get("EFGP_NO_PINNED_UPLOAD"):
+        with torch.cuda.device(dev):
+            return _STAGES.setdefault(dev.index or 0, _PinnedStage()).upload(t, dev)
     return t.to(dev)
 
 
@@ -275,12 +308,19 @@ class _Grid:
         # The same host pathology hits torch.pow with a real exponent even on a few hundred elements (12 ms per call
         # measured on the 256-thread host): Matern densities always go to the device.
         host_ok = self.M * d <= 16384 and type(kernel).__name__ != "Matern"
-        where = self.xis if host_ok else _upload(self.xis, dev)
+        # Non-blocking uploads only where the whole solve is one launch (circulant grid small enough for the persistent
+        # kernel: F^d <= 4096 with F = next_pow2(2 mtot - 1)).  The multi-kernel solves poll the device per burst, and with
+        # the host running ahead those waits hit this platform's missed wake-ups: there the pageable
+        # copy's implicit synchronisation at the top of the fit is kept.
+        F = 1 << (2 * self.mtot - 2).bit_length()
+        async_ok = F ** d <= 4096
+        up = _upload if async_ok else (lambda t, dv: t.to(dv))
+        where = self.xis if host_ok else up(self.xis, dev)
         S = kernel.spectral_density(where).to(torch.float64)
-        self.ws = _upload(torch.sqrt(S.to(torch.complex128) * self.h ** d), dev)  # (M,) complex, imag 0
+        self.ws = up(torch.sqrt(S.to(torch.complex128) * self.h ** d), dev)       # (M,) complex, imag 0
         self.dprime = None
         if want_grad:
-            self.dprime = _upload((self.h ** d * kernel.spectral_grad(where)).to(torch.complex128), dev)   # (M,H)
+            self.dprime = up((self.h ** d * kernel.spectral_grad(where)).to(torch.complex128), dev)   # (M,H)
 
 
 def _domain_length(xd: torch.Tensor, shards: PointShards) -> float:
