@@ -177,3 +177,18 @@ def test_generic_cg_matches_oracle():
     assert cgb.iters_completed == itob and torch.allclose(xb, xob, rtol=1e-12, atol=1e-14)
     with pytest.raises(ValueError):
         ConjugateGradients(3.0, b, b)
+
+
+def test_cpu_quota_parsing(tmp_path):
+    """efgp_hip.cpu_quota reads the CFS bandwidth limit (cgroup v2 cpu.max, v1 cfs files); 'max' / absent = unlimited."""
+    from efgp_hip import cpu_quota
+    assert cpu_quota.cpu_quota_cores(str(tmp_path)) is None
+    (tmp_path / "cpu.max").write_text("1600000 100000\n")
+    assert cpu_quota.cpu_quota_cores(str(tmp_path)) == 16.0
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert cpu_quota.cpu_quota_cores(str(tmp_path)) is None
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("250000\n")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert cpu_quota.cpu_quota_cores(str(v1)) == 2.5
