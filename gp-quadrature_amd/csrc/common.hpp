@@ -100,11 +100,10 @@ void* pool_alloc(DeviceCtx* ctx, size_t bytes);
 void pool_free(DeviceCtx* ctx, void* p, size_t bytes);
 void release_ctx(int device);
 
-// Wait for `stream` by polling hipStreamQuery (for up to 50 ms, then hipStreamSynchronize).  The blocking wait of the
-// runtime sleeps on an interrupt once its short spin is over; on this platform that wake-up is missed every few calls and
-// the host then sleeps until a 100-ms tick (rocprofv3 trace: the GPU idle for 87-92 ms at instants exactly 100 ms apart,
-// inside the per-burst poll of the multi-kernel CG: a 2.3-ms fit took 93 ms on every third step).  Our waits are short
-// (a burst of CG iterations, a read-back of a few scalars), so polling is the cheaper and the reliable way.
+// Wait for `stream` by polling hipStreamQuery (for up to 50 ms, then hipStreamSynchronize; EFGP_BLOCKING_WAIT=1 goes
+// straight to the latter).  Our waits are short -- a burst of CG iterations, a read-back of a few scalars -- so the
+// polling thread never reaches the runtime's interrupt sleep.  (The 90-ms stalls once seen inside these waits were CFS
+// CPU-quota throttling of the whole process by torch's oversized OpenMP pool: efgp_hip/cpu_quota.py.)
 hipError_t stream_wait(hipStream_t stream);
 
 // Optional HIP-event timing of selected kernels (see efgp_kernel_timing in the C ABI).

@@ -1296,8 +1296,7 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
             it += burst;
             {
                 TraceSpan span_poll("poll (D2H scalars + stream synchronize)");
-                // into the context's PINNED buffer: a pageable destination makes the runtime pin / stage it per call,
-                // which stalled for 50-90 ms every few solves (EFGP_CG_TRACE; 3-D 64^3 fit 10 -> 80 ms on those steps)
+                // into the context's PINNED buffer (a pageable destination is staged by the runtime on every call)
                 EFGP_HIP_CHECK(hipMemcpyAsync(host, a.sc, (size_t)rows * sizeof(CgRowScalars), hipMemcpyDeviceToHost, stream));
                 EFGP_HIP_CHECK(stream_wait(stream));
                 std::memcpy(hsc.data(), host, (size_t)rows * sizeof(CgRowScalars));

@@ -308,10 +308,10 @@ class _Grid:
         # The same host pathology hits torch.pow with a real exponent even on a few hundred elements (12 ms per call
         # measured on the 256-thread host): Matern densities always go to the device.
         host_ok = self.M * d <= 16384 and type(kernel).__name__ != "Matern"
-        # Non-blocking uploads only where the whole solve is one launch (circulant grid small enough for the persistent
-        # kernel: F^d <= 4096 with F = next_pow2(2 mtot - 1)).  The multi-kernel solves poll the device per burst, and with
-        # the host running ahead those waits hit this platform's missed wake-ups: there the pageable
-        # copy's implicit synchronisation at the top of the fit is kept.
+        # Non-blocking uploads where the whole solve is one launch (circulant grid small enough for the persistent kernel:
+        # F^d <= 4096 with F = next_pow2(2 mtot - 1)) -- that is where the host running ahead pays (launch gaps of the
+        # N = 1e6 step).  The multi-kernel solves synchronise with the device per burst anyway and keep the plain copy
+        # (measured together with the CPU-quota stalls of efgp_hip/cpu_quota.py, not re-measured since: conservative).
         F = 1 << (2 * self.mtot - 2).bit_length()
         async_ok = F ** d <= 4096
         up = _upload if async_ok else (lambda t, dv: t.to(dv))
