@@ -219,3 +219,26 @@ def test_line_fft_iteration_3d(mtot, monkeypatch):
         T = O.Toeplitz(v)
         xo, ito = O.cg_batched(O.make_A_mean(ws, T, sig2), b, torch.zeros_like(b), 1e-9, diag=diag)
         assert abs(res["lines"][1] - ito) <= 1 and _rel(res["lines"][0], xo) < 1e-7
+
+
+@pytest.mark.parametrize("mtot", [17, 23, 29, 32])
+def test_one_launch_toeplitz_spectrum_matches_rocfft_path(mtot, monkeypatch):
+    """64 x 64 circulant grids: the single-launch LDS transform of the Toeplitz vector (toeplitz_vhat_2d64_kernel) and
+    the pad + rocFFT route (EFGP_NO_VHAT64) give the same operator, and both match the oracle (efgpnd.py:1283-1290)."""
+    from efgp_hip import ToeplitzOp
+    from oracle import efgp_oracle as O
+    g = torch.Generator().manual_seed(3)
+    if mtot % 2:
+        x, v, T = _setup(2, mtot, N=900, seed=7)
+    else:      # even block size: lags box (2 mtot - 1)^2 = 63^2 of arbitrary complex numbers (the operator is generic)
+        L = 2 * mtot - 1
+        v = torch.complex(torch.randn(L, L, generator=g, dtype=torch.float64), torch.randn(L, L, generator=g, dtype=torch.float64))
+        T = O.Toeplitz(v)
+    assert tuple(T.fft_shape) == (64, 64)
+    u = torch.complex(torch.randn(4, T.size, generator=g, dtype=torch.float64),
+                      torch.randn(4, T.size, generator=g, dtype=torch.float64))
+    fused = ToeplitzOp(v.cuda()).apply(u.cuda())
+    monkeypatch.setenv("EFGP_NO_VHAT64", "1")
+    plain = ToeplitzOp(v.cuda()).apply(u.cuda())
+    assert _rel(fused, plain) < 1e-14
+    assert _rel(fused, T(u)) < 1e-13
