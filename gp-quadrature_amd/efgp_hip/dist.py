@@ -18,6 +18,19 @@ def shard_bounds(n, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _adjacent_span(tensors):
+    """One flat view covering `tensors` when they are contiguous views placed back to back in the same storage
+    (same dtype and device), else None.  Saves the pack / unpack copies around the fused all-reduce."""
+    t0 = tensors[0]
+    off = t0.storage_offset()
+    for t in tensors:
+        if not t.is_contiguous() or t.dtype != t0.dtype or t.device != t0.device or \
+                t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr() or t.storage_offset() != off:
+            return None
+        off += t.numel()
+    return torch.as_strided(t0, (off - t0.storage_offset(),), (1,), t0.storage_offset())
+
+
 class PointShards:
     """All-reduce helper bound to a process group; a no-op when world_size == 1."""
 
@@ -49,6 +62,10 @@ class PointShards:
     def sum_many_(self, tensors):
         """One fused all-reduce for several small tensors (latency-bound messages)."""
         if not self.active or not tensors:
+            return tensors
+        span = _adjacent_span(tensors)
+        if span is not None:          # views laid out back to back in one buffer (NufftPlan.type1_pair): reduce in place
+            dist.all_reduce(torch.view_as_real(span) if span.is_complex() else span, op=dist.ReduceOp.SUM, group=self.group)
             return tensors
         flats = [(torch.view_as_real(t) if t.is_complex() else t).reshape(-1) for t in tensors]
         packed = torch.cat(flats)

@@ -99,8 +99,16 @@ class NufftPlan:
     def type1_pair(self, y, n_modes_y, n_modes_one):
         """One pass over the points: (F* y on n_modes_y, F* 1 on n_modes_one)."""
         yy = y.to(device=self.dev, dtype=_RD).contiguous()
-        out_y = torch.empty(tuple(int(m) for m in n_modes_y), dtype=_CD, device=self.dev)
-        out_o = torch.empty(tuple(int(m) for m in n_modes_one), dtype=_CD, device=self.dev)
+        shape_y, shape_o = tuple(int(m) for m in n_modes_y), tuple(int(m) for m in n_modes_one)
+        My = 1
+        for m in shape_y:
+            My *= m
+        Mo = 1
+        for m in shape_o:
+            Mo *= m
+        # one buffer, two views: the sharded fit all-reduces both results in place with a single collective
+        flat = torch.empty(My + Mo, dtype=_CD, device=self.dev)
+        out_y, out_o = flat[:My].view(shape_y), flat[My:].view(shape_o)
         with torch.cuda.device(self.dev):
             check(lib().efgp_nufft_type1_pair(self._h, _ptr(yy), _i64(n_modes_y), _ptr(out_y), _i64(n_modes_one),
                                               _ptr(out_o), _stream(self.dev)), "efgp_nufft_type1_pair")

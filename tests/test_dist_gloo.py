@@ -46,6 +46,16 @@ def _worker(rank, world, port, q):
         v_full = O.conv_vector(x, h, (mtot - 1) // 2)
         e1 = float((Fy - Fy_full).abs().max() / Fy_full.abs().max())
         e2 = float((v - v_full).abs().max() / v_full.abs().max())
+        # the product path hands sum_many_ two views of ONE buffer (NufftPlan.type1_pair): reduced in place, no packing
+        from efgp_hip.dist import _adjacent_span
+        Fy2 = O.nudft_type1(xs, h, ys, (mtot, mtot))
+        v2 = O.conv_vector(xs, h, (mtot - 1) // 2)
+        flat = torch.cat([Fy2.reshape(-1), v2.reshape(-1)])
+        Fy_v, v_v = flat[:Fy2.numel()].view(Fy2.shape), flat[Fy2.numel():].view(v2.shape)
+        assert _adjacent_span([Fy_v, v_v]) is not None and _adjacent_span([Fy2, v2]) is None
+        sh.sum_many_([Fy_v, v_v])
+        e1 = max(e1, float((Fy_v - Fy_full).abs().max() / Fy_full.abs().max()))
+        e2 = max(e2, float((v_v - v_full).abs().max() / v_full.abs().max()))
         Z = torch.ones(3, hi - lo, dtype=torch.float64)
         FZ = O.nudft_type1(xs, h, Z, (mtot, mtot)).reshape(3, -1)
         sh.sum_(FZ)
