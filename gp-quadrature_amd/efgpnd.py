@@ -311,9 +311,11 @@ class _Grid:
         # Non-blocking uploads where the whole solve is one launch (circulant grid small enough for the persistent kernel:
         # F^d <= 4096 with F = next_pow2(2 mtot - 1)) -- that is where the host running ahead pays (launch gaps of the
         # N = 1e6 step).  The multi-kernel solves synchronise with the device per burst anyway and keep the plain copy
-        # (measured together with the CPU-quota stalls of efgp_hip/cpu_quota.py, not re-measured since: conservative).
+        # (with torch's CPU pool capped, EFGP_ASYNC_UPLOAD_ALL=1 measures 7.11 vs 7.28 ms on the 3-D 64^3 fit and no
+        # difference at 2-D 256^2; with an uncapped pool under a CPU quota the host running ahead made the throttling
+        # stalls of efgp_hip/cpu_quota.py appear there too, so the conservative choice stays the default).
         F = 1 << (2 * self.mtot - 2).bit_length()
-        async_ok = F ** d <= 4096
+        async_ok = F ** d <= 4096 or bool(os.environ.get("EFGP_ASYNC_UPLOAD_ALL"))
         up = _upload if async_ok else (lambda t, dv: t.to(dv))
         where = self.xis if host_ok else up(self.xis, dev)
         S = kernel.spectral_density(where).to(torch.float64)
