@@ -275,7 +275,7 @@ class _PinnedStage:
         return out
 
 
-_STAGES: Dict[int, _PinnedStage] = {}
+_STAGES: Dict[int, Optional[_PinnedStage]] = {}
 
 
 def _upload(t: torch.Tensor, dev: torch.device) -> torch.Tensor:
@@ -284,8 +284,13 @@ def _upload(t: torch.Tensor, dev: torch.device) -> torch.Tensor:
     N = 1e6).  Staged through a persistent pinned buffer the copy is just another stream-ordered operation
     (`Tensor.pin_memory()` per call is no alternative: 14 ms per call measured for a 292-KB grid)."""
     if t.device.type == "cpu" and dev.type == "cuda" and t.numel() > 0 and not os.environ.get("EFGP_NO_PINNED_UPLOAD"):
-        with torch.cuda.device(dev):
-            return _STAGES.setdefault(dev.index or 0, _PinnedStage()).upload(t, dev)
+        stage = _STAGES.setdefault(dev.index or 0, _PinnedStage())
+        if stage is not None:
+            try:
+                with torch.cuda.device(dev):
+                    return stage.upload(t, dev)
+            except RuntimeError:          # no pinned memory to be had (locked-memory limit): plain copies from now on
+                _STAGES[dev.index or 0] = None
     return t.to(dev)
 
 
