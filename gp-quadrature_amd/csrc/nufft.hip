@@ -20,159 +20,12 @@
 
 #include "common.hpp"
 #include "es_kernel.hpp"
+#include "nufft_dev.hpp"
+#include "points_layout.hpp"
+#include "spread_mfma.hpp"
 
 namespace efgp {
 
-constexpr int kSpreadThreads = 1024;
-constexpr int kInterpThreads = 1024;        // LDS-resident fine grid
-constexpr int kInterpThreadsGlobal = 256;   // fine grid read through L2
-constexpr double kFixMagic = 6755399441055744.0;   // 1.5 * 2^52: adding it rounds to an integer in the mantissa
-
-enum StrengthMode {
-    STR_REAL = 0,            // one real row per fine grid
-    STR_COMPLEX = 1,         // one complex row (re, im channels)
-    STR_REAL_AND_ONES = 2,   // (y, 1): the fit-time pair
-    STR_ONES = 3,
-    STR_REAL_PAIR = 4,       // two real rows (2g, 2g+1) share one complex fine grid
-    STR_RNG = 5,             // one Rademacher row generated in the kernel
-    STR_RNG_PAIR = 6         // two Rademacher rows
-};
-
-// counter-based Rademacher probe: sign(seed, row, point index) -- splitmix64 finaliser
-__host__ __device__ __forceinline__ unsigned long long efgp_mix64(unsigned long long z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-__host__ __device__ __forceinline__ double efgp_rademacher(unsigned long long seed, long long row, long long n) {
-    const unsigned long long r = efgp_mix64(seed ^ efgp_mix64((unsigned long long)row * 0xD1342543DE82EF95ull +
-                                                             (unsigned long long)n));
-    return (r >> 63) ? 1.0 : -1.0;
-}
-
-struct StrengthSrc {
-    const double* c;          // base pointer of all rows (layout by mode)
-    int64_t npts;             // row length
-    int mode;
-    unsigned long long seed;
-    int64_t index_offset;     // added to the point index for the RNG (global index of this shard's first point)
-};
-
-// strengths (c0, c1) of point `n` (original index) for fine grid `g`
-__device__ __forceinline__ void fetch_strength(const StrengthSrc& s, int g, int64_t n, double& c0, double& c1) {
-    c0 = 1.0;
-    c1 = 1.0;
-    switch (s.mode) {
-        case STR_REAL: c0 = s.c[(int64_t)g * s.npts + n]; break;
-        case STR_COMPLEX: {
-            const double2 cc = reinterpret_cast<const double2*>(s.c)[(int64_t)g * s.npts + n];
-            c0 = cc.x;
-            c1 = cc.y;
-        } break;
-        case STR_REAL_AND_ONES: c0 = s.c[n]; break;
-        case STR_REAL_PAIR:
-            c0 = s.c[(int64_t)(2 * g) * s.npts + n];
-            c1 = s.c[(int64_t)(2 * g + 1) * s.npts + n];
-            break;
-        case STR_RNG: c0 = efgp_rademacher(s.seed, g, n + s.index_offset); break;
-        case STR_RNG_PAIR:
-            c0 = efgp_rademacher(s.seed, 2 * g, n + s.index_offset);
-            c1 = efgp_rademacher(s.seed, 2 * g + 1, n + s.index_offset);
-            break;
-        default: break;
-    }
-}
-
-struct GridGeom {
-    int64_t nf[3];      // fine-grid size per dimension (unused dims = 1)
-    double scale[3];    // X = scale * (x - xcen): h * nf
-    double xcen[3];
-    int64_t cells;      // prod nf
-};
-
-// ------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------
-// The Horner coefficients are read through the CONSTANT address space: the table is never written while a
-// kernel runs, and telling the compiler so lets it use scalar loads (s_load) for these wave-uniform values.
-// With a plain global pointer the interpolation kernels (which also store to global memory) fell back to
-// vector global loads inside the Horner loop -- a chain of ~2*degree dependent L2 round trips per point.
-typedef const __attribute__((address_space(4))) double* const_coef_ptr;
-
-// All dimensions of a point at once, with half the coefficient traffic: the window is even, so polynomial
-// W-1-j at s equals polynomial j at -s.  Only the first RH = ceil(W/2) polynomials are read (table
-// `sym` behind the plain one: [kMaxDegree+1][RHP] doubles, one scalar load per degree) and every loaded
-// coefficient feeds 2*D FMAs as a scalar operand.
-__host__ __device__ constexpr int sym_row(int W) { return (W + 1) / 2 <= 2 ? 2 : ((W + 1) / 2 <= 4 ? 4 : 8); }
-
-template <int D, int W>
-__device__ __forceinline__ void window_eval(const double* __restrict__ coef_generic, int degree, const double (&X)[3],
-                                            int64_t nf0, int64_t nf1, int64_t nf2, int& f0, int& f1, int& f2,
-                                            double (&v0)[W], double (&v1)[W], double (&v2)[W]) {
-    constexpr int RH = (W + 1) / 2, RHP = sym_row(W);
-    const_coef_ptr coef = (const_coef_ptr)(coef_generic + (kMaxDegree + 1) * W);
-    const int64_t nfs[3] = {nf0, nf1, nf2};
-    int fs[3] = {0, 0, 0};
-    double s[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const double i0 = ceil(X[d] - 0.5 * W);
-        s[d] = 2.0 * (i0 - X[d] + 0.5 * W) - 1.0;
-        int f = (int)i0;
-        if (f < 0) f += (int)nfs[d];
-        fs[d] = f;
-    }
-    double vp[D][RH], vm[D][RH];
-#pragma unroll
-    for (int j = 0; j < RH; ++j) {
-        const double c = coef[degree * RHP + j];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            vp[d][j] = c;
-            vm[d][j] = c;
-        }
-    }
-    for (int k = degree - 1; k >= 0; --k) {
-#pragma unroll
-        for (int j = 0; j < RH; ++j) {
-            const double c = coef[k * RHP + j];
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                vp[d][j] = fma(vp[d][j], s[d], c);
-                vm[d][j] = fma(vm[d][j], -s[d], c);
-            }
-        }
-    }
-    f0 = fs[0];
-    f1 = fs[1];
-    f2 = fs[2];
-#pragma unroll
-    for (int j = 0; j < RH; ++j) {
-        v0[j] = vp[0][j];
-        if (W - 1 - j != j) v0[W - 1 - j] = vm[0][j];
-        if (D > 1) {
-            v1[j] = vp[D > 1 ? 1 : 0][j];
-            if (W - 1 - j != j) v1[W - 1 - j] = vm[D > 1 ? 1 : 0][j];
-        }
-        if (D > 2) {
-            v2[j] = vp[D > 2 ? 2 : 0][j];
-            if (W - 1 - j != j) v2[W - 1 - j] = vm[D > 2 ? 2 : 0][j];
-        }
-    }
-}
-
-__device__ __forceinline__ double fold(double X, double nf) {
-    // reciprocal instead of an fp64 division per coordinate (1/nf is loop invariant); a quotient that lands one
-    // unit off next to an integer leaves X within rounding of 0 or nf, which the guards below fold back
-    X -= nf * floor(X * (1.0 / nf));
-    // guard against X == nf after rounding
-    if (X >= nf) X -= nf;
-    if (X < 0.0) X = 0.0;
-    return X;
-}
-
-__device__ __forceinline__ int wrap(int i, int nf) { return i >= nf ? i - nf : i; }
 
 // ------------------------------------------------------------------------------------------
 // type-1 spreader.  One thread per point; grid = (workgroups, nbatch).
@@ -592,6 +445,13 @@ __global__ void fixed_scale_kernel(double floor_bound, int ones_channel, int64_t
                                    int sum_bits) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     fixed_scale_write(0.0, floor_bound, ones_channel, per, scale, sum_bits);
+}
+
+// same, with max|c| read from a device word that holds it as an ordered bit pattern (the per-model cache of
+// points_layout: y never changes between fits, so its N-length maximum pass runs once per model)
+__global__ void fixed_scale_cached_kernel(const unsigned long long* __restrict__ cmax_bits, ScaleJob job) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    fixed_scale_write(__longlong_as_double((long long)*cmax_bits), job.floor_bound, job.ones_channel, job.per, job.scale, job.sum_bits);
 }
 
 // max |c| over n doubles as an ordered bit pattern (non-negative doubles compare like integers).
@@ -1594,6 +1454,59 @@ __global__ __launch_bounds__(kInterpThreads) void interp_real_halo_kernel(Interp
     }
 }
 
+// 2-D real-output gather from TWO halo-padded LDS copies of the real fine grid: copy 1 is copy 0 shifted left by one
+// column, so a stencil row starting at an odd column is read from copy 1 at the even column below it and every row
+// read is a 16-byte-aligned ds_read_b128 (two cells per lane-instruction).  The single-copy kernel has to use
+// ds_read2_b64 (8-byte alignment): twice the LDS cycles per byte (MI355X_MICROARCH section LDS), and the gather is
+// LDS-bound (PMC, round 1).  No processing order is needed: points are streamed as the caller holds them, so x
+// loads and result stores stay coalesced and no per-plan ordering pass exists.
+template <int W>
+__global__ __launch_bounds__(kInterpThreads) void interp_real2_pair_kernel(InterpArgs a) {
+    extern __shared__ double lds[];
+    constexpr int WP = (W + 1) / 2;                  // 16-byte pairs per stencil row
+    const int batch = blockIdx.y;
+    const double2* F = a.fine + (int64_t)batch * a.g.cells;
+    const int nf0 = (int)a.g.nf[0], nf1 = (int)a.g.nf[1];
+    const int p0 = nf0 + W - 1, p1 = (nf1 + 2 * WP + 1) & ~1;            // even row pitch, room for the pair overhang
+    const int plane = p0 * p1;
+    for (int i = threadIdx.x; i < 2 * plane; i += kInterpThreads) {
+        const int cp = i >= plane ? 1 : 0;
+        const int r = (i - cp * plane) / p1, c = (i - cp * plane) - r * p1 + cp;      // copy 1 holds column c + 1
+        int i0 = r >= nf0 ? r - nf0 : r;
+        int i1 = c % nf1;
+        lds[i] = F[(int64_t)i0 * nf1 + i1].x;
+    }
+    __syncthreads();
+    double* out = reinterpret_cast<double*>(a.out) + (int64_t)batch * a.npts;
+    for (int64_t n = (int64_t)blockIdx.x * kInterpThreads + threadIdx.x; n < a.npts; n += (int64_t)gridDim.x * kInterpThreads) {
+        double v0[W], v1[W], v2[W];
+        int f0 = 0, f1 = 0, f2 = 0;
+        {
+            const double2 xy = reinterpret_cast<const double2*>(a.x)[n];
+            double Xw[3] = {0.0, 0.0, 0.0};
+            Xw[0] = fold(a.g.scale[0] * (xy.x - a.g.xcen[0]), (double)nf0);
+            Xw[1] = fold(a.g.scale[1] * (xy.y - a.g.xcen[1]), (double)nf1);
+            window_eval<2, W>(a.coef, a.degree, Xw, nf0, nf1, 1, f0, f1, f2, v0, v1, v2);
+        }
+        const double2* p = reinterpret_cast<const double2*>(lds + (f1 & 1) * plane + f0 * p1 + (f1 & ~1));
+        double acc = 0.0;
+#pragma unroll
+        for (int j0 = 0; j0 < W; ++j0) {
+            double2 c[WP];
+#pragma unroll
+            for (int k = 0; k < WP; ++k) c[k] = p[j0 * (p1 / 2) + k];
+            double r = 0.0;
+#pragma unroll
+            for (int k = 0; k < WP; ++k) {
+                r = fma(v1[2 * k], c[k].x, r);
+                if (2 * k + 1 < W) r = fma(v1[2 * k + 1], c[k].y, r);
+            }
+            acc = fma(v0[j0], r, acc);
+        }
+        out[n] = acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1641,6 +1554,7 @@ struct efgp_nufft_s {
     DeviceCtx* ctx = nullptr;
     std::vector<efgp::BinSet*> bins;     // tile-sorted copies of the points, per (fine grid, W, tile) geometry
     std::vector<efgp::ClassOrder*> orders;   // bank-balanced processing orders of spread_pad_kernel, per (fine grid, W, launch)
+    efgp_points_s* points = nullptr;     // per-model sorted layout (efgp_nufft_create_on), not owned
 };
 
 namespace efgp {
@@ -2011,6 +1925,30 @@ static hipError_t launch_interp_halo_d(int W, dim3 grid, size_t lds_bytes, hipSt
     return hipErrorInvalidValue;
 }
 
+static size_t interp_pair_lds_bytes(int nf0, int nf1, int W) {
+    const int wp = (W + 1) / 2;
+    return 2 * (size_t)(nf0 + W - 1) * (size_t)((nf1 + 2 * wp + 1) & ~1) * sizeof(double);
+}
+
+static hipError_t launch_interp_pair(int W, dim3 grid, size_t lds_bytes, hipStream_t s, const InterpArgs& a) {
+    switch (W) {
+#define EFGP_CASE(w_)                                                                                               \
+    case w_: {                                                                                                      \
+        auto k = interp_real2_pair_kernel<w_>;                                                                      \
+        if (lds_bytes > 65536) {                                                                                    \
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            if (e != hipSuccess) return e;                                                                          \
+        }                                                                                                           \
+        hipLaunchKernelGGL(k, grid, dim3(kInterpThreads), lds_bytes, s, a);                                         \
+        return hipGetLastError();                                                                                   \
+    }
+        EFGP_CASE(2) EFGP_CASE(3) EFGP_CASE(4) EFGP_CASE(5) EFGP_CASE(6) EFGP_CASE(7) EFGP_CASE(8) EFGP_CASE(9)
+        EFGP_CASE(10) EFGP_CASE(11) EFGP_CASE(12) EFGP_CASE(13) EFGP_CASE(14) EFGP_CASE(15) EFGP_CASE(16)
+#undef EFGP_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
 template <int D>
 static hipError_t launch_interp_d(int W, bool cplx, bool use_lds, dim3 grid, size_t lds_bytes, hipStream_t s,
                                   const InterpArgs& a) {
@@ -2220,6 +2158,28 @@ static char* scale_slot(DeviceCtx* ctx, hipStream_t stream) {
     return misc;
 }
 
+// Level of the plan's point layout the MFMA spreader can use for this fine grid, or nullptr (no layout, not 2-D,
+// window wider than the register tile, too few points per run to amortise the tile flushes, EFGP_NO_MFMA_SPREAD).
+// Bands may be at most 8 cells high: the tile's 16 columns hold the 8-cell stencil at offsets 0..8.
+static SortedLevel* pick_level(efgp_nufft_s* plan, const WindowSet* w, const GridGeom& g, hipStream_t stream) {
+    efgp_points_s* pts = plan->points;
+    if (!pts || plan->dim != 2 || w->p.w > kMfmaMaxW || plan->npts < 32768 || std::getenv("EFGP_NO_MFMA_SPREAD")) return nullptr;
+    double span[2], far = 0.0;
+    for (int a = 0; a < 2; ++a) {
+        span[a] = (pts->hi[a] - pts->lo[a]) * std::fabs(g.scale[a]);
+        far = std::max(far, std::max(std::fabs(pts->hi[a] - plan->xcen[a]), std::fabs(pts->lo[a] - plan->xcen[a])) * std::fabs(g.scale[a]));
+    }
+    if (!(far < 1e9) || !(g.scale[0] > 0.0) || !(g.scale[1] > 0.0)) return nullptr;      // cell indices are kept in 32-bit ints
+    int nb = 1;
+    while (span[1] / nb > 8.0 - 1e-6 && nb <= kMaxBands) nb *= 2;
+    if (nb > kMaxBands) return nullptr;
+    const double runs = (double)nb * std::max(1.0, span[0]);
+    if ((double)plan->npts / runs < 24.0) return nullptr;
+    SortedLevel* lvl = nullptr;
+    if (points_level(pts, nb, stream, &lvl) != EFGP_OK) return nullptr;
+    return lvl;
+}
+
 // spread + reduce + FFT; leaves the transformed fine grids in SLOT_FINE
 static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int mode, int nbatch, int isign,
                           hipStream_t stream, double2** fine_out, unsigned long long seed = 0, int64_t index_offset = 0,
@@ -2241,6 +2201,52 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     src.index_offset = index_offset;
     const size_t lds_bytes = (size_t)channels * (size_t)g.cells * sizeof(double);
     const bool use_lds = lds_bytes <= (size_t)ctx->max_lds && plan->npts > 0;
+    // 2-D plans made on a per-model point layout (efgp_nufft_create_on): MFMA register accumulation over
+    // (band, x_0)-sorted points, no per-plan sorting (spread_mfma.hip)
+    if (SortedLevel* lvl = pick_level(plan, w, g, stream)) {
+        const double* ys = nullptr;
+        if (c && c == plan->points->values && (mode == STR_REAL_AND_ONES || (mode == STR_REAL && nbatch == 1))) {
+            int rc = points_level_values(plan->points, lvl, stream);
+            if (rc != EFGP_OK) return rc;
+            ys = lvl->ys;
+        }
+        const size_t acc_bytes = (size_t)nbatch * channels * (size_t)g.cells * sizeof(long long);
+        unsigned long long* gacc = (unsigned long long*)scratch(ctx, SLOT_SLABS, acc_bytes);
+        double2* fine = (double2*)scratch(ctx, SLOT_FINE, (size_t)nbatch * (size_t)g.cells * sizeof(double2));
+        char* misc = scale_slot(ctx, stream);
+        if (!gacc || !fine || !misc) return EFGP_ENOMEM;
+        double* d_scale = (double*)misc;
+        unsigned long long* d_cmax = (unsigned long long*)(misc + 56);
+        if (scale_out) *scale_out = d_scale;
+        EFGP_HIP_CHECK(hipMemsetAsync(gacc, 0, acc_bytes, stream));
+        // the global int64 grid sums over ALL points: the scale is bounded with N
+        const ScaleJob job{floor_bound, mode == STR_REAL_AND_ONES ? 1 : 0, plan->npts, d_scale, 61};
+        if (need_max && ys && plan->points->d_values_max) {
+            hipLaunchKernelGGL(fixed_scale_cached_kernel, dim3(1), dim3(64), 0, stream,
+                               (const unsigned long long*)plan->points->d_values_max, job);
+        } else if (need_max) {
+            const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nvals + 8191) / 8192, 256));
+            hipLaunchKernelGGL(maxabs_kernel, dim3(blocks), dim3(1024), 0, stream, c, nvals, d_cmax,
+                               (unsigned int*)(misc + 48), job);
+        } else {
+            hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream, job.floor_bound, job.ones_channel, job.per,
+                               job.scale, job.sum_bits);
+        }
+        EFGP_HIP_CHECK(hipGetLastError());
+        int rc = spread_mfma_launch(ctx, lvl, ys, src, g, w->p.w, w->d_coef, w->p.degree, channels, nbatch, gacc, d_scale, stream);
+        if (rc != EFGP_OK) return rc;
+        const int rb = (int)((g.cells + 63) / 64);
+        hipLaunchKernelGGL((reduce_slabs_kernel<true>), dim3(rb, nbatch), dim3(512), 0, stream, (const double*)gacc, 1,
+                           channels, g.cells, (const double*)d_scale, fine);
+        EFGP_HIP_CHECK(hipGetLastError());
+        hipfftHandle fh;
+        rc = fft_plan(ctx, plan->dim, g.nf, nbatch, stream, &fh);
+        if (rc != EFGP_OK) return rc;
+        EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)fine, (hipfftDoubleComplex*)fine,
+                                     isign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
+        *fine_out = fine;
+        return EFGP_OK;
+    }
     // 2-D with many points per fine-grid cell: register accumulation over base-cell-sorted points
     {
         // Opt-in (EFGP_CELLSORT=1): the kernel itself is 1.2-1.7x faster than the LDS-atomic spreader at >= 250 points
@@ -2528,6 +2534,14 @@ int efgp_nufft_create(efgp_nufft_t** plan_out, int device, int dim, int64_t npts
     return EFGP_OK;
 }
 
+int efgp_nufft_create_on(efgp_nufft_t** plan_out, efgp_points_t* pts, const double* xcen_host, double h, double tol) {
+    EFGP_REQUIRE(pts, "efgp_nufft_create_on: null point layout");
+    int rc = efgp_nufft_create(plan_out, pts->device, pts->dim, pts->npts, pts->x, xcen_host, h, tol);
+    if (rc != EFGP_OK) return rc;
+    (*plan_out)->points = pts;
+    return EFGP_OK;
+}
+
 int efgp_nufft_destroy(efgp_nufft_t* plan) {
     if (!plan) return EFGP_OK;
     DeviceGuard guard(plan->device);
@@ -2745,6 +2759,10 @@ static int type2_impl(efgp_nufft_t* plan, const void* f, const void* mode_scale,
     for (int a_ = 0; a_ < plan->dim; ++a_) halo_cells *= (size_t)(g.nf[a_] + w->p.w - 1);
     const bool use_halo = !cplx && halo_cells * sizeof(double) <= (size_t)ctx->max_lds && std::getenv("EFGP_NO_HALO") == nullptr;
     if (use_halo) lds_bytes = halo_cells * sizeof(double);
+    // 2-D real outputs whose two parity copies fit LDS: aligned 16-byte reads, no processing order
+    const size_t pair_bytes = plan->dim == 2 ? interp_pair_lds_bytes((int)g.nf[0], (int)g.nf[1], w->p.w) : 0;
+    const bool use_pair = use_halo && plan->dim == 2 && pair_bytes <= (size_t)ctx->max_lds && std::getenv("EFGP_NO_PAIR_GATHER") == nullptr;
+    if (use_pair) lds_bytes = pair_bytes;
     const bool use_lds = lds_bytes <= (size_t)ctx->max_lds;
     // grids beyond LDS: tile-sorted points + LDS tiles (the binning is shared with the tiled spreader when the
     // tile geometry coincides, and cached in the plan otherwise)
@@ -2801,7 +2819,7 @@ static int type2_impl(efgp_nufft_t* plan, const void* f, const void* mode_scale,
         nwg = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->num_cu * 8, want));
     }
     a.order = nullptr;
-    if (use_halo && plan->dim >= 2 && plan->npts >= (int64_t)kOrderWindow * 64 && std::getenv("EFGP_NO_CLASS_ORDER") == nullptr) {
+    if (use_halo && !use_pair && plan->dim >= 2 && plan->npts >= (int64_t)kOrderWindow * 64 && std::getenv("EFGP_NO_CLASS_ORDER") == nullptr) {
         // same classes as the padded spreader (row pitch nf + W - 1), over global windows: nwg = 0 marks that layout
         ClassOrder* co = nullptr;
         for (ClassOrder* o : plan->orders)
@@ -2832,7 +2850,9 @@ static int type2_impl(efgp_nufft_t* plan, const void* f, const void* mode_scale,
     dim3 grid(nwg, nbatch);
     hipError_t e;
     KernelTimer timer("interp", stream);
-    if (use_halo) {
+    if (use_pair) {
+        e = launch_interp_pair(w->p.w, grid, lds_bytes, stream, a);
+    } else if (use_halo) {
         if (plan->dim == 1) e = launch_interp_halo_d<1>(w->p.w, grid, lds_bytes, stream, a);
         else if (plan->dim == 2) e = launch_interp_halo_d<2>(w->p.w, grid, lds_bytes, stream, a);
         else e = launch_interp_halo_d<3>(w->p.w, grid, lds_bytes, stream, a);

@@ -1,0 +1,288 @@
+// Type-1 spreading with MFMA register accumulation over (band, x_0)-sorted points (2-D, window width <= 8).
+//
+// Replaces the FINUFFT type-1 call of the reference (efgpnd.py:1496-1499) for the N-scale pass of a fit
+// (F*y and the Toeplitz vector in one pass, efgpnd.py:786, 789-790) and for the probe transforms of the
+// hyper-gradient (efgpnd.py:186-189).
+//
+// Why a matrix instruction: the contribution of a point to the fine grid is the outer product
+// (c wx) (x) wy of two 8-vectors, and the sum over the points that share a stencil is a rank-K update
+// D += A B with K = points -- exactly what v_mfma_f64_16x16x4_f64 computes (4 points per instruction), with the
+// reduction over points done inside the matrix unit instead of by LDS atomics (the LDS-atomic spreader spends
+// 2 W^2 = 128 ds_add_u64 per point and is bound by LDS bank conflicts).
+//   rows    (16) = (channel, x stencil cell): A[(ch, i)][k] = c_ch,k * wx_k[i]
+//   columns (16) = y stencil cell relative to the band's first one: B[k][j + off_k] = wy_k[j], 0 <= off_k <= 8
+// The tile belongs to one x-cell run of one band of the per-model point layout (points_layout.hpp); it is added
+// to the global int64 fine grid (exact fixed point, order independent) when the run ends: one flush of 256 values
+// per ~1000 points instead of 128 atomics per point.  On gfx950 the fp64 matrix and vector pipes are the same
+// unit (tools/mfma_f64_bench.hip: an independent v_fma_f64 next to the MFMA costs its full issue time), so the
+// budget per point is  16 Horner polynomials (lane = point, no redundancy: 2.5 wave-FMAs)  +  1/4 MFMA.
+//
+// Per wave, no workgroup barrier anywhere: a wave owns chunks of sorted points (grid-stride) and a private LDS
+// region; per batch of 64 points, phase 1 (lane = point) evaluates the windows and writes the operand rows to
+// LDS [component][point]; phase 2 (lane = (k, r)) reads its A / B element of 4 points per step and issues the
+// MFMA.  LDS row stride 66 doubles: the 16 rows x 2 points read by one 32-lane group hit 32 distinct bank pairs.
+#include "spread_mfma.hpp"
+
+#include <algorithm>
+
+namespace efgp {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMfmaRow = 66;                  // doubles per LDS row: 64 points + 2 (bank spread)
+constexpr int kMfmaWaves = 4;                 // waves per workgroup (independent)
+constexpr int kMfmaWaveDoubles = 32 * kMfmaRow + 32;   // A (16 rows) + B (16 rows) + 64 ints (x cell of every point)
+constexpr size_t kMfmaLdsBytes = (size_t)kMfmaWaves * kMfmaWaveDoubles * sizeof(double);
+
+struct MfmaSpreadArgs {
+    const double* xs;
+    const double* ys;          // strengths in level order (null: fetch through src + perm)
+    const int* perm;
+    const int* chunks;
+    int nchunks;
+    int total_waves;
+    const double* band_lo;
+    StrengthSrc src;
+    double scale0, scale1, xcen0, xcen1;      // X = scale * (x - xcen) in fine-grid cells
+    int nf0, nf1;
+    const double* coef;
+    int degree;
+    int channels;
+    unsigned long long* gacc;
+    const double* scale;
+};
+
+// Window values of both dimensions from the offsets s in [-1, 1): symmetric Horner (see window_eval).  The
+// coefficients of one degree (ceil(W/2) doubles, scalar loads) are fetched one iteration ahead: with two waves per
+// SIMD a scalar-cache round trip per degree would otherwise sit in the dependent chain of every batch.
+template <int W>
+__device__ __forceinline__ void horner2(const double* __restrict__ coef_generic, int degree, double s0, double s1,
+                                        double (&v0)[W], double (&v1)[W]) {
+    constexpr int RH = (W + 1) / 2, RHP = sym_row(W);
+    const_coef_ptr coef = (const_coef_ptr)(coef_generic + (kMaxDegree + 1) * W);
+    double p0[RH], m0[RH], p1[RH], m1[RH], c[RH], cn[RH];
+#pragma unroll
+    for (int j = 0; j < RH; ++j) {
+        const double top = coef[degree * RHP + j];
+        p0[j] = top;
+        m0[j] = top;
+        p1[j] = top;
+        m1[j] = top;
+        c[j] = coef[(degree - 1) * RHP + j];
+    }
+    for (int k = degree - 1; k >= 0; --k) {
+        const int kn = k > 0 ? k - 1 : 0;
+#pragma unroll
+        for (int j = 0; j < RH; ++j) cn[j] = coef[kn * RHP + j];
+#pragma unroll
+        for (int j = 0; j < RH; ++j) {
+            p0[j] = fma(p0[j], s0, c[j]);
+            m0[j] = fma(m0[j], -s0, c[j]);
+            p1[j] = fma(p1[j], s1, c[j]);
+            m1[j] = fma(m1[j], -s1, c[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < RH; ++j) c[j] = cn[j];
+    }
+#pragma unroll
+    for (int j = 0; j < RH; ++j) {
+        v0[j] = p0[j];
+        v1[j] = p1[j];
+        if (W - 1 - j != j) {
+            v0[W - 1 - j] = m0[j];
+            v1[W - 1 - j] = m1[j];
+        }
+    }
+}
+
+__device__ __forceinline__ int pos_mod(int a, int n) {
+    int r = a % n;
+    return r < 0 ? r + n : r;
+}
+
+template <int W>
+__device__ __forceinline__ void flush_tile(const d4& acc, int cur_bx, int q, int ycell, int nf0, int nf1, int64_t cells, int channels,
+                                           double S0, double S1, unsigned long long* __restrict__ gch) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = q + 4 * r, ch = row >> 3, i = row & 7;       // ch is a compile-time function of r
+        const double v = acc[r];
+        if (i < W && ch < channels && v != 0.0) {
+            const int xc = pos_mod(cur_bx + i, nf0);
+            const long long f = __double2ll_rn(v * (ch ? S1 : S0));
+            __hip_atomic_fetch_add(gch + (int64_t)ch * cells + (int64_t)xc * nf1 + ycell, (unsigned long long)f, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+struct PointIn {
+    double2 xy;
+    double c0, c1;
+};
+
+__device__ __forceinline__ PointIn load_point(const MfmaSpreadArgs& a, int batch, int p) {
+    PointIn r;
+    r.xy = reinterpret_cast<const double2*>(a.xs)[p];
+    if (a.ys) {
+        r.c0 = a.ys[p];
+        r.c1 = 1.0;
+    } else {
+        fetch_strength(a.src, batch, a.perm[p], r.c0, r.c1);
+    }
+    return r;
+}
+
+template <int W>
+__global__ __launch_bounds__(64 * kMfmaWaves, 2) void spread_mfma_kernel(MfmaSpreadArgs a) {
+    extern __shared__ double lds_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* A = lds_raw + (size_t)wave * kMfmaWaveDoubles;
+    double* B = A + 16 * kMfmaRow;
+    int* bxs = reinterpret_cast<int*>(A + 32 * kMfmaRow);
+    const int batch = blockIdx.y;
+    const int nf0 = a.nf0, nf1 = a.nf1;
+    const int64_t cells = (int64_t)nf0 * nf1;
+    const double S0 = a.scale[0], S1 = a.scale[2];
+    unsigned long long* gch = a.gacc + (int64_t)batch * a.channels * cells;
+    const int q = lane >> 4, c16 = lane & 15;
+    if (W < 8) {                                  // A rows of the unused stencil cells stay zero
+#pragma unroll
+        for (int r = W; r < 8; ++r) {
+            A[r * kMfmaRow + lane] = 0.0;
+            A[(8 + r) * kMfmaRow + lane] = 0.0;
+        }
+    }
+    const double* Ard = A + c16 * kMfmaRow + q;   // this lane's operand elements of step g: Ard[4 g], Brd[4 g]
+    const double* Brd = B + c16 * kMfmaRow + q;
+    for (int chunk = blockIdx.x * kMfmaWaves + wave; chunk < a.nchunks; chunk += a.total_waves) {
+        const int4 ci = reinterpret_cast<const int4*>(a.chunks)[chunk];
+        const int start = __builtin_amdgcn_readfirstlane(ci.x), count = __builtin_amdgcn_readfirstlane(ci.y);
+        const int band = __builtin_amdgcn_readfirstlane(ci.z);
+        const int by0 = (int)ceil(a.scale1 * (a.band_lo[band] - a.xcen1) - 0.5 * W);
+        const int ycell = pos_mod(by0 + c16, nf1);
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        int cur_bx = 0;
+        PointIn nxt = load_point(a, batch, start + (lane < count ? lane : count - 1));
+        for (int b0 = 0; b0 < count; b0 += 64) {
+            const int rem = count - b0;                                       // wave-uniform
+            const bool valid = lane < rem;
+            const PointIn cur = nxt;
+            if (rem > 64) {                                                   // next batch's loads fly during this one
+                const int r2 = rem - 64;
+                nxt = load_point(a, batch, start + b0 + 64 + (lane < r2 ? lane : r2 - 1));
+            }
+            double c0 = cur.c0, c1 = a.channels == 1 ? 0.0 : cur.c1;
+            if (!valid) {                                                     // tail lanes repeat the last point with zero strength
+                c0 = 0.0;
+                c1 = 0.0;
+            }
+            const double X0 = a.scale0 * (cur.xy.x - a.xcen0), X1 = a.scale1 * (cur.xy.y - a.xcen1);
+            const double i0 = ceil(X0 - 0.5 * W), j0 = ceil(X1 - 0.5 * W);
+            double v0[W], v1[W];
+            horner2<W>(a.coef, a.degree, 2.0 * (i0 - X0 + 0.5 * W) - 1.0, 2.0 * (j0 - X1 + 0.5 * W) - 1.0, v0, v1);
+            const int bx = (int)i0, off = (int)j0 - by0;                      // 0 <= off <= 8 (bands are at most 8 cells high)
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                A[i * kMfmaRow + lane] = c0 * v0[i];
+                A[(8 + i) * kMfmaRow + lane] = c1 * v0[i];
+                B[(off + i) * kMfmaRow + lane] = v1[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 16 - W; ++i)                                  // the 16 - W columns outside [off, off + W) are zero
+                B[((i < off) ? i : i + W) * kMfmaRow + lane] = 0.0;
+            bxs[lane] = bx;
+            if (b0 == 0) cur_bx = __builtin_amdgcn_readfirstlane(bx);
+            int prev = __shfl_up(bx, 1, 64);
+            if (lane == 0) prev = cur_bx;
+            const unsigned long long mask = __ballot(bx != prev);              // run starts inside this batch
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (mask == 0ull && rem >= 64) {
+                // whole batch continues the current run: 16 operand pairs read up front, 16 back-to-back MFMAs
+                double av[16], bv[16];
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    av[g] = Ard[4 * g];
+                    bv[g] = Brd[4 * g];
+                }
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g], bv[g], acc, 0, 0, 0);
+            } else {
+                for (int g = 0; g < 16; ++g) {
+                    if (4 * g >= rem) break;
+                    const double av = Ard[4 * g], bv = Brd[4 * g];
+                    const unsigned bits = (unsigned)(mask >> (4 * g)) & 15u;   // wave-uniform
+                    if (bits == 0u) {
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                    } else {
+                        for (int k = 0; k < 4; ++k) {                          // a run ends inside these four points
+                            if ((bits >> k) & 1u) {
+                                flush_tile<W>(acc, cur_bx, q, ycell, nf0, nf1, cells, a.channels, S0, S1, gch);
+                                acc = d4{0.0, 0.0, 0.0, 0.0};
+                                cur_bx = __builtin_amdgcn_readfirstlane(bxs[4 * g + k]);
+                            }
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(q == k ? av : 0.0, bv, acc, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                                   // the next batch overwrites the rows
+        }
+        flush_tile<W>(acc, cur_bx, q, ycell, nf0, nf1, cells, a.channels, S0, S1, gch);
+    }
+}
+
+template <int W>
+static hipError_t launch_w(dim3 grid, hipStream_t s, const MfmaSpreadArgs& a) {
+    hipLaunchKernelGGL((spread_mfma_kernel<W>), grid, dim3(64 * kMfmaWaves), kMfmaLdsBytes, s, a);
+    return hipGetLastError();
+}
+
+int spread_mfma_launch(DeviceCtx* ctx, const SortedLevel* lvl, const double* ys_sorted, const StrengthSrc& src, const GridGeom& g,
+                       int W, const double* coef, int degree, int channels, int nbatch, unsigned long long* gacc,
+                       const double* scale, hipStream_t stream) {
+    EFGP_REQUIRE(W >= 2 && W <= kMfmaMaxW, "spread_mfma: window width %d outside 2..%d", W, kMfmaMaxW);
+    EFGP_REQUIRE(channels == 1 || channels == 2, "spread_mfma: channels must be 1 or 2");
+    EFGP_REQUIRE(lvl && lvl->nchunks > 0, "spread_mfma: empty level");
+    MfmaSpreadArgs a;
+    a.xs = lvl->xs;
+    a.ys = ys_sorted;
+    a.perm = lvl->perm;
+    a.chunks = lvl->chunks;
+    a.nchunks = lvl->nchunks;
+    a.band_lo = lvl->d_band_lo;
+    a.src = src;
+    a.scale0 = g.scale[0];
+    a.scale1 = g.scale[1];
+    a.xcen0 = g.xcen[0];
+    a.xcen1 = g.xcen[1];
+    a.nf0 = (int)g.nf[0];
+    a.nf1 = (int)g.nf[1];
+    a.coef = coef;
+    a.degree = degree;
+    a.channels = channels;
+    a.gacc = gacc;
+    a.scale = scale;
+    // two workgroups (8 waves) per CU; a wave strides over the chunks (points_layout.hip sizes them for this)
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)lvl->nchunks + kMfmaWaves - 1) / kMfmaWaves, (int64_t)ctx->num_cu * 2));
+    a.total_waves = blocks * kMfmaWaves;
+    hipError_t e;
+    {
+        KernelTimer timer("spread", stream);
+        switch (W) {
+#define EFGP_CASE(w_) case w_: e = launch_w<w_>(dim3(blocks, nbatch), stream, a); break;
+            EFGP_CASE(2) EFGP_CASE(3) EFGP_CASE(4) EFGP_CASE(5) EFGP_CASE(6) EFGP_CASE(7) EFGP_CASE(8)
+#undef EFGP_CASE
+            default: e = hipErrorInvalidValue;
+        }
+    }
+    if (e != hipSuccess) {
+        set_error("MFMA spread kernel launch failed: %s", hipGetErrorString(e));
+        return EFGP_EHIP;
+    }
+    return EFGP_OK;
+}
+
+}  // namespace efgp

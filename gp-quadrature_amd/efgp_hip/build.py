@@ -10,8 +10,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
-SOURCES = ["es_kernel.cpp", "common.cpp", "nufft.hip", "toeplitz_cg.hip", "cg_persistent.hip"]
-HEADERS = ["es_kernel.hpp", "common.hpp", "toeplitz_cg.hpp", os.path.join("..", "..", "include", "efgp_hip.h")]
+SOURCES = ["es_kernel.cpp", "common.cpp", "nufft.hip", "spread_mfma.hip", "points_layout.hip", "toeplitz_cg.hip", "cg_persistent.hip"]
+HEADERS = ["es_kernel.hpp", "common.hpp", "toeplitz_cg.hpp", "nufft_dev.hpp", "points_layout.hpp", "spread_mfma.hpp", os.path.join("..", "..", "include", "efgp_hip.h")]
 TARGET = os.path.join(HERE, "libefgp_hip.so")
 
 
@@ -39,11 +39,32 @@ def build(force=False, verbose=True, stamps=False):
 
 
 def _build(target, extra, verbose):
+    """Every source is compiled to its own object (in parallel, skipped when the object is newer than the source and
+    all headers), then linked: a one-file edit costs one compile instead of the whole library."""
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tl = _torch_lib_dir()
-    cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-munsafe-fp-atomics",
-           "-no-hip-rt"] + extra + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + [
-           "-I/opt/rocm/include", "-L" + tl, "-lhipfft", "-lamdhip64", "-Wl,-rpath," + tl, "-o", target + ".tmp"]
+    tag = "stamps" if extra else "obj"
+    objdir = os.path.join(HERE, "build", tag)
+    os.makedirs(objdir, exist_ok=True)
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-I/opt/rocm/include"] + extra
+
+    def compile_one(src):
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(objdir, src + ".o")
+        if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), hdr_time):
+            return obj
+        cmd = [hipcc] + flags + ["-x", "hip", "-c", sp, "-o", obj]
+        if verbose:
+            print("[efgp_hip] " + " ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), int(os.environ.get("EFGP_BUILD_JOBS", "6")))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-no-hip-rt"] + objs + [
+        "-L" + tl, "-lhipfft", "-lamdhip64", "-Wl,-rpath," + tl, "-o", target + ".tmp"]
     if verbose:
         print("[efgp_hip] " + " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -93,6 +93,31 @@ class PointShards:
         dist.all_gather(counts, torch.tensor([int(n_local)], dtype=torch.int64, device=device), group=self.group)
         return int(sum(int(c.item()) for c in counts[:self.rank]))
 
+    def broadcast_(self, t, src=0):
+        """Overwrite `t` on every rank with rank `src`'s copy (group rank).  Replicated state that is DRAWN at random
+        -- probe seeds, feature-space probes -- must come from one rank: replicas that draw their own diverge after
+        the first optimizer step (different gradients -> different grids -> mismatched all-reduce sizes)."""
+        if not self.active:
+            return t
+        root = dist.get_global_rank(self.group, src) if self.group is not None else src
+        buf = torch.view_as_real(t) if t.is_complex() else t
+        if not buf.is_contiguous():
+            tmp = buf.contiguous()
+            dist.broadcast(tmp, src=root, group=self.group)
+            buf.copy_(tmp)
+        else:
+            dist.broadcast(buf, src=root, group=self.group)
+        return t
+
+    def shared_seed(self, device, generator=None):
+        """A 62-bit seed drawn on rank 0 (from torch's generator there) and broadcast: identical on all ranks."""
+        seed = torch.randint(0, 2 ** 62, (1,), generator=generator, dtype=torch.int64)
+        if not self.active:
+            return int(seed.item())
+        t = seed.to(device)
+        self.broadcast_(t)
+        return int(t.item())
+
     def minmax(self, lo, hi):
         """Global per-dimension min / max of the point coordinates (for the domain length L)."""
         if not self.active:

@@ -44,6 +44,11 @@ _SIGNATURES = {
     "efgp_window_deconv": (_I, [_D, _I64, _I64, C.POINTER(_D)]),
     "efgp_nufft_create": (_I, [C.POINTER(_VP), _I, _I, _I64, _VP, C.POINTER(_D), _D, _D]),
     "efgp_nufft_destroy": (_I, [_VP]),
+    "efgp_points_create": (_I, [C.POINTER(_VP), _I, _I, _I64, _VP, _VP]),
+    "efgp_points_destroy": (_I, [_VP]),
+    "efgp_points_bounds": (_I, [_VP, C.POINTER(_D), C.POINTER(_D)]),
+    "efgp_points_attach_values": (_I, [_VP, _VP, _VP]),
+    "efgp_nufft_create_on": (_I, [C.POINTER(_VP), _VP, C.POINTER(_D), _D, _D]),
     "efgp_nufft_type1": (_I, [_VP, _VP, _I, _I, _PI64, _I, _I, _VP, _VP]),
     "efgp_nufft_type1_rademacher": (_I, [_VP, C.c_uint64, _I64, _I, _PI64, _I, _VP, _VP]),
     "efgp_rademacher_fill": (_I, [_I, C.c_uint64, _I64, _I, _I64, _VP, _VP]),

@@ -44,12 +44,56 @@ def _i64(vals):
     return (C.c_int64 * len(vals))(*[int(v) for v in vals])
 
 
-class NufftPlan:
-    """Type-1 / type-2 transforms for a fixed point set (C ABI: efgp_nufft_*)."""
+class PointSet:
+    """Per-model layout of the observation points (C ABI: efgp_points_*): bounding box and, for d = 2, copies
+    sorted by a grid-independent key that the type-1 pass of every later plan streams (csrc/points_layout.hpp).
+    `values` (the model's targets) may be attached so that plans read a sorted copy and max|y| is computed once."""
 
-    def __init__(self, x, h, tol, xcen=None):
+    def __init__(self, x, values=None):
         assert x.is_cuda and x.dtype == _RD and x.ndim == 2 and x.is_contiguous()
         self.x = x                    # keeps the storage alive; the library does not copy
+        self.dev = x.device
+        self.npts, self.dim = x.shape
+        self.values = None
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.dev):
+            check(lib().efgp_points_create(C.byref(self._h), self.dev.index, self.dim, self.npts, _ptr(x), _stream(self.dev)),
+                  "efgp_points_create")
+        if values is not None:
+            self.attach_values(values)
+
+    def attach_values(self, y):
+        assert y.is_cuda and y.dtype == _RD and y.is_contiguous() and y.numel() == self.npts
+        self.values = y
+        with torch.cuda.device(self.dev):
+            check(lib().efgp_points_attach_values(self._h, _ptr(y), _stream(self.dev)), "efgp_points_attach_values")
+
+    def bounds(self):
+        lo = (C.c_double * 3)()
+        hi = (C.c_double * 3)()
+        check(lib().efgp_points_bounds(self._h, lo, hi), "efgp_points_bounds")
+        return [float(lo[a]) for a in range(self.dim)], [float(hi[a]) for a in range(self.dim)]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().efgp_points_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NufftPlan:
+    """Type-1 / type-2 transforms for a fixed point set (C ABI: efgp_nufft_*).  With `points` (a PointSet over the
+    same x) the plan is made on the model's layout (efgp_nufft_create_on)."""
+
+    def __init__(self, x, h, tol, xcen=None, points=None):
+        assert x.is_cuda and x.dtype == _RD and x.ndim == 2 and x.is_contiguous()
+        self.x = x                    # keeps the storage alive; the library does not copy
+        self.points = points          # the layout must outlive the plan
         self.dev = x.device
         self.npts, self.dim = x.shape
         self.h = float(h)
@@ -60,8 +104,12 @@ class NufftPlan:
             if any(v != 0.0 for v in vals):
                 xc = (C.c_double * self.dim)(*vals)
         self._h = C.c_void_p()
-        check(lib().efgp_nufft_create(C.byref(self._h), self.dev.index, self.dim, self.npts, _ptr(x), xc,
-                                      self.h, self.tol), "efgp_nufft_create")
+        if points is not None:
+            assert points.x.data_ptr() == x.data_ptr() and points.npts == self.npts
+            check(lib().efgp_nufft_create_on(C.byref(self._h), points._h, xc, self.h, self.tol), "efgp_nufft_create_on")
+        else:
+            check(lib().efgp_nufft_create(C.byref(self._h), self.dev.index, self.dim, self.npts, _ptr(x), xc,
+                                          self.h, self.tol), "efgp_nufft_create")
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -31,7 +31,7 @@ from cg import ConjugateGradients
 from kernels.kernel_params import GPParams
 from utils.kernels import get_xis
 
-from efgp_hip import NufftPlan, ToeplitzOp, cg_solve, cg_solve_async, cg_solve_mean_async, vdot_real, compute_device
+from efgp_hip import NufftPlan, PointSet, ToeplitzOp, cg_solve, cg_solve_async, cg_solve_mean_async, vdot_real, compute_device, rademacher_fill
 from efgp_hip.dist import PointShards
 
 TWO_PI = 2.0 * math.pi
@@ -363,7 +363,7 @@ def efgpnd_gradient_batched(
         log_marginal_probes=100, log_marginal_steps=25,
         probes_Z: Optional[torch.Tensor] = None, probes_V: Optional[torch.Tensor] = None,
         shards: Optional[PointShards] = None, trace_mode: str = "adjoint", probe_seed: Optional[int] = None,
-        domain_length: Optional[float] = None, y_norm_sq: Optional[float] = None):
+        domain_length: Optional[float] = None, y_norm_sq: Optional[float] = None, points: Optional[PointSet] = None):
     """d(negative log marginal likelihood)/d(kernel hypers..., sigma^2) = (term1 - term2)/2 with
     Hutchinson trace estimates (data-space probes Z for non-variance kernel hypers, feature-space
     probes V for the noise) and CG solves.  ``x0, x1`` are ignored as in the reference (:72-73).
@@ -433,8 +433,10 @@ def efgpnd_gradient_batched(
     # need the caller's nufft_eps (:186-189), i.e. a narrower window: a second plan over the same points (W^d LDS
     # operations per point: 3-D, eps 1e-4 vs 6e-8 is 216 vs 512 per channel).
     tight = min(float(nufft_eps), _CONV_TOL) if nufft_eps else _CONV_TOL
-    plan = NufftPlan(xd, grid.h, tight)
-    plan_p = plan if (not nufft_eps or float(nufft_eps) <= tight) else NufftPlan(xd, grid.h, float(nufft_eps))
+    if points is not None and (points.x.data_ptr() != xd.data_ptr() or points.npts != N_local):
+        points = None
+    plan = NufftPlan(xd, grid.h, tight, points=points)
+    plan_p = plan if (not nufft_eps or float(nufft_eps) <= tight) else NufftPlan(xd, grid.h, float(nufft_eps), points=points)
     lap("2_nufft_setup")
 
     # 3) Toeplitz operator, Jacobi diagonal (F*y rides in the same pass over the points) --------
@@ -490,9 +492,16 @@ def efgpnd_gradient_batched(
             FZ = plan_p.type1(Z, grid.shape).reshape(T, M)                            # real rows, two per pass
         elif adjoint:
             if probe_seed is None:
-                probe_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                probe_seed = shards.shared_seed(dev)              # one draw on rank 0: all shards use one Z stream
             offset = shards.exclusive_offset(N_local, dev)
             FZ = plan_p.type1_rademacher(probe_seed, T, grid.shape, index_offset=offset).reshape(T, M)
+        elif shards.active:
+            # sharded literal mode: Z[t, n] from (seed, t, GLOBAL index n) so the shards hold slices of one global
+            # probe matrix (per-rank torch generators would repeat or decorrelate blocks depending on their seeds)
+            if probe_seed is None:
+                probe_seed = shards.shared_seed(dev)
+            Z = rademacher_fill(dev, probe_seed, T, N_local, index_offset=shards.exclusive_offset(N_local, dev))
+            FZ = plan_p.type1(Z, grid.shape).reshape(T, M)
         else:
             Z = torch.empty((T, N_local), device=dev, dtype=torch.float64).bernoulli_(0.5).mul_(2).sub_(1)
             FZ = plan_p.type1(Z, grid.shape).reshape(T, M)
@@ -508,6 +517,7 @@ def efgpnd_gradient_batched(
         V = probes_V.detach().to(device=dev, dtype=torch.float64).contiguous()
     else:
         V = torch.empty((T, M), device=dev, dtype=torch.float64).bernoulli_(0.5).mul_(2).sub_(1)
+        shards.broadcast_(V)                                      # replicated solves need ONE draw (rank 0's)
     Vc = V.to(torch.complex128)
     B_n = ws * top.apply(ws * Vc)
     B_all = torch.cat((B_k, B_n), dim=0)
@@ -855,7 +865,10 @@ class EFGPND(nn.Module):
                 L = 1.0
             n_glob = int(self._shards.sum_scalars([xd.shape[0]], dev)[0]) if self._shards.active else xd.shape[0]
             yy = self._shards.sum_scalars([vdot_real(yd, yd)], dev)[0]          # global sum of y^2 (gradient, once)
-            self._devdata = dict(dev=dev, x=xd, y=yd, L=L, N=n_glob, yy=yy)
+            # the model's point layout: every plan of this model is made on it (grid-independent sorted copies for
+            # the type-1 pass, max|y| once per model)
+            pts = PointSet(xd, values=yd) if xd.shape[0] > 0 else None
+            self._devdata = dict(dev=dev, x=xd, y=yd, L=L, N=n_glob, yy=yy, points=pts)
         return self._devdata
 
     # -- gradient -----------------------------------------------------------------------------------
@@ -885,7 +898,7 @@ class EFGPND(nn.Module):
             use_trace_cg_preconditioner=self.opts.get("trace_cg_preconditioner", True),
             compute_log_marginal=compute_log_marginal, log_marginal_probes=log_marginal_probes,
             log_marginal_steps=log_marginal_steps, shards=self._shards, domain_length=dd["L"], y_norm_sq=dd["yy"],
-            **kwargs)
+            points=dd["points"], **kwargs)
         self._last_gradient_beta = stats.pop("mean_beta", None)
         self.last_gradient_stats = stats
         grads, log_marginal = res if compute_log_marginal else (res, None)
@@ -915,7 +928,7 @@ class EFGPND(nn.Module):
         cdtype = _cmplx(rdtype)
 
         grid = _Grid(self.kernel, self.eps, dd["L"], d, dev)
-        plan = NufftPlan(xd, grid.h, min(float(nufft_eps), _CONV_TOL))
+        plan = NufftPlan(xd, grid.h, min(float(nufft_eps), _CONV_TOL), points=dd["points"])
         Fy, v = _normal_equations(plan, yd, grid, self._shards)
         toeplitz = ToeplitzND(v, force_pow2=True)
         use_precond = self.opts.get("mean_cg_preconditioner", True)
@@ -980,6 +993,10 @@ class EFGPND(nn.Module):
         out_mean = mean.to(device=self.device, dtype=rdtype)
         t1 = time.perf_counter()
         if return_variance:
+            if variance_probes is None and self._shards.active and variance_method.lower() == "stochastic":
+                # replicas must estimate the SAME lag sums: rank 0's draw (reference draw: efgpnd.py:1644)
+                variance_probes = (torch.randint(0, 2, (hutchinson_probes, st["ws"].numel()), device=dev) * 2 - 1).to(torch.float64)
+                self._shards.broadcast_(variance_probes)
             A_var = create_A_var(st["ws"], self._toeplitz, st["sig"], torch.complex128)
             var = compute_prediction_variance(
                 x_new=xn, xis=self._xis.to(torch.float64), ws=st["ws"], A_var=A_var,

@@ -34,6 +34,7 @@ extern "C" {
 
 typedef struct efgp_nufft_s efgp_nufft_t;
 typedef struct efgp_toeplitz_s efgp_toeplitz_t;
+typedef struct efgp_points_s efgp_points_t;
 
 /* ---- library ---------------------------------------------------------------------------- */
 int efgp_version(void);                      /* 1000*major + minor */
@@ -69,6 +70,28 @@ int efgp_window_deconv(double tol, int64_t nf, int64_t n_modes, double* out);
 int efgp_nufft_create(efgp_nufft_t** plan_out, int device, int dim, int64_t npts, const double* x,
                       const double* xcen_host /* d doubles or NULL (=0) */, double h, double tol);
 int efgp_nufft_destroy(efgp_nufft_t* plan);
+
+/* ---- per-model point layout: replaces the reference's habit of keeping x, y on the model and rebuilding a NUFFT
+ * object over the SAME points at every hyper-parameter step (EFGPND.__init__, efgpnd.py:342,386-387; NUFFT.__init__,
+ * efgpnd.py:1432-1451; one per fit / gradient evaluation at :786 and :97-101).  The layout is made once per model:
+ * bounding box, and -- for d = 2, lazily, when a plan first needs it -- copies of the points sorted by a key that
+ * does not depend on the grid spacing (band of x_1, then x_0), which the type-1 pass streams and accumulates in MFMA
+ * register tiles (csrc/spread_mfma.hip).  `x` (npts, dim) row-major must stay valid and unchanged for the layout's
+ * lifetime; the layout must outlive the plans created on it.  Synchronises `stream` (host-side statistics). */
+int efgp_points_create(efgp_points_t** pts_out, int device, int dim, int64_t npts, const double* x, void* stream);
+int efgp_points_destroy(efgp_points_t* pts);
+/* bounding box of the points (dim HOST doubles each): what the reference computes with x.min / x.max for the
+ * domain length L (efgpnd.py:752-759) */
+int efgp_points_bounds(efgp_points_t* pts, double* lo_out, double* hi_out);
+/* Declares y (npts doubles, the model's targets, efgpnd.py:387) as this layout's value array: transforms on plans of
+ * this layout that are handed this very pointer as strengths (efgp_nufft_type1_pair, single-row efgp_nufft_type1)
+ * read a sorted copy kept by the layout, and max|y| (needed for the fixed-point accumulation) is computed here once
+ * instead of per transform.  y must stay unchanged while attached (attach again after changing it; NULL detaches). */
+int efgp_points_attach_values(efgp_points_t* pts, const double* y, void* stream);
+/* efgp_nufft_create for the points of a layout: same plan, same entry points; d = 2 type-1 transforms with window
+ * width <= 8 (tol >= ~6e-8) and enough points per fine-grid cell run on the sorted copies. */
+int efgp_nufft_create_on(efgp_nufft_t** plan_out, efgp_points_t* pts, const double* xcen_host /* d doubles or NULL */,
+                         double h, double tol);
 
 /* type 1 (points -> modes), replaces pff.finufft_type1(phi, vals, out_shape, eps, isign, modeord)
  * at efgpnd.py:1496-1499:
