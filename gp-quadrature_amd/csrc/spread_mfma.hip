@@ -24,15 +24,17 @@
 #include "spread_mfma.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace efgp {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMfmaRow = 66;                  // doubles per LDS row: 64 points + 2 (bank spread)
-constexpr int kMfmaWaves = 4;                 // waves per workgroup (independent)
-constexpr int kMfmaWaveDoubles = 32 * kMfmaRow + 32;   // A (16 rows) + B (16 rows) + 64 ints (x cell of every point)
-constexpr size_t kMfmaLdsBytes = (size_t)kMfmaWaves * kMfmaWaveDoubles * sizeof(double);
+constexpr int kMfmaMaxWaves = 4;              // waves per workgroup (independent; 3 or 4, chosen at launch)
+constexpr int kMfmaRows = 32;                 // A: (channel, x cell) 16 rows; B: y cell + offset, 16 rows
+constexpr int kMfmaWaveDoubles = kMfmaRows * kMfmaRow + 32;   // + 64 ints: x cell of every point
+static size_t mfma_lds_bytes(int waves) { return (size_t)waves * kMfmaWaveDoubles * sizeof(double); }
 
 struct MfmaSpreadArgs {
     const double* xs;
@@ -50,39 +52,79 @@ struct MfmaSpreadArgs {
     int channels;
     unsigned long long* gacc;
     const double* scale;
+    int diag;                  // diagnostics (EFGP_MFMA_DIAG): 1 skips the MFMA phase, 2 the window polynomials, 4 the LDS writes
 };
 
-// Window values of both dimensions from the offsets s in [-1, 1): symmetric Horner (see window_eval).  The
-// coefficients of one degree (ceil(W/2) doubles, scalar loads) are fetched one iteration ahead: with two waves per
-// SIMD a scalar-cache round trip per degree would otherwise sit in the dependent chain of every batch.
-template <int W>
-__device__ __forceinline__ void horner2(const double* __restrict__ coef_generic, int degree, double s0, double s1,
-                                        double (&v0)[W], double (&v1)[W]) {
-    constexpr int RH = (W + 1) / 2, RHP = sym_row(W);
-    const_coef_ptr coef = (const_coef_ptr)(coef_generic + (kMaxDegree + 1) * W);
-    double p0[RH], m0[RH], p1[RH], m1[RH], c[RH], cn[RH];
+// Window values of both dimensions from the offsets s in [-1, 1): symmetric Horner (see window_eval).
+// DEG > 0: the degree is a compile-time constant and the ceil(W/2) x (DEG + 1) coefficients live in VGPRs for the
+// whole kernel (loaded once per wave).  Measured alternatives at N = 1e7 (Horner share of the launch): scalar loads
+// per degree (as window_eval does) 65 us -- with two waves per SIMD the scalar-cache round trips sit in the dependent
+// chain of every batch; a table in LDS read by broadcast 68 us (the compiler keeps the reads one step ahead only);
+// registers 37 us.  DEG == 0: run-time degree through scalar loads (uncommon degrees).
+template <int W, int DEG>
+struct WindowCoef {
+    static constexpr int RH = (W + 1) / 2, RHP = sym_row(W);
+    double cf[DEG > 0 ? (DEG + 1) * RH : 1];
+    __device__ __forceinline__ void load(const double* __restrict__ coef_generic) {
+        if (DEG > 0) {
+            // a zero the compiler cannot see through: the loads become per-lane (vector) loads and the values stay in
+            // VGPRs; as provably uniform values they would be allocated to SGPRs and spilled (79 spills measured)
+            int z;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+            const double* t = coef_generic + (kMaxDegree + 1) * W + z;
 #pragma unroll
-    for (int j = 0; j < RH; ++j) {
-        const double top = coef[degree * RHP + j];
-        p0[j] = top;
-        m0[j] = top;
-        p1[j] = top;
-        m1[j] = top;
-        c[j] = coef[(degree - 1) * RHP + j];
+            for (int k = 0; k <= DEG; ++k)
+#pragma unroll
+                for (int j = 0; j < RH; ++j) cf[k * RH + j] = t[k * RHP + j];
+        }
     }
-    for (int k = degree - 1; k >= 0; --k) {
-        const int kn = k > 0 ? k - 1 : 0;
-#pragma unroll
-        for (int j = 0; j < RH; ++j) cn[j] = coef[kn * RHP + j];
+};
+
+template <int W, int DEG>
+__device__ __forceinline__ void horner2(const WindowCoef<W, DEG>& wc, const double* __restrict__ coef_generic, int degree, double s0,
+                                        double s1, double (&v0)[W], double (&v1)[W]) {
+    constexpr int RH = (W + 1) / 2, RHP = sym_row(W);
+    double p0[RH], m0[RH], p1[RH], m1[RH];
+    if (DEG > 0) {
 #pragma unroll
         for (int j = 0; j < RH; ++j) {
-            p0[j] = fma(p0[j], s0, c[j]);
-            m0[j] = fma(m0[j], -s0, c[j]);
-            p1[j] = fma(p1[j], s1, c[j]);
-            m1[j] = fma(m1[j], -s1, c[j]);
+            const double top = wc.cf[DEG * RH + j];
+            p0[j] = top;
+            m0[j] = top;
+            p1[j] = top;
+            m1[j] = top;
         }
 #pragma unroll
-        for (int j = 0; j < RH; ++j) c[j] = cn[j];
+        for (int k = DEG - 1; k >= 0; --k) {
+#pragma unroll
+            for (int j = 0; j < RH; ++j) {
+                const double c = wc.cf[k * RH + j];
+                p0[j] = fma(p0[j], s0, c);
+                m0[j] = fma(m0[j], -s0, c);
+                p1[j] = fma(p1[j], s1, c);
+                m1[j] = fma(m1[j], -s1, c);
+            }
+        }
+    } else {
+        const_coef_ptr coef = (const_coef_ptr)(coef_generic + (kMaxDegree + 1) * W);
+#pragma unroll
+        for (int j = 0; j < RH; ++j) {
+            const double top = coef[degree * RHP + j];
+            p0[j] = top;
+            m0[j] = top;
+            p1[j] = top;
+            m1[j] = top;
+        }
+        for (int k = degree - 1; k >= 0; --k) {
+#pragma unroll
+            for (int j = 0; j < RH; ++j) {
+                const double c = coef[k * RHP + j];
+                p0[j] = fma(p0[j], s0, c);
+                m0[j] = fma(m0[j], -s0, c);
+                p1[j] = fma(p1[j], s1, c);
+                m1[j] = fma(m1[j], -s1, c);
+            }
+        }
     }
 #pragma unroll
     for (int j = 0; j < RH; ++j) {
@@ -121,10 +163,13 @@ struct PointIn {
     double c0, c1;
 };
 
+// SORTED: strengths come from the level-ordered copy (the fit-time (y, 1) pair or y alone): two coalesced loads and
+// no strength-mode dispatch in the hot loop.
+template <bool SORTED>
 __device__ __forceinline__ PointIn load_point(const MfmaSpreadArgs& a, int batch, int p) {
     PointIn r;
     r.xy = reinterpret_cast<const double2*>(a.xs)[p];
-    if (a.ys) {
+    if (SORTED) {
         r.c0 = a.ys[p];
         r.c1 = 1.0;
     } else {
@@ -133,13 +178,15 @@ __device__ __forceinline__ PointIn load_point(const MfmaSpreadArgs& a, int batch
     return r;
 }
 
-template <int W>
-__global__ __launch_bounds__(64 * kMfmaWaves, 2) void spread_mfma_kernel(MfmaSpreadArgs a) {
+template <int W, int DEG, bool SORTED>
+__global__ __launch_bounds__(64 * kMfmaMaxWaves, 2) void spread_mfma_kernel(MfmaSpreadArgs a) {
     extern __shared__ double lds_raw[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
     double* A = lds_raw + (size_t)wave * kMfmaWaveDoubles;
     double* B = A + 16 * kMfmaRow;
-    int* bxs = reinterpret_cast<int*>(A + 32 * kMfmaRow);
+    int* bxs = reinterpret_cast<int*>(A + kMfmaRows * kMfmaRow);
+    WindowCoef<W, DEG> wc;
+    wc.load(a.coef);
     const int batch = blockIdx.y;
     const int nf0 = a.nf0, nf1 = a.nf1;
     const int64_t cells = (int64_t)nf0 * nf1;
@@ -155,7 +202,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void spread_mfma_kernel(MfmaSpr
     }
     const double* Ard = A + c16 * kMfmaRow + q;   // this lane's operand elements of step g: Ard[4 g], Brd[4 g]
     const double* Brd = B + c16 * kMfmaRow + q;
-    for (int chunk = blockIdx.x * kMfmaWaves + wave; chunk < a.nchunks; chunk += a.total_waves) {
+    for (int chunk = blockIdx.x * nwaves + wave; chunk < a.nchunks; chunk += a.total_waves) {
         const int4 ci = reinterpret_cast<const int4*>(a.chunks)[chunk];
         const int start = __builtin_amdgcn_readfirstlane(ci.x), count = __builtin_amdgcn_readfirstlane(ci.y);
         const int band = __builtin_amdgcn_readfirstlane(ci.z);
@@ -163,14 +210,14 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void spread_mfma_kernel(MfmaSpr
         const int ycell = pos_mod(by0 + c16, nf1);
         d4 acc = {0.0, 0.0, 0.0, 0.0};
         int cur_bx = 0;
-        PointIn nxt = load_point(a, batch, start + (lane < count ? lane : count - 1));
+        PointIn nxt = load_point<SORTED>(a, batch, start + (lane < count ? lane : count - 1));
         for (int b0 = 0; b0 < count; b0 += 64) {
             const int rem = count - b0;                                       // wave-uniform
             const bool valid = lane < rem;
             const PointIn cur = nxt;
             if (rem > 64) {                                                   // next batch's loads fly during this one
                 const int r2 = rem - 64;
-                nxt = load_point(a, batch, start + b0 + 64 + (lane < r2 ? lane : r2 - 1));
+                nxt = load_point<SORTED>(a, batch, start + b0 + 64 + (lane < r2 ? lane : r2 - 1));
             }
             double c0 = cur.c0, c1 = a.channels == 1 ? 0.0 : cur.c1;
             if (!valid) {                                                     // tail lanes repeat the last point with zero strength
@@ -180,17 +227,29 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void spread_mfma_kernel(MfmaSpr
             const double X0 = a.scale0 * (cur.xy.x - a.xcen0), X1 = a.scale1 * (cur.xy.y - a.xcen1);
             const double i0 = ceil(X0 - 0.5 * W), j0 = ceil(X1 - 0.5 * W);
             double v0[W], v1[W];
-            horner2<W>(a.coef, a.degree, 2.0 * (i0 - X0 + 0.5 * W) - 1.0, 2.0 * (j0 - X1 + 0.5 * W) - 1.0, v0, v1);
-            const int bx = (int)i0, off = (int)j0 - by0;                      // 0 <= off <= 8 (bands are at most 8 cells high)
+            if (a.diag & 2) {
 #pragma unroll
-            for (int i = 0; i < W; ++i) {
-                A[i * kMfmaRow + lane] = c0 * v0[i];
-                A[(8 + i) * kMfmaRow + lane] = c1 * v0[i];
-                B[(off + i) * kMfmaRow + lane] = v1[i];
+                for (int i = 0; i < W; ++i) {
+                    v0[i] = X0 + i;
+                    v1[i] = X1 - i;
+                }
+            } else {
+                horner2<W, DEG>(wc, a.coef, a.degree, 2.0 * (i0 - X0 + 0.5 * W) - 1.0, 2.0 * (j0 - X1 + 0.5 * W) - 1.0, v0, v1);
             }
+            const int bx = (int)i0, off = (int)j0 - by0;                      // 0 <= off <= 8 (bands are at most 8 cells high)
+            if (!(a.diag & 4)) {
 #pragma unroll
-            for (int i = 0; i < 16 - W; ++i)                                  // the 16 - W columns outside [off, off + W) are zero
-                B[((i < off) ? i : i + W) * kMfmaRow + lane] = 0.0;
+                for (int i = 0; i < W; ++i) {
+                    A[i * kMfmaRow + lane] = c0 * v0[i];
+                    A[(8 + i) * kMfmaRow + lane] = c1 * v0[i];
+                    B[(off + i) * kMfmaRow + lane] = v1[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 16 - W; ++i)                              // the 16 - W columns outside [off, off + W) are zero
+                    B[((i < off) ? i : i + W) * kMfmaRow + lane] = 0.0;
+            } else {
+                acc[0] += v0[0] * c0 + v1[W - 1] * c1 + v0[W / 2] + v1[W / 2];
+            }
             bxs[lane] = bx;
             if (b0 == 0) cur_bx = __builtin_amdgcn_readfirstlane(bx);
             int prev = __shfl_up(bx, 1, 64);
@@ -198,8 +257,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void spread_mfma_kernel(MfmaSpr
             const unsigned long long mask = __ballot(bx != prev);              // run starts inside this batch
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (mask == 0ull && rem >= 64) {
-                // whole batch continues the current run: 16 operand pairs read up front, 16 back-to-back MFMAs
+            if (a.diag & 1) {
+                acc[1] += A[lane] + B[lane];
+            } else if (mask == 0ull && rem >= 64) {
+                // whole batch continues the current run: 16 operand pairs, 16 back-to-back MFMAs, no branches
                 double av[16], bv[16];
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
@@ -235,8 +296,25 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void spread_mfma_kernel(MfmaSpr
 }
 
 template <int W>
-static hipError_t launch_w(dim3 grid, hipStream_t s, const MfmaSpreadArgs& a) {
-    hipLaunchKernelGGL((spread_mfma_kernel<W>), grid, dim3(64 * kMfmaWaves), kMfmaLdsBytes, s, a);
+static hipError_t launch_w(dim3 grid, int waves, hipStream_t s, const MfmaSpreadArgs& a) {
+    const bool fixed_deg = a.degree == W + 1;          // what es_make_params picks for every standard tolerance
+    const bool sorted = a.ys != nullptr;
+    const size_t lds = mfma_lds_bytes(waves);
+    const dim3 block(64 * waves);
+#define EFGP_GO(deg_, sorted_)                                                                                       \
+    do {                                                                                                             \
+        auto k = spread_mfma_kernel<W, deg_, sorted_>;                                                               \
+        if (lds > 65536) {                                                                                           \
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                           \
+        }                                                                                                            \
+        hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                               \
+    } while (0)
+    if (fixed_deg && sorted) EFGP_GO(W + 1, true);
+    else if (fixed_deg) EFGP_GO(W + 1, false);
+    else if (sorted) EFGP_GO(0, true);
+    else EFGP_GO(0, false);
+#undef EFGP_GO
     return hipGetLastError();
 }
 
@@ -265,14 +343,20 @@ int spread_mfma_launch(DeviceCtx* ctx, const SortedLevel* lvl, const double* ys_
     a.channels = channels;
     a.gacc = gacc;
     a.scale = scale;
-    // two workgroups (8 waves) per CU; a wave strides over the chunks (points_layout.hip sizes them for this)
-    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)lvl->nchunks + kMfmaWaves - 1) / kMfmaWaves, (int64_t)ctx->num_cu * 2));
-    a.total_waves = blocks * kMfmaWaves;
+    // Two workgroups of four waves per CU (176 VGPRs and 16.9 KB of LDS rows per wave: two waves per SIMD); a wave strides
+    // over the chunks (points_layout.hip sizes them for 8 waves per CU and several rounds).  Measured at N = 1e7:
+    // 4 x 2 221 us, 3 x 3 (LDS table) 270 us, 1 x 9 265 us.
+    int waves = 4, per_cu = 2;
+    if (const char* e1 = std::getenv("EFGP_MFMA_WAVES")) waves = std::max(1, std::min(kMfmaMaxWaves, std::atoi(e1)));
+    if (const char* e2 = std::getenv("EFGP_MFMA_BLOCKS_PER_CU")) per_cu = std::max(1, std::atoi(e2));
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)lvl->nchunks + waves - 1) / waves, (int64_t)ctx->num_cu * per_cu));
+    a.total_waves = blocks * waves;
+    a.diag = std::getenv("EFGP_MFMA_DIAG") ? std::atoi(std::getenv("EFGP_MFMA_DIAG")) : 0;
     hipError_t e;
     {
         KernelTimer timer("spread", stream);
         switch (W) {
-#define EFGP_CASE(w_) case w_: e = launch_w<w_>(dim3(blocks, nbatch), stream, a); break;
+#define EFGP_CASE(w_) case w_: e = launch_w<w_>(dim3(blocks, nbatch), waves, stream, a); break;
             EFGP_CASE(2) EFGP_CASE(3) EFGP_CASE(4) EFGP_CASE(5) EFGP_CASE(6) EFGP_CASE(7) EFGP_CASE(8)
 #undef EFGP_CASE
             default: e = hipErrorInvalidValue;
