@@ -11,13 +11,17 @@ Toeplitz FFT 64^2), NUFFT tol 1e-7, CG tol 1e-4 (the reference's default).
 One step = one GP fit + posterior mean at the training points:
   grid construction (host) -> ONE fused spread pass over the points for (F*y, Toeplitz vector) ->
   rocFFT + deconvolve -> Toeplitz setup -> Jacobi-PCG to tolerance -> type-2 interpolation at x.
-Inputs are resident in HBM before the timed region.  With N GPUs every rank holds its own 1e6
-points (weak scaling: global N = n_gpus * 1e6), the gridded partial sums are all-reduced (RCCL) and
-CG is replicated; `value` counts 1e6-point fit equivalents per second, i.e. n_gpus * fits/s.
+Inputs are resident in HBM before the timed region.  With N GPUs the metric's GLOBAL problem (N = 1e6 points)
+is sharded over the ranks (strong scaling: every rank holds N / n_gpus points, the gridded partial sums are
+all-reduced over RCCL, CG is replicated) and `value` is the true fits/s of that global problem.  Extra keys:
+`weak_scaling` (1e6 points PER rank, fits/s of the n_gpus x 1e6 problem) and `north_star_n1e7` (the
+north_star's N = 1e7, d = 2 configuration: spread / gather / ordering microseconds per launch and their
+fractions of the HBM peak; global N = 1e7 sharded over the ranks = BASELINE configs[3]).
 
 The JSON line also carries `roofline` for the dominant N-scale kernel (the fused spread launch,
 timed with HIP events on its launch stream inside the library) and `cpu_baseline` (the CPU oracle
-of oracle/efgp_oracle.py timed on this box's host cores on a bounded sample; rank 0, N=1 only).
+of oracle/efgp_oracle.py timed on this box's host cores on a bounded sample, with 1 thread and with
+all threads of the box's share; rank 0, N=1 only).
 """
 import argparse
 import json
@@ -51,31 +55,100 @@ def synth(N, d, seed, device):
 
 
 def cpu_baseline(seed):
-    """CPU oracle (port of the reference algorithm, exact NUDFT) on a bounded sample."""
+    """CPU oracle (port of the reference algorithm, exact NUDFT) on a bounded sample: the full step with all threads
+    of this box's share, and a 1-thread leg on a tenth of the points (SURVEY 8d asks for k in {1, all})."""
     from oracle import efgp_oracle as O
     # a one-GPU box owns a 16-core share of the host; more threads only oversubscribe it
     ncores = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(ncores)
-    Ns = N_PER_GPU                  # the whole workload: the separable exact NUDFT takes a few seconds at N = 1e6
-    x, y = synth(Ns, DIM, seed, "cpu")
     kern = O.KernelSpec("se", DIM, LS, VAR)
-    t0 = time.perf_counter()
-    fit = O.fit(x, y, kern, SIG2, EPS, cg_tol=CG_TOL)
-    t1 = time.perf_counter()
-    O.predict_mean(fit, x)
-    t2 = time.perf_counter()
-    # CG iteration rate of the oracle's loop on the same operator
-    A = O.make_A_mean(fit.ws, fit.T, SIG2)
-    diag = O.jacobi_diag(fit.ws, SIG2, float(Ns))
-    t3 = time.perf_counter()
-    _, its = O.cg_single(A, fit.rhs, torch.zeros_like(fit.rhs), 1e-30, max_iter=200, diag=diag)
-    t4 = time.perf_counter()
+
+    def one(Ns, threads):
+        torch.set_num_threads(threads)
+        x, y = synth(Ns, DIM, seed, "cpu")
+        t0 = time.perf_counter()
+        fit = O.fit(x, y, kern, SIG2, EPS, cg_tol=CG_TOL)
+        t1 = time.perf_counter()
+        O.predict_mean(fit, x)
+        t2 = time.perf_counter()
+        A = O.make_A_mean(fit.ws, fit.T, SIG2)
+        diag = O.jacobi_diag(fit.ws, SIG2, float(Ns))
+        t3 = time.perf_counter()
+        _, its = O.cg_single(A, fit.rhs, torch.zeros_like(fit.rhs), 1e-30, max_iter=200, diag=diag)
+        t4 = time.perf_counter()
+        return dict(fit_s=t1 - t0, mean_s=t2 - t1, iters=fit.iters, cg_iters_per_s=its / (t4 - t3))
+
+    Ns = N_PER_GPU                  # the whole workload: the separable exact NUDFT takes a few seconds at N = 1e6
+    full = one(Ns, ncores)
+    n1 = Ns // 10
+    single = one(n1, 1)
+    torch.set_num_threads(ncores)
     return {
-        "value": 1.0 / (t2 - t0), "unit": "GP-fits/s (fit + mean at the N points, N=1e6)", "cores": ncores, "kind": "port",
-        "sample": f"the full N={Ns} workload, same kernel/eps, one step: fit {t1 - t0:.2f}s ({fit.iters} CG iterations) + mean at "
-                  f"N points {t2 - t1:.2f}s (exact-NUDFT oracle, torch CPU, {ncores} threads)",
-        "cg_iters_per_s": its / (t4 - t3),
+        "value": 1.0 / (full["fit_s"] + full["mean_s"]), "unit": "GP-fits/s (fit + mean at the N points, N=1e6)", "cores": ncores,
+        "kind": "port",
+        "sample": f"the full N={Ns} workload, same kernel/eps, one step: fit {full['fit_s']:.2f}s ({full['iters']} CG iterations) + mean "
+                  f"at N points {full['mean_s']:.2f}s (exact-NUDFT oracle, torch CPU, {ncores} threads)",
+        "cg_iters_per_s": full["cg_iters_per_s"],
+        "one_thread": {"cores": 1, "sample": f"N={n1} (a tenth of the points), one step: fit {single['fit_s']:.2f}s + mean "
+                                             f"{single['mean_s']:.2f}s",
+                       "fits_per_s_scaled_to_n1e6": (n1 / Ns) / (single["fit_s"] + single["mean_s"]),
+                       "cg_iters_per_s": single["cg_iters_per_s"]},
     }
+
+
+def north_star(dev, rank, world, distributed, barrier):
+    """The north_star configuration (N = 1e7, d = 2, SE): microseconds per launch of the N-scale kernels of one
+    fit + mean step, HIP events inside the library.  `ordering_us` = per-step ordering passes (none: the point layout
+    is built once per model, its cost is reported as `layout_once_ms`)."""
+    from efgpnd import EFGPND
+    from efgp_hip import kernel_timing, kernel_timing_read
+    from kernels.squared_exponential import SquaredExponential
+    NG = 10_000_000
+    n_loc = NG // world + (1 if rank < NG % world else 0)
+    x, y = synth(n_loc, DIM, 2000 + rank, dev)
+    kern = SquaredExponential(dimension=DIM, init_lengthscale=LS, init_variance=VAR)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    model = EFGPND(x, y, kern, sigmasq=SIG2, eps=EPS, nufft_eps=NUFFT_TOL, estimate_params=False,
+                   opts={"cg_tolerance": CG_TOL, "mean_cg_warm_start": False, "shard_points": distributed})
+    model._compute_common_parameters(force_recompute=True)
+    model.predict(x, return_variance=False)
+    torch.cuda.synchronize(dev)
+    first_ms = 1e3 * (time.perf_counter() - t0)
+
+    def step():
+        model._compute_common_parameters(force_recompute=True)
+        return model.predict(x, return_variance=False)[0]
+    for _ in range(2):
+        step()
+    barrier()
+    kernel_timing(True)
+    reps = 10
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    barrier()
+    el = time.perf_counter() - t1
+    sp_ms, sp_n = kernel_timing_read("spread")
+    ip_ms, ip_n = kernel_timing_read("interp")
+    od_ms, od_n = kernel_timing_read("order")
+    kernel_timing(False)
+    if distributed:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    spread_us = 1e3 * sp_ms / max(sp_n, 1)
+    gather_us = 1e3 * ip_ms / max(ip_n, 1)
+    order_us = 1e3 * od_ms / reps
+    total_us = spread_us + gather_us + order_us
+    survey_bytes = 3 * n_loc * (8 * DIM + 16)        # SURVEY 8(d): N(8d+16) per transform, two in the fused spread + one gather
+    actual_bytes = 2 * n_loc * (8 * DIM + 8)         # x + real y read / x read + real mean written
+    del model
+    return {"global_n": NG, "n_per_gpu": n_loc, "ms_per_step": 1e3 * el / reps, "fits_per_s": reps / el,
+            "spread_us": spread_us, "gather_us": gather_us, "ordering_us": order_us, "sum_us": total_us,
+            "first_fit_and_layout_ms": first_ms,
+            "frac_hbm_survey_bytes": survey_bytes / (total_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "frac_hbm_actual_bytes": actual_bytes / (total_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "survey_bytes": survey_bytes, "actual_bytes": actual_bytes}
 
 
 def main():
@@ -83,7 +156,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n-per-gpu", type=int, default=N_PER_GPU)
+    ap.add_argument("--global-n", type=int, default=N_PER_GPU, help="points of the GLOBAL problem, sharded over the ranks")
+    ap.add_argument("--no-extras", action="store_true", help="skip the weak-scaling and north-star legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--main-only", action="store_true",
                     help="timed steps only (no CG-rate / gradient / CPU-baseline extras): for rocprofv3 --pmc passes, so "
@@ -107,7 +181,8 @@ def main():
     from efgp_hip import cg_solve, kernel_timing, kernel_timing_read
     from kernels.squared_exponential import SquaredExponential
 
-    N = args.n_per_gpu
+    NG = args.global_n
+    N = NG // world + (1 if rank < NG % world else 0)          # strong scaling: this rank's block of the global problem
     x, y = synth(N, DIM, 1000 + rank, dev)
     kern = SquaredExponential(dimension=DIM, init_lengthscale=LS, init_variance=VAR)
     model = EFGPND(x, y, kern, sigmasq=SIG2, eps=EPS, nufft_eps=NUFFT_TOL, estimate_params=False,
@@ -147,7 +222,7 @@ def main():
 
     if args.main_only:
         if rank == 0:
-            print(json.dumps({"metric": "GP-fits/sec (main-only profiling run)", "value": fits_per_s * world,
+            print(json.dumps({"metric": "GP-fits/sec (main-only profiling run)", "value": fits_per_s,
                               "ms_per_step": ms_per_step, "steps": args.steps, "warmup": args.warmup, "n_gpus": world}))
         if distributed:
             dist.barrier()
@@ -163,7 +238,7 @@ def main():
     fit_only_ms = 1e3 * (time.perf_counter() - t1) / 5
     st = model._fit_state
     rhs = st["ws"] * st["Fy"]
-    diag = (float(N * world) * st["ws"].abs().pow(2).real + SIG2)
+    diag = (float(NG) * st["ws"].abs().pow(2).real + SIG2)
     cg_solve(model._toeplitz._op, st["ws"], SIG2, 0, rhs, torch.zeros_like(rhs), 1e-30, max_iter=50, diag=diag, batched=False)
     torch.cuda.synchronize(dev)
     t2 = time.perf_counter()
@@ -194,6 +269,32 @@ def main():
     barrier()
     grad_step_ms = 1e3 * sorted(gts)[len(gts) // 2]
 
+    # extra legs (every rank takes part: they contain collectives)
+    weak = None
+    star = None
+    if not args.no_extras:
+        if distributed:      # weak scaling: 1e6 points PER rank, fits/s of the n_gpus x 1e6 problem (at one GPU = the headline run)
+            del model
+            xw, yw = synth(N_PER_GPU, DIM, 3000 + rank, dev)
+            mw = EFGPND(xw, yw, SquaredExponential(dimension=DIM, init_lengthscale=LS, init_variance=VAR), sigmasq=SIG2, eps=EPS,
+                        nufft_eps=NUFFT_TOL, estimate_params=False,
+                        opts={"cg_tolerance": CG_TOL, "mean_cg_warm_start": False, "shard_points": True})
+            for _ in range(3):
+                mw._compute_common_parameters(force_recompute=True)
+                mw.predict(xw, return_variance=False)
+            barrier()
+            tw = time.perf_counter()
+            for _ in range(args.steps):
+                mw._compute_common_parameters(force_recompute=True)
+                mw.predict(xw, return_variance=False)
+            barrier()
+            elw = torch.tensor([time.perf_counter() - tw], dtype=torch.float64, device=dev)
+            dist.all_reduce(elw, op=dist.ReduceOp.MAX)
+            weak = {"n_per_gpu": N_PER_GPU, "global_n": N_PER_GPU * world, "fits_per_s": args.steps / float(elw.item()),
+                    "ms_per_step": 1e3 * float(elw.item()) / args.steps}
+            del mw, xw, yw
+        star = north_star(dev, rank, world, distributed, barrier)
+
     if rank == 0:
         m = (mtot - 1) // 2
         out_bytes = 16 * (mtot ** DIM + (4 * m + 1) ** DIM)
@@ -202,7 +303,7 @@ def main():
         spread_avg_s = (spread_ms / max(spread_n, 1)) * 1e-3
         achieved = spread_bytes / spread_avg_s / 1e9 if spread_n else None
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "round1_spread_pmc.json")
+        tpath = os.path.join(ROOT, "profiles", "r2_spread_pmc.json")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
@@ -215,22 +316,23 @@ def main():
         cg_bytes = 16 * (ftot + 8 * mtot ** DIM) * mean_iters        # fused-ideal bytes per iteration
         rec = {
             "metric": "GP-fits/sec (fit + posterior mean at the N training points), N=1e6 d=2 SE kernel",
-            "value": fits_per_s * world,
-            "unit": "1e6-point GP fits/s (whole job: n_gpus x fits/s, each fit over global N = n_gpus x 1e6)",
+            "value": fits_per_s,
+            "unit": "GP fits/s of the global N=1e6 problem (whole job; the points are sharded over the GPUs)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "2D squared-exponential l=0.2 var=2 sigma2=0.2, eps=1e-4, N=1e6 per GPU synthetic "
-                                   "(BASELINE configs[1] at the metric's N=1e6)",
-                       "n_per_gpu": N, "global_n": N * world, "d": DIM, "mtot": mtot, "M": mtot ** DIM,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "2D squared-exponential l=0.2 var=2 sigma2=0.2, eps=1e-4, global N=1e6 synthetic "
+                                   "(BASELINE configs[1] at the metric's N=1e6), points sharded over the GPUs",
+                       "n_per_gpu": N, "global_n": NG, "d": DIM, "mtot": mtot, "M": mtot ** DIM,
                        "nufft_tol": NUFFT_TOL, "cg_tol": CG_TOL, "mean_cg_iters": mean_iters,
                        "parallelism": f"points sharded over {world} GPU(s), CG replicated"},
             "fit_only_ms": fit_only_ms,
             "cg_iter_per_s": cg_iter_per_s,
             "cg_us_per_iter": 1e6 / cg_iter_per_s,
             "cg_rhs_iter_per_s_batch64": cg_rhs_iter_per_s,
-            "points_per_s": N * world * fits_per_s,
+            "points_per_s": NG * fits_per_s,
             "gradient_step_ms_T5": grad_step_ms,
-            "roofline": {"bound": "hbm", "kernel": "spread_kernel (fused F*y + Toeplitz-vector pass, LDS-resident fine grid)",
+            "roofline": {"bound": "hbm", "kernel": "spread_mfma_kernel (fused F*y + Toeplitz-vector pass over the per-model sorted "
+                                             "point layout, MFMA register tiles)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "bytes_per_launch": spread_bytes, "avg_launch_us": spread_avg_s * 1e6, "launches": spread_n,
@@ -246,6 +348,10 @@ def main():
                          "frac_hbm": cg_bytes / (1e-3 * cgs_ms / max(cgs_n, 1)) / 1e9 / HBM_PEAK_GBS if cgs_n else None,
                          "share_of_step": (cgs_ms / max(cgs_n, 1)) / ms_per_step if cgs_n else None},
         }
+        if weak is not None:
+            rec["weak_scaling"] = weak
+        if star is not None:
+            rec["north_star_n1e7"] = star
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(1000)
         print(json.dumps(rec))

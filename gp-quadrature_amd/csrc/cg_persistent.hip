@@ -80,6 +80,15 @@ struct Args {
     const double2* b;
     double2* x;              // in: x0, out: solution
     int* iters;              // per row
+    double* hist;            // diagnostic: row 0's |r_i| / |b| per iteration (efgp_cg_record_history) or null
+    int hist_cap;
+    // Lanczos mode (efgp_lanczos; reference: logdet_slq, efgpnd.py:1716-1738): lz_steps > 0 runs that many three-term
+    // recurrence steps on A (variant as given) from q_0 = b / |b| instead of the CG loop; row r's alpha_k, beta_k go to
+    // lz_alpha / lz_beta [r * lz_steps + k], |b|^2 to lz_norm2[r], the number of steps taken to iters[r]
+    int lz_steps;
+    double* lz_alpha;
+    double* lz_beta;
+    double* lz_norm2;
 #ifdef EFGP_CG_STAMPS
     long long* stamps;       // diagnostic build only: cycles per phase class, accumulated by block 0
 #endif
@@ -374,6 +383,60 @@ __device__ __forceinline__ int grid_offset(const Geom& g, int flat, int shift) {
     return off;
 }
 
+// Lanczos three-term recurrence inside the persistent kernels (shared by both): no launch and no host round trip per step
+// (the host loop it replaces made two device->host reads per step: 100 probes x 25 steps x 2 at the defaults).
+#define EFGP_LANCZOS_BRANCH(NS_, TID_)                                                                          \
+    if (a.lz_steps > 0) {                                                                                       \
+        double2 q[NS_], qp[NS_], vv[NS_];                                                                       \
+        double nb = 0.0;                                                                                        \
+        _Pragma("unroll") for (int s = 0; s < NS_; ++s) {                                                       \
+            const int t = TID_ + s * kThreads;                                                                  \
+            q[s] = t < M ? a.b[base + t] : make_double2(0.0, 0.0);                                              \
+            qp[s] = make_double2(0.0, 0.0);                                                                     \
+            nb += q[s].x * q[s].x + q[s].y * q[s].y;                                                            \
+        }                                                                                                       \
+        nb = block_sum2(nb, red);                                                                               \
+        const double inv_nb = nb > 0.0 ? 1.0 / sqrt(nb) : 0.0;                                                  \
+        _Pragma("unroll") for (int s = 0; s < NS_; ++s) q[s] = make_double2(q[s].x * inv_nb, q[s].y * inv_nb);  \
+        double beta_prev = 0.0;                                                                                 \
+        int k = 0;                                                                                              \
+        while (k < a.lz_steps) {                                                                                \
+            apply_A(q, vv);                                                                                     \
+            double al = 0.0;                                                                                    \
+            _Pragma("unroll") for (int s = 0; s < NS_; ++s) {                                                   \
+                vv[s].x -= beta_prev * qp[s].x;                                                                 \
+                vv[s].y -= beta_prev * qp[s].y;                                                                 \
+                al += q[s].x * vv[s].x + q[s].y * vv[s].y;                                                      \
+            }                                                                                                   \
+            al = block_sum2(al, red);                                                                           \
+            double bt = 0.0, unused = 0.0;                                                                      \
+            _Pragma("unroll") for (int s = 0; s < NS_; ++s) {                                                   \
+                vv[s].x -= al * q[s].x;                                                                         \
+                vv[s].y -= al * q[s].y;                                                                         \
+                bt += vv[s].x * vv[s].x + vv[s].y * vv[s].y;                                                    \
+            }                                                                                                   \
+            block_sum_pair(bt, unused, red);                                                                    \
+            bt = sqrt(bt);                                                                                      \
+            if (TID_ == 0) {                                                                                    \
+                a.lz_alpha[(int64_t)row * a.lz_steps + k] = al;                                                 \
+                a.lz_beta[(int64_t)row * a.lz_steps + k] = bt;                                                  \
+            }                                                                                                   \
+            ++k;                                                                                                \
+            if (bt < 1e-12) break;                                                                              \
+            const double ib = 1.0 / bt;                                                                         \
+            _Pragma("unroll") for (int s = 0; s < NS_; ++s) {                                                   \
+                qp[s] = q[s];                                                                                   \
+                q[s] = make_double2(vv[s].x * ib, vv[s].y * ib);                                                \
+            }                                                                                                   \
+            beta_prev = bt;                                                                                     \
+        }                                                                                                       \
+        if (TID_ == 0) {                                                                                        \
+            a.iters[row] = k;                                                                                   \
+            if (a.lz_norm2) a.lz_norm2[row] = nb;                                                               \
+        }                                                                                                       \
+        return;                                                                                                 \
+    }
+
 __global__ __launch_bounds__(kThreads) void cg_persistent_kernel(Args a) {
     extern __shared__ double2 lds2[];
     __shared__ double red[3 * kRedWaves];
@@ -485,6 +548,8 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_kernel(Args a) {
         EFGP_STAMP(8);
     };
 
+    EFGP_LANCZOS_BRANCH(kSlots, (int)threadIdx.x)
+
     // r = b - A x0, z = r / diag, p = z
     double2 Ap[kSlots];
     if (a.zero_x0) {
@@ -533,6 +598,7 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_kernel(Args a) {
         block_sum_pair(rr, rzn, red);
         ++it;
         const double rnorm = sqrt(rr);
+        if (a.hist && row == 0 && threadIdx.x == 0 && it <= a.hist_cap) a.hist[it - 1] = rnorm / (den + 1e-16);
         const bool conv = a.early_stop && ((rnorm / (den + 1e-16) < a.tol) || (a.batched && rnorm < 1e-12));
         if (!a.batched && conv) break;                  // cg.py:132 (before the preconditioner / p update)
         const double beta = rzn / (rz + 1e-16);
@@ -734,6 +800,8 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
         EFGP_STAMP(8);
     };
 
+    EFGP_LANCZOS_BRANCH(KS, tid)
+
     double2 Ap[KS];
     if (a.zero_x0) {
 #pragma unroll
@@ -779,6 +847,7 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
         block_sum_pair(rr, rzn, red);
         ++it;
         const double rnorm = sqrt(rr);
+        if (a.hist && row == 0 && threadIdx.x == 0 && it <= a.hist_cap) a.hist[it - 1] = rnorm / (den + 1e-16);
         const bool conv = a.early_stop && ((rnorm / (den + 1e-16) < a.tol) || (a.batched && rnorm < 1e-12));
         if (!a.batched && conv) break;
         const double beta = rzn / (rz + 1e-16);
@@ -922,7 +991,7 @@ bool persistent_cg_eligible(const ToepGeom& tg) {
 int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, const double2* vhat, const double2* ws,
                          const double* diag, double sigmasq, int variant, double tol, int early_stop, int batched,
                          int max_iter, const double2* b, double2* x, int rows, int* d_iters, hipStream_t stream,
-                         const double* diag_scale, int b_times_ws, int zero_x0) {
+                         const double* diag_scale, int b_times_ws, int zero_x0, const LanczosOut* lz) {
     using namespace pcg;
     Args a;
     Geom& g = a.g;
@@ -1087,6 +1156,12 @@ int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, con
     a.b = b;
     a.x = x;
     a.iters = d_iters;
+    a.hist = cg_history().buf;
+    a.hist_cap = cg_history().capacity;
+    a.lz_steps = lz ? lz->steps : 0;
+    a.lz_alpha = lz ? lz->alpha : nullptr;
+    a.lz_beta = lz ? lz->beta : nullptr;
+    a.lz_norm2 = lz ? lz->norm2 : nullptr;
 #ifdef EFGP_CG_STAMPS
     {
         static long long* d_stamps = nullptr;

@@ -188,6 +188,20 @@ void release_ctx(int device) {
     }
 }
 
+// ---- CG residual history hook ----------------------------------------------------------------
+static CgHistory g_cg_history;
+CgHistory cg_history() { return g_cg_history; }
+
+}  // namespace efgp
+
+extern "C" int efgp_cg_record_history(double* history_dev, int capacity) {
+    efgp::g_cg_history.buf = capacity > 0 ? history_dev : nullptr;
+    efgp::g_cg_history.capacity = history_dev ? (capacity > 0 ? capacity : 0) : 0;
+    return EFGP_OK;
+}
+
+namespace efgp {
+
 // ---- kernel timing ------------------------------------------------------------------------
 struct TimingRec {
     std::string name;

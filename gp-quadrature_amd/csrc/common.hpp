@@ -106,6 +106,14 @@ void release_ctx(int device);
 // CPU-quota throttling of the whole process by torch's oversized OpenMP pool: efgp_hip/cpu_quota.py.)
 hipError_t stream_wait(hipStream_t stream);
 
+// Diagnostic hook of the CG solvers (efgp_cg_record_history): device buffer that receives row 0's relative residual
+// |r_i| / |b| of every iteration of the solves enqueued while it is set.
+struct CgHistory {
+    double* buf = nullptr;
+    int capacity = 0;
+};
+CgHistory cg_history();
+
 // Optional HIP-event timing of selected kernels (see efgp_kernel_timing in the C ABI).
 bool timing_enabled();
 struct KernelTimer {     // RAII: records start at construction, stop at destruction, on `stream`

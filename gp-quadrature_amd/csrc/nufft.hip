@@ -2014,6 +2014,7 @@ static void free_binset(DeviceCtx* ctx, BinSet* b) {
 // Bank-balanced order inside the tiles (tile_class_order_kernel); tiles proper only: the single-cell bins of the
 // cell-sorted spreader have one class.  Costs one out-of-place pass over the sorted points.
 static int balance_tiles(efgp_nufft_s* plan, BinSet* b, hipStream_t stream) {
+    KernelTimer order_timer("order", stream);
     DeviceCtx* ctx = plan->ctx;
     const TileGeom& t = b->t;
     if (b->balanced) return EFGP_OK;
@@ -2073,6 +2074,7 @@ static int get_bins(efgp_nufft_s* plan, const TileGeom& t, int channels, hipStre
     }
     int* hist = tmp;
     int* cursor = tmp + t.nbins + 1;
+    KernelTimer* order_timer = new KernelTimer("order", stream);      // closed after the scatter below
     EFGP_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)(t.nbins + 1) * sizeof(int), stream));
     // chunks of <= 32 * 1024 points per workgroup (bin_scatter_kernel keeps 32 ranks per thread)
     const int nwg = (int)std::max<int64_t>(1, (plan->npts + 32 * 1024 - 1) / (32 * 1024));
@@ -2094,6 +2096,7 @@ static int get_bins(efgp_nufft_s* plan, const TileGeom& t, int channels, hipStre
     else if (plan->dim == 2) { EFGP_BIN_LAUNCH(2) }
     else { EFGP_BIN_LAUNCH(3) }
 #undef EFGP_BIN_LAUNCH
+    delete order_timer;
     EFGP_HIP_CHECK(hipGetLastError());
     // 3-D stencils (W^3 LDS atomics per point) repay the reordering pass at once; 2-D tiles on the second pass
     if (plan->dim == 3) {
@@ -2406,7 +2409,11 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     if (use_lds) {
         if (scale_out) *scale_out = d_scale;
         // fixed-point scale from max |c| (device side, no host round trip)
-        const ScaleJob job{floor_bound, mode == STR_REAL_AND_ONES ? 1 : 0, per, d_scale, raw48 ? 46 : 61};
+        // raw48: every workgroup's sums stay below 2^46 and reduce_slabs_kernel adds at most 512 of them in int64.
+        // Otherwise the bound must hold for the SUM OVER ALL SLABS (reduce_slabs_kernel adds them in plain int64):
+        // bounding only one workgroup's share let same-sign strengths (the all-ones channel, clustered points) wrap
+        // the total, e.g. 1-D, N = 1e6, tol <= 1e-9: 512 slabs x 2^61 / 1954 points each.
+        const ScaleJob job{floor_bound, mode == STR_REAL_AND_ONES ? 1 : 0, raw48 ? per : plan->npts, d_scale, raw48 ? 46 : 61};
         if (need_max) {
             const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nvals + 8191) / 8192, 256));
             hipLaunchKernelGGL(maxabs_kernel, dim3(blocks), dim3(1024), 0, stream, c, nvals, d_cmax,
@@ -2446,6 +2453,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
                 delete co;
                 return EFGP_ENOMEM;
             }
+            KernelTimer order_timer("order", stream);
             if (plan->dim == 2)
                 hipLaunchKernelGGL((class_order_kernel<2, 16>), dim3(nwg), dim3(kSpreadThreads), 0, stream, g, w->p.w, plan->x, plan->npts, per,
                                    co->order);
@@ -2836,6 +2844,7 @@ static int type2_impl(efgp_nufft_t* plan, const void* f, const void* mode_scale,
                 return EFGP_ENOMEM;
             }
             const unsigned nwin = (unsigned)((plan->npts + kOrderWindow - 1) / kOrderWindow);
+            KernelTimer order_timer("order", stream);
             if (plan->dim == 2)
                 hipLaunchKernelGGL((class_order_kernel<2, 16>), dim3(nwin), dim3(kSpreadThreads), 0, stream, g, w->p.w, plan->x, plan->npts,
                                    (int64_t)kOrderWindow, co->order);

@@ -160,6 +160,8 @@ struct CgArgs {
     double* partial;          // [rows][3][kCgBlocksMax] per-workgroup partial sums
     int* counter;             // [rows][2] arrival counters of the two reductions
     int nblk;                 // workgroups per system
+    double* hist;             // diagnostic: row 0's |r_i| / |b| per iteration (efgp_cg_record_history) or null
+    int hist_cap;
 };
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -371,6 +373,7 @@ __global__ __launch_bounds__(kVecThreads) void cg_axpy_kernel(CgArgs a) {
             srz += fin[kCgBlocksMax + i];
         }
         const double rnorm = sqrt(srr);
+        if (a.hist && row == 0 && sc.iters < a.hist_cap) a.hist[sc.iters] = rnorm / (sc.den + kDivEps);
         const bool conv = a.early_stop && ((rnorm / (sc.den + kDivEps) < a.tol) || (a.batched && rnorm < 1e-12));
         CgRowScalars out = sc;
         out.iters = sc.iters + 1;
@@ -1122,6 +1125,8 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         a.pad = pad;
         a.pad_out = pad;
         a.rows = nullptr;
+        a.hist = r0 == 0 ? cg_history().buf : nullptr;
+        a.hist_cap = cg_history().capacity;
         a.sc = (CgRowScalars*)scb;
         a.status = (int*)(scb + off_status);
         int* d_rows = a.status + 16;
@@ -1364,6 +1369,23 @@ int efgp_cg_solve_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int
     return persistent_cg_launch(op->g, (const double2* const*)op->tw, op->vhat, (const double2*)ws, precond_diag, sigmasq,
                                 variant, tol, early_stop, batched_semantics, max_iter, (const double2*)b, (double2*)x, nbatch,
                                 row_iters_dev, stream);
+}
+
+int efgp_lanczos(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const void* z, int nprobes, int steps,
+                 double* alpha_dev, double* beta_dev, double* norm2_dev, int* steps_taken_dev, void* stream_) {
+    EFGP_REQUIRE(op && ws && z && alpha_dev && beta_dev && steps_taken_dev, "efgp_lanczos: null argument");
+    EFGP_REQUIRE(nprobes >= 1 && steps >= 1, "efgp_lanczos: nprobes and steps must be >= 1");
+    EFGP_REQUIRE(variant == 0 || variant == 1, "efgp_lanczos: variant must be 0 or 1");
+    EFGP_REQUIRE(sigmasq > 0.0 || variant == 0, "efgp_lanczos: sigmasq must be positive for A_var");
+    if (!op->persistent_ok || std::getenv("EFGP_NO_PERSISTENT_CG") != nullptr) {
+        set_error("efgp_lanczos: grid does not fit the persistent kernel");
+        return EFGP_EUNSUPPORTED;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(op->device);
+    const LanczosOut lz{steps, alpha_dev, beta_dev, norm2_dev};
+    return persistent_cg_launch(op->g, (const double2* const*)op->tw, op->vhat, (const double2*)ws, nullptr, sigmasq, variant, 0.0, 0,
+                                1, steps, (const double2*)z, nullptr, nprobes, steps_taken_dev, stream, nullptr, 0, 1, &lz);
 }
 
 int efgp_cg_solve_mean_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, const double* diag_scale_dev, const void* fy,

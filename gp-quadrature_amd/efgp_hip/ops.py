@@ -336,6 +336,28 @@ def cg_solve_mean_async(op, ws, sigmasq, diag_scale, fy, tol, max_iter=None, ear
     return x.reshape(fy.shape), LazyIterations(rows_dev, False, mi)
 
 
+def lanczos(op, ws, sigmasq, variant, z, steps):
+    """`steps` Lanczos steps on A (variant 0: ws*T(ws*.) + sigmasq, 1: /sigmasq + 1) from every row of z (P, M), all inside
+    one launch (efgp_lanczos).  Returns (alpha (P,steps), beta (P,steps), |z|^2 (P,), steps_taken (P,) int32) as DEVICE
+    tensors -- nothing is read back -- or None when the grid does not fit the persistent kernel."""
+    from .lib import EFGP_EUNSUPPORTED
+    dev = op.dev
+    zz = z.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous()
+    P = zz.shape[0]
+    wsd = ws.to(device=dev, dtype=_CD).contiguous()
+    alpha = torch.zeros((P, int(steps)), dtype=_RD, device=dev)
+    beta = torch.zeros((P, int(steps)), dtype=_RD, device=dev)
+    norm2 = torch.empty(P, dtype=_RD, device=dev)
+    taken = torch.empty(P, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().efgp_lanczos(op._h, _ptr(wsd), float(sigmasq), int(variant), _ptr(zz), P, int(steps), _ptr(alpha), _ptr(beta),
+                                _ptr(norm2), _ptr(taken), _stream(dev))
+    if rc == EFGP_EUNSUPPORTED:
+        return None
+    check(rc, "efgp_lanczos")
+    return alpha, beta, norm2, taken
+
+
 def vdot_real(a, b):
     """Re <a, b> = Re sum conj(a) b for real or complex device vectors, reduced by the HIP kernel."""
     dev = a.device
@@ -367,3 +389,23 @@ def kernel_timing_read(name):
     n = C.c_int64(0)
     check(lib().efgp_kernel_timing_read(name.encode(), C.byref(ms), C.byref(n)), "efgp_kernel_timing_read")
     return float(ms.value), int(n.value)
+
+
+class cg_residual_history:
+    """Context manager: records row 0's relative residuals |r_i| / |b| of the CG solves enqueued inside it
+    (efgp_cg_record_history).  `.values()` -> 1-D float64 tensor of the recorded iterations (zeros beyond the last)."""
+
+    def __init__(self, dev, capacity=4096):
+        self.buf = torch.zeros(int(capacity), dtype=_RD, device=dev)
+
+    def __enter__(self):
+        check(lib().efgp_cg_record_history(_ptr(self.buf), self.buf.numel()), "efgp_cg_record_history")
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize(self.buf.device)
+        check(lib().efgp_cg_record_history(None, 0), "efgp_cg_record_history")
+        return False
+
+    def values(self):
+        return self.buf.detach().cpu()

@@ -31,7 +31,7 @@ from cg import ConjugateGradients
 from kernels.kernel_params import GPParams
 from utils.kernels import get_xis
 
-from efgp_hip import NufftPlan, PointSet, ToeplitzOp, cg_solve, cg_solve_async, cg_solve_mean_async, vdot_real, compute_device, rademacher_fill
+from efgp_hip import NufftPlan, PointSet, ToeplitzOp, lanczos, cg_solve, cg_solve_async, cg_solve_mean_async, vdot_real, compute_device, rademacher_fill
 from efgp_hip.dist import PointShards
 
 TWO_PI = 2.0 * math.pi
@@ -363,7 +363,8 @@ def efgpnd_gradient_batched(
         log_marginal_probes=100, log_marginal_steps=25,
         probes_Z: Optional[torch.Tensor] = None, probes_V: Optional[torch.Tensor] = None,
         shards: Optional[PointShards] = None, trace_mode: str = "adjoint", probe_seed: Optional[int] = None,
-        domain_length: Optional[float] = None, y_norm_sq: Optional[float] = None, points: Optional[PointSet] = None):
+        domain_length: Optional[float] = None, y_norm_sq: Optional[float] = None, points: Optional[PointSet] = None,
+        log_marginal_probe_vectors: Optional[torch.Tensor] = None):
     """d(negative log marginal likelihood)/d(kernel hypers..., sigma^2) = (term1 - term2)/2 with
     Hutchinson trace estimates (data-space probes Z for non-variance kernel hypers, feature-space
     probes V for the noise) and CG solves.  ``x0, x1`` are ignored as in the reference (:72-73).
@@ -576,7 +577,7 @@ def efgpnd_gradient_batched(
     log_marginal = None
     if compute_log_marginal:
         det_term = logdet_slq(ws, sig, top, probes=log_marginal_probes, steps=log_marginal_steps,
-                              dtype=torch.float64, device=dev, n=N)
+                              dtype=torch.float64, device=dev, n=N, probe_vectors=log_marginal_probe_vectors)
         log_marginal = torch.tensor(-0.5 * float(y_alpha) - 0.5 * det_term - 0.5 * N * math.log(TWO_PI), dtype=rdtype)
         lap("9_log_marginal_likelihood")
 
@@ -641,9 +642,16 @@ def nufft_var_est_nd(est_sums, h_val, x_center, pts, eps_val):
 
 
 @torch.no_grad()
-def logdet_slq(ws, sigma2, toeplitz, *, probes=1000, steps=100, dtype=torch.float64, device="cpu", eps=1e-18, n=None):
+def logdet_slq(ws, sigma2, toeplitz, *, probes=1000, steps=100, dtype=torch.float64, device="cpu", eps=1e-18, n=None,
+               probe_vectors: Optional[torch.Tensor] = None):
     """Stochastic Lanczos quadrature estimate of log det(sigma^2 I + D T D) restricted to feature space,
-    i.e. log det(I + D T D / sigma^2) + n log sigma^2 (reference: efgpnd.py:1686-1759)."""
+    i.e. log det(I + D T D / sigma^2) + n log sigma^2 (reference: efgpnd.py:1686-1759).
+
+    All probes run their Lanczos recurrences inside ONE launch (`efgp_lanczos`: one workgroup per probe, alpha / beta
+    stay on the device); grids beyond the single-launch kernel run the same recurrence for all probes at once as batched
+    device operations.  Either way nothing is read back before the tridiagonal eigen-problems (one batched `eigh` of
+    (probes, steps, steps) at the end): the reference's loop structure costs two host reads per Lanczos step.
+    ``probe_vectors`` (probes, M) of +-1 may be injected; otherwise they are drawn as the reference does (:1716-1717)."""
     if n is None:
         raise ValueError("logdet_slq needs n (number of observations)")
     top = toeplitz._op if isinstance(toeplitz, ToeplitzND) else toeplitz
@@ -652,37 +660,46 @@ def logdet_slq(ws, sigma2, toeplitz, *, probes=1000, steps=100, dtype=torch.floa
     wc = w.to(torch.complex128)
     m = w.numel()
     s2 = float(sigma2)
-    acc = 0.0
-    for _ in range(probes):
-        zv = torch.empty(m, dtype=torch.float64, device=dev).bernoulli_(0.5).mul_(2).sub_(1)
-        znorm = zv.norm()
-        q = (zv / znorm).to(torch.complex128)
+    if probe_vectors is None:
+        zs = torch.empty((int(probes), m), dtype=torch.float64, device=dev).bernoulli_(0.5).mul_(2).sub_(1)
+    else:
+        zs = probe_vectors.detach().to(device=dev, dtype=torch.float64).reshape(-1, m)
+    P, K = zs.shape[0], int(steps)
+    res = lanczos(top, wc, s2, 1, zs, K)
+    if res is not None:
+        alphas, betas, norm2, taken = res
+        k_idx = torch.arange(K, device=dev)[None, :]
+        live = k_idx < taken[:, None]                               # steps actually taken per probe
+    else:
+        q = (zs / zs.norm(dim=1, keepdim=True)).to(torch.complex128)
+        norm2 = (zs * zs).sum(dim=1)
         q_prev = torch.zeros_like(q)
-        beta_prev = 0.0
-        alphas, betas = [], []
-        for _ in range(steps):
-            Aq = q + (wc * top.apply(wc * q)) / s2
-            vv = Aq - beta_prev * q_prev
-            a = float((q.conj() * vv).sum().real)
-            vv = vv - a * q
-            b = float(vv.norm())
-            alphas.append(a)
-            betas.append(b)
-            if b < 1e-12:
-                break
-            q_prev, beta_prev = q, b
-            q = vv / b
-        k = len(alphas)
-        Tm = torch.zeros(k, k, dtype=torch.float64)
-        for i in range(k):
-            Tm[i, i] = alphas[i]
-            if i < k - 1:
-                Tm[i, i + 1] = betas[i]
-                Tm[i + 1, i] = betas[i]
-        evals, evecs = torch.linalg.eigh(Tm)
-        evals.clamp_min_(eps)
-        acc += float(((evecs[0] ** 2) * torch.log(evals)).sum() * (float(znorm) ** 2))
-    return acc / probes + n * math.log(s2)
+        beta_prev = torch.zeros(P, dtype=torch.float64, device=dev)
+        alive = torch.ones(P, dtype=torch.bool, device=dev)
+        a_list, b_list, l_list = [], [], []
+        for _ in range(K):
+            vv = q + (wc * top.apply(wc * q)) / s2 - beta_prev[:, None] * q_prev
+            a = (q.conj() * vv).sum(dim=1).real
+            vv = vv - a[:, None] * q
+            b = vv.norm(dim=1)
+            a_list.append(a)
+            b_list.append(b)
+            l_list.append(alive)
+            nxt = alive & (b >= 1e-12)                               # the reference breaks after recording this step (:1733)
+            safe = torch.where(nxt, b, torch.ones_like(b))
+            q_prev = torch.where(nxt[:, None], q, q_prev)
+            q = torch.where(nxt[:, None], vv / safe[:, None], q)
+            beta_prev = torch.where(nxt, b, beta_prev)
+            alive = nxt
+        alphas, betas, live = torch.stack(a_list, 1), torch.stack(b_list, 1), torch.stack(l_list, 1)
+    # tridiagonal matrices, padded with decoupled unit diagonal entries behind the steps taken (log 1 = 0, zero weight)
+    alphas = torch.where(live, alphas, torch.ones_like(alphas))
+    off = torch.where(live[:, 1:], betas[:, :-1], torch.zeros_like(betas[:, :-1]))      # beta_i couples steps i and i+1
+    Tm = torch.diag_embed(alphas) + torch.diag_embed(off, offset=1) + torch.diag_embed(off, offset=-1)
+    evals, evecs = torch.linalg.eigh(Tm.cpu())                       # (P, K, K) tiny: one transfer, LAPACK on the host
+    evals = evals.clamp_min(eps)
+    quad = ((evecs[:, 0, :] ** 2) * torch.log(evals)).sum(dim=1) * norm2.cpu()
+    return float(quad.sum() / P) + n * math.log(s2)
 
 
 def compute_prediction_variance(x_new, xis, ws, A_var, cg_tol, max_cg_iter, variance_method, h, xcen,
@@ -1045,7 +1062,8 @@ class EFGPND(nn.Module):
     def _compute_log_marginal(self, beta, ws, sigmasq, toeplitz, device, rdtype, n):
         """-(logdet + sum |ws| |beta|^2)/2, the `predict`-path formula of the reference (:1050-1066)."""
         log_det = logdet_slq(ws=ws, sigma2=sigmasq, toeplitz=toeplitz, probes=self.opts.get("log_marginal_probes", 100),
-                             steps=self.opts.get("log_marginal_steps", 25), dtype=rdtype, device=device, n=n)
+                             steps=self.opts.get("log_marginal_steps", 25), dtype=rdtype, device=device, n=n,
+                             probe_vectors=self.opts.get("log_marginal_probe_vectors"))
         data_fit = float((ws.abs() * (beta.abs() ** 2)).sum().real)
         return -0.5 * (log_det + data_fit)
 

@@ -186,6 +186,23 @@ int efgp_cg_solve_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int
 int efgp_cg_solve_mean_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, const double* diag_scale_dev, const void* fy,
                              void* x, double tol, int max_iter, int early_stop, int* iters_dev, void* stream);
 
+/* Lanczos three-term recurrence on A (variant as in efgp_cg_solve), the inner loop of the reference's stochastic
+ * Lanczos quadrature log-determinant (logdet_slq, efgpnd.py:1716-1738):
+ *     q_0 = z / |z|;  v = A q_k - beta_{k-1} q_{k-1};  alpha_k = Re<q_k, v>;  v -= alpha_k q_k;  beta_k = |v|;
+ *     stop after `steps` steps or when beta_k < 1e-12;  q_{k+1} = v / beta_k
+ * for nprobes start vectors z (nprobes, M) complex, one workgroup per probe, all steps inside ONE launch (the reference
+ * loops in Python).  alpha_dev, beta_dev: (nprobes, steps) doubles; norm2_dev: (nprobes) |z|^2 or NULL;
+ * steps_taken_dev: (nprobes) ints -- all DEVICE arrays; no host synchronisation.  EFGP_EUNSUPPORTED when the circulant
+ * grid does not fit the single-launch kernel (callers then loop over efgp_toeplitz_apply). */
+int efgp_lanczos(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const void* z, int nprobes, int steps,
+                 double* alpha_dev, double* beta_dev, double* norm2_dev, int* steps_taken_dev, void* stream);
+
+/* Diagnostic hook for iterate-level parity with cg.py:132 (`norm(r) / (norm(b) + div_eps) < tol`): while a device
+ * buffer is registered, every solve enqueued by efgp_cg_solve* writes row 0's relative residual of iteration i
+ * (1-based, the value the stopping rule tests) to history_dev[i - 1], i <= capacity.  NULL (or capacity 0) switches
+ * it off.  Process-wide; not meant for production use. */
+int efgp_cg_record_history(double* history_dev, int capacity);
+
 /* ---- N-length reductions of the hyper-gradient (efgpnd.py:163, 170, 239) ----------------------
  * out_host[0] = Re sum_n conj(a_n) b_n over n < count; each operand is complex (interleaved) when
  * its *_is_complex flag is set, else real.  Wavefront-shuffle + LDS reduction, deterministic order.

@@ -17,7 +17,7 @@ NOMINAL = {"c1_se1d_n5000": ("se", 0.1, 2.0, 0.1, 2.5), "c2_se2d_n100000": ("se"
            "s2_matern12_1d_n200": ("matern", 0.3, 1.2, 0.1, 0.5)}
 
 
-def make_model(name, g, x, y, cg_tol, **opts):
+def make_model(name, g, x, y, cg_tol, nufft_eps=1e-9, **opts):
     from efgpnd import EFGPND
     from kernels.squared_exponential import SquaredExponential
     from kernels.matern import Matern
@@ -27,7 +27,7 @@ def make_model(name, g, x, y, cg_tol, **opts):
         Matern(dimension=d, nu=nu, init_lengthscale=ls, init_variance=var)
     o = {"cg_tolerance": cg_tol, "mean_cg_warm_start": False}
     o.update(opts)
-    m = EFGPND(x, y, k, sigmasq=sig2, eps=float(g["eps"]), nufft_eps=1e-9, estimate_params=False, opts=o)
+    m = EFGPND(x, y, k, sigmasq=sig2, eps=float(g["eps"]), nufft_eps=nufft_eps, estimate_params=False, opts=o)
     # effective hyper-parameters equal what the reference read back
     assert abs(k.get_hyper("lengthscale") - float(g["lengthscale"])) < 1e-15
     assert abs(float(m.sigmasq.detach()) - float(g["sigmasq"])) < 1e-15

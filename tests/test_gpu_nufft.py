@@ -273,3 +273,18 @@ def test_tile_balancing_is_bitwise_neutral(d, nm, N, monkeypatch):
         assert torch.equal(a1, a2) and torch.equal(a2, a3) and torch.equal(g1, g2)
         res.append((a1, g1))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_type1_ones_many_slabs_no_fixed_point_overflow():
+    """Same-sign strengths over many workgroup slabs: the int64 sum over all slabs must not wrap (1-D, N = 1e6,
+    tol 1e-10 so that the 48-bit raw accumulation is off: 512 slabs, each bounded alone would allow 2^61 per slab)."""
+    from efgp_hip import NufftPlan
+    N, nm = 1_000_000, 45
+    x = _points(N, 1, 77)
+    plan = NufftPlan(x.cuda(), 0.31, 1e-10)
+    v = plan.type1_ones((nm,))
+    assert abs(float(v[nm // 2].real) - N) < 1e-6 * N
+    assert float(v.abs().max()) <= N * (1 + 1e-9)
+    y = torch.full((N,), 3.0, dtype=torch.float64)
+    Fy = plan.type1(y.cuda(), (nm,))
+    assert _rel(Fy, 3.0 * v) < 1e-9
