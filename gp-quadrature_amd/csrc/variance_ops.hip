@@ -1,0 +1,199 @@
+// M-scale device operations of the predictive variance (SURVEY kernels K5 / K8) behind the C ABI:
+//   efgp_lag_sums          Hutchinson lag sums  c[r] = mean_j sum_{k-l=r} gamma_j[k] eta_j[l]   (efgpnd.py:1660-1664)
+//   efgp_variance_rhs      right-hand sides ws .* conj(f(x*)) of the 'regular' variance          (efgpnd.py:1805-1812)
+//   efgp_variance_contract s^2(x*) = max(0, Re sum_k f_k(x*) ws_k gamma_k)                        (efgpnd.py:1817-1820)
+// The reference does these with torch.fft / dense torch ops; here they are hipFFT transforms plus three small kernels,
+// so a caller that binds only include/efgp_hip.h can compute a variance end to end.
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace efgp {
+
+struct LagGeom {
+    int d;
+    int n[3];       // mtot per dimension (unused = 1)
+    int s[3];       // 2 n - 1
+    int64_t M, S;   // prod n, prod s
+};
+
+// zero-padded copies: pad[j][0][...] = gamma_j, pad[j][1][...] = eta_j  (two transforms per probe in one batch)
+__global__ __launch_bounds__(256) void lag_pad_kernel(LagGeom g, const double2* __restrict__ gam, const double* __restrict__ eta,
+                                                      double2* __restrict__ pad) {
+    const int j = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < g.S; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int i2 = (int)(r % g.s[2]);
+        r /= g.s[2];
+        const int i1 = (int)(r % g.s[1]);
+        const int i0 = (int)(r / g.s[1]);
+        const bool in = i0 < g.n[0] && i1 < g.n[1] && i2 < g.n[2];
+        const int64_t src = ((int64_t)i0 * g.n[1] + i1) * g.n[2] + i2;
+        double2* row = pad + (int64_t)2 * j * g.S;
+        row[i] = in ? gam[(int64_t)j * g.M + src] : make_double2(0.0, 0.0);
+        row[g.S + i] = in ? make_double2(eta[(int64_t)j * g.M + src], 0.0) : make_double2(0.0, 0.0);
+    }
+}
+
+// acc[i] (+)= sum_j G_j[i] conj(E_j[i])   (the inverse transform is linear: one inverse FFT of the probe sum)
+__global__ __launch_bounds__(256) void lag_mul_sum_kernel(int64_t S, int J, const double2* __restrict__ pad, double2* __restrict__ acc,
+                                                          int add) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
+        double re = 0.0, im = 0.0;
+        for (int j = 0; j < J; ++j) {
+            const double2 a = pad[(int64_t)2 * j * S + i], b = pad[(int64_t)(2 * j + 1) * S + i];
+            re += a.x * b.x + a.y * b.y;
+            im += a.y * b.x - a.x * b.y;
+        }
+        if (add) {
+            re += acc[i].x;
+            im += acc[i].y;
+        }
+        acc[i] = make_double2(re, im);
+    }
+}
+
+__global__ __launch_bounds__(256) void lag_scale_kernel(int64_t S, double factor, const double2* __restrict__ in, double2* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = make_double2(in[i].x * factor, in[i].y * factor);
+}
+
+// phase 2 pi h k . x for mode index t of the (mtot,)*d box, k = i - (mtot-1)/2 per dimension, last dimension fastest
+__device__ __forceinline__ double mode_phase(int d, int mtot, double h, const double* __restrict__ x, int64_t t) {
+    const int m = (mtot - 1) / 2;
+    double ph = 0.0;
+    for (int a = d - 1; a >= 0; --a) {
+        const int ia = (int)(t % mtot);
+        t /= mtot;
+        ph += (double)(ia - m) * x[a];
+    }
+    return 2.0 * M_PI * h * ph;
+}
+
+__global__ __launch_bounds__(256) void variance_rhs_kernel(int d, int mtot, int64_t M, double h, const double* __restrict__ x,
+                                                           const double2* __restrict__ ws, double2* __restrict__ rhs) {
+    const int b = blockIdx.y;
+    const double* xb = x + (int64_t)b * d;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < M; t += (int64_t)gridDim.x * blockDim.x) {
+        double sn, cs;
+        sincos(mode_phase(d, mtot, h, xb, t), &sn, &cs);
+        const double2 w = ws[t];
+        rhs[(int64_t)b * M + t] = make_double2(w.x * cs + w.y * sn, w.y * cs - w.x * sn);      // ws * conj(f)
+    }
+}
+
+__global__ __launch_bounds__(256) void variance_contract_kernel(int d, int mtot, int64_t M, double h, const double* __restrict__ x,
+                                                                const double2* __restrict__ ws, const double2* __restrict__ gamma,
+                                                                double* __restrict__ out) {
+    __shared__ double part[4];
+    const int b = blockIdx.x;
+    const double* xb = x + (int64_t)b * d;
+    double acc = 0.0;
+    for (int64_t t = threadIdx.x; t < M; t += blockDim.x) {
+        double sn, cs;
+        sincos(mode_phase(d, mtot, h, xb, t), &sn, &cs);
+        const double2 w = ws[t], g = gamma[(int64_t)b * M + t];
+        const double2 wg = make_double2(w.x * g.x - w.y * g.y, w.x * g.y + w.y * g.x);
+        acc += cs * wg.x - sn * wg.y;                                                          // Re (f * ws * gamma)
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += part[i];
+        out[b] = s > 0.0 ? s : 0.0;                                                           // clamp_min(0), efgpnd.py:1820
+    }
+}
+
+}  // namespace efgp
+
+using namespace efgp;
+
+extern "C" {
+
+int efgp_lag_sums(int device, int dim, int64_t mtot, const void* gamma, const double* eta, int nprobes, void* out, void* stream_) {
+    EFGP_REQUIRE(dim >= 1 && dim <= 3, "efgp_lag_sums: dim must be 1, 2 or 3");
+    EFGP_REQUIRE(mtot >= 1 && nprobes >= 1, "efgp_lag_sums: mtot and nprobes must be >= 1");
+    EFGP_REQUIRE(gamma && eta && out, "efgp_lag_sums: null argument");
+    DeviceCtx* ctx = device_ctx(device);
+    if (!ctx) return EFGP_EHIP;
+    DeviceGuard guard(device);
+    hipStream_t stream = (hipStream_t)stream_;
+    LagGeom g;
+    g.d = dim;
+    g.M = 1;
+    g.S = 1;
+    int64_t sizes[3] = {1, 1, 1};
+    // slots are right-aligned so that the LAST real dimension is the fastest one (n[2] / s[2])
+    for (int a = 0; a < 3; ++a) {
+        const bool real = a >= 3 - dim;
+        g.n[a] = real ? (int)mtot : 1;
+        g.s[a] = real ? (int)(2 * mtot - 1) : 1;
+        g.M *= g.n[a];
+        g.S *= g.s[a];
+    }
+    for (int a = 0; a < dim; ++a) sizes[a] = 2 * mtot - 1;
+    // probes are processed in slabs so that the padded transforms stay within ~256 MB of scratch
+    const int64_t per = std::max<int64_t>(1, std::min<int64_t>(nprobes, ((int64_t)256 << 20) / (int64_t)(2 * g.S * sizeof(double2))));
+    double2* pad = (double2*)scratch(ctx, SLOT_TOEP_PAD, (size_t)(2 * per + 1) * g.S * sizeof(double2));
+    if (!pad) return EFGP_ENOMEM;
+    double2* acc = pad + (int64_t)2 * per * g.S;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((g.S + 255) / 256, 1024));
+    for (int64_t j0 = 0; j0 < nprobes; j0 += per) {
+        const int J = (int)std::min<int64_t>(per, nprobes - j0);
+        hipLaunchKernelGGL(lag_pad_kernel, dim3(blocks, J), dim3(256), 0, stream, g, (const double2*)gamma + j0 * g.M, eta + j0 * g.M, pad);
+        EFGP_HIP_CHECK(hipGetLastError());
+        hipfftHandle fh;
+        int rc = fft_plan(ctx, dim, sizes, 2 * J, stream, &fh);
+        if (rc != EFGP_OK) return rc;
+        EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)pad, (hipfftDoubleComplex*)pad, HIPFFT_FORWARD));
+        hipLaunchKernelGGL(lag_mul_sum_kernel, dim3(blocks), dim3(256), 0, stream, g.S, J, (const double2*)pad, acc, j0 > 0 ? 1 : 0);
+        EFGP_HIP_CHECK(hipGetLastError());
+    }
+    hipfftHandle fi;
+    int rc = fft_plan(ctx, dim, sizes, 1, stream, &fi);
+    if (rc != EFGP_OK) return rc;
+    EFGP_FFT_CHECK(hipfftExecZ2Z(fi, (hipfftDoubleComplex*)acc, (hipfftDoubleComplex*)acc, HIPFFT_BACKWARD));
+    hipLaunchKernelGGL(lag_scale_kernel, dim3(blocks), dim3(256), 0, stream, g.S, 1.0 / ((double)g.S * (double)nprobes), (const double2*)acc,
+                       (double2*)out);
+    EFGP_HIP_CHECK(hipGetLastError());
+    return EFGP_OK;
+}
+
+int efgp_variance_rhs(int device, int dim, int64_t mtot, double h, const double* x_new, int64_t npts, const void* ws, void* rhs,
+                      void* stream_) {
+    EFGP_REQUIRE(dim >= 1 && dim <= 3 && mtot >= 1 && npts >= 0, "efgp_variance_rhs: bad sizes");
+    if (npts == 0) return EFGP_OK;
+    EFGP_REQUIRE(x_new && ws && rhs, "efgp_variance_rhs: null argument");
+    if (!device_ctx(device)) return EFGP_EHIP;
+    DeviceGuard guard(device);
+    int64_t M = 1;
+    for (int a = 0; a < dim; ++a) M *= mtot;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((M + 255) / 256, 256));
+    for (int64_t b0 = 0; b0 < npts; b0 += 65535) {
+        const int nb = (int)std::min<int64_t>(65535, npts - b0);
+        hipLaunchKernelGGL(variance_rhs_kernel, dim3(blocks, nb), dim3(256), 0, (hipStream_t)stream_, dim, (int)mtot, M, h, x_new + b0 * dim,
+                           (const double2*)ws, (double2*)rhs + b0 * M);
+    }
+    EFGP_HIP_CHECK(hipGetLastError());
+    return EFGP_OK;
+}
+
+int efgp_variance_contract(int device, int dim, int64_t mtot, double h, const double* x_new, int64_t npts, const void* ws,
+                           const void* gamma, double* out, void* stream_) {
+    EFGP_REQUIRE(dim >= 1 && dim <= 3 && mtot >= 1 && npts >= 0, "efgp_variance_contract: bad sizes");
+    if (npts == 0) return EFGP_OK;
+    EFGP_REQUIRE(x_new && ws && gamma && out, "efgp_variance_contract: null argument");
+    if (!device_ctx(device)) return EFGP_EHIP;
+    DeviceGuard guard(device);
+    int64_t M = 1;
+    for (int a = 0; a < dim; ++a) M *= mtot;
+    hipLaunchKernelGGL(variance_contract_kernel, dim3((unsigned)npts), dim3(256), 0, (hipStream_t)stream_, dim, (int)mtot, M, h, x_new,
+                       (const double2*)ws, (const double2*)gamma, out);
+    EFGP_HIP_CHECK(hipGetLastError());
+    return EFGP_OK;
+}
+
+}  // extern "C"

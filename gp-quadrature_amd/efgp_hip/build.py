@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
-SOURCES = ["es_kernel.cpp", "common.cpp", "nufft.hip", "spread_mfma.hip", "points_layout.hip", "toeplitz_cg.hip", "cg_persistent.hip"]
+SOURCES = ["es_kernel.cpp", "common.cpp", "nufft.hip", "spread_mfma.hip", "points_layout.hip", "variance_ops.hip", "comm.cpp", "toeplitz_cg.hip", "cg_persistent.hip"]
 HEADERS = ["es_kernel.hpp", "common.hpp", "toeplitz_cg.hpp", "nufft_dev.hpp", "points_layout.hpp", "spread_mfma.hpp", os.path.join("..", "..", "include", "efgp_hip.h")]
 TARGET = os.path.join(HERE, "libefgp_hip.so")
 
@@ -64,7 +64,7 @@ def _build(target, extra, verbose):
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), int(os.environ.get("EFGP_BUILD_JOBS", "6")))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-no-hip-rt"] + objs + [
-        "-L" + tl, "-lhipfft", "-lamdhip64", "-Wl,-rpath," + tl, "-o", target + ".tmp"]
+        "-L" + tl, "-lhipfft", "-lamdhip64", "-lrccl", "-Wl,-rpath," + tl, "-o", target + ".tmp"]
     if verbose:
         print("[efgp_hip] " + " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -31,10 +31,36 @@ def _adjacent_span(tensors):
     return torch.as_strided(t0, (off - t0.storage_offset(),), (1,), t0.storage_offset())
 
 
-class PointShards:
-    """All-reduce helper bound to a process group; a no-op when world_size == 1."""
+def rccl_comm_from_env(device):
+    """An `RcclComm` (C ABI efgp_comm_*, no torch process group) for the launch environment of torch.distributed.run:
+    RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.  The 128-byte RCCL id travels through a TCPStore on MASTER_PORT + 1."""
+    import os
+    from datetime import timedelta
+    from .ops import RcclComm
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return RcclComm(device, 0, 1, RcclComm.make_id())
+    store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 1, world,
+                          is_master=(rank == 0), timeout=timedelta(seconds=300))
+    if rank == 0:
+        uid = RcclComm.make_id()
+        store.set("efgp_rccl_id", uid)
+    else:
+        uid = bytes(store.get("efgp_rccl_id"))
+    return RcclComm(device, rank, world, uid)
 
-    def __init__(self, group=None, enabled=None):
+
+class PointShards:
+    """All-reduce helper bound to a torch process group, or to an `RcclComm` (C ABI collectives, no process group) when
+    `comm` is given; a no-op when world_size == 1."""
+
+    def __init__(self, group=None, enabled=None, comm=None):
+        self.comm = comm
+        if comm is not None:
+            self.enabled = True
+            self.group = None
+            self.world_size, self.rank = comm.world, comm.rank
+            return
         if enabled is None:
             enabled = dist.is_available() and dist.is_initialized()
         self.enabled = bool(enabled) and dist.is_available() and dist.is_initialized()
@@ -53,11 +79,17 @@ class PointShards:
         buf = torch.view_as_real(t) if t.is_complex() else t
         if not buf.is_contiguous():
             tmp = buf.contiguous()
-            dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+            self._allreduce_sum(tmp)
             buf.copy_(tmp)
         else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            self._allreduce_sum(buf)
         return t
+
+    def _allreduce_sum(self, buf):
+        if self.comm is not None:
+            self.comm.all_reduce_sum_(buf)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
 
     def sum_many_(self, tensors):
         """One fused all-reduce for several small tensors (latency-bound messages)."""
@@ -65,11 +97,11 @@ class PointShards:
             return tensors
         span = _adjacent_span(tensors)
         if span is not None:          # views laid out back to back in one buffer (NufftPlan.type1_pair): reduce in place
-            dist.all_reduce(torch.view_as_real(span) if span.is_complex() else span, op=dist.ReduceOp.SUM, group=self.group)
+            self._allreduce_sum(torch.view_as_real(span) if span.is_complex() else span)
             return tensors
         flats = [(torch.view_as_real(t) if t.is_complex() else t).reshape(-1) for t in tensors]
         packed = torch.cat(flats)
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+        self._allreduce_sum(packed)
         off = 0
         for t, f in zip(tensors, flats):
             n = f.numel()
@@ -82,13 +114,18 @@ class PointShards:
         if not self.active:
             return [float(v) for v in values]
         t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self._allreduce_sum(t)
         return [float(v) for v in t.tolist()]
 
     def exclusive_offset(self, n_local, device):
         """Global index of this rank's first point (ranks hold consecutive blocks of the observations)."""
         if not self.active:
             return 0
+        if self.comm is not None:      # counts as a one-hot sum (exact in float64 below 2^53)
+            t = torch.zeros(self.world_size, dtype=torch.float64, device=device)
+            t[self.rank] = float(n_local)
+            self._allreduce_sum(t)
+            return int(t[:self.rank].sum().item())
         counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(self.world_size)]
         dist.all_gather(counts, torch.tensor([int(n_local)], dtype=torch.int64, device=device), group=self.group)
         return int(sum(int(c.item()) for c in counts[:self.rank]))
@@ -98,6 +135,14 @@ class PointShards:
         -- probe seeds, feature-space probes -- must come from one rank: replicas that draw their own diverge after
         the first optimizer step (different gradients -> different grids -> mismatched all-reduce sizes)."""
         if not self.active:
+            return t
+        if self.comm is not None:
+            if t.is_contiguous():
+                self.comm.broadcast_(t, src)
+            else:
+                tmp = t.contiguous()
+                self.comm.broadcast_(tmp, src)
+                t.copy_(tmp)
             return t
         root = dist.get_global_rank(self.group, src) if self.group is not None else src
         buf = torch.view_as_real(t) if t.is_complex() else t
@@ -124,6 +169,10 @@ class PointShards:
             return lo, hi
         lo = lo.clone()
         hi = hi.clone()
+        if self.comm is not None:
+            self.comm.all_reduce_minmax_(lo, False)
+            self.comm.all_reduce_minmax_(hi, True)
+            return lo, hi
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
         return lo, hi

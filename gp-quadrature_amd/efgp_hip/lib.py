@@ -64,6 +64,15 @@ _SIGNATURES = {
     "efgp_cg_solve_mean_async": (_I, [_VP, _VP, _D, _VP, _VP, _VP, _D, _I, _I, _VP, _VP]),
     "efgp_cg_record_history": (_I, [_VP, _I]),
     "efgp_lanczos": (_I, [_VP, _VP, _D, _I, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP]),
+    "efgp_lag_sums": (_I, [_I, _I, _I64, _VP, _VP, _I, _VP, _VP]),
+    "efgp_variance_rhs": (_I, [_I, _I, _I64, _D, _VP, _I64, _VP, _VP, _VP]),
+    "efgp_variance_contract": (_I, [_I, _I, _I64, _D, _VP, _I64, _VP, _VP, _VP, _VP]),
+    "efgp_comm_unique_id": (_I, [_VP]),
+    "efgp_comm_init": (_I, [C.POINTER(_VP), _I, _I, _I, _VP]),
+    "efgp_comm_allreduce_sum": (_I, [_VP, _VP, C.c_size_t, _VP]),
+    "efgp_comm_allreduce_minmax": (_I, [_VP, _VP, C.c_size_t, _I, _VP]),
+    "efgp_comm_broadcast": (_I, [_VP, _VP, C.c_size_t, _I, _VP]),
+    "efgp_comm_destroy": (_I, [_VP]),
     "efgp_vdot_real": (_I, [_I, _VP, _I, _VP, _I, _I64, C.POINTER(_D), _VP]),
 }
 

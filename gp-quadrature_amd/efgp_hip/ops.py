@@ -358,6 +358,96 @@ def lanczos(op, ws, sigmasq, variant, z, steps):
     return alpha, beta, norm2, taken
 
 
+def lag_sums(gamma, eta, mtot, dim):
+    """c[r] = mean_j sum_{k-l=r} gamma[j,k] eta[j,l] on the (2 mtot - 1)^d lag box in FFT order (efgp_lag_sums)."""
+    dev = gamma.device
+    M = int(mtot) ** int(dim)
+    gg = gamma.reshape(-1, M).to(_CD).contiguous()
+    ee = eta.reshape(-1, M).to(device=dev, dtype=_RD).contiguous()
+    out = torch.empty((2 * int(mtot) - 1,) * int(dim), dtype=_CD, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().efgp_lag_sums(dev.index, int(dim), int(mtot), _ptr(gg), _ptr(ee), gg.shape[0], _ptr(out), _stream(dev)),
+              "efgp_lag_sums")
+    return out
+
+
+def variance_rhs(x_new, h, mtot, ws):
+    """rhs[b, k] = ws[k] conj(f_k(x*_b)) for the 'regular' variance solves (efgp_variance_rhs)."""
+    dev = ws.device
+    xn = x_new.to(device=dev, dtype=_RD).contiguous()
+    B, d = xn.shape
+    wsd = ws.to(_CD).contiguous()
+    out = torch.empty((B, wsd.numel()), dtype=_CD, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().efgp_variance_rhs(dev.index, d, int(mtot), float(h), _ptr(xn), B, _ptr(wsd), _ptr(out), _stream(dev)),
+              "efgp_variance_rhs")
+    return out
+
+
+def variance_contract(x_new, h, mtot, ws, gamma):
+    """s^2[b] = max(0, Re sum_k f_k(x*_b) ws[k] gamma[b, k]) (efgp_variance_contract)."""
+    dev = ws.device
+    xn = x_new.to(device=dev, dtype=_RD).contiguous()
+    B, d = xn.shape
+    wsd = ws.to(_CD).contiguous()
+    gg = gamma.reshape(B, -1).to(_CD).contiguous()
+    out = torch.empty(B, dtype=_RD, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().efgp_variance_contract(dev.index, d, int(mtot), float(h), _ptr(xn), B, _ptr(wsd), _ptr(gg), _ptr(out),
+                                           _stream(dev)), "efgp_variance_contract")
+    return out
+
+
+class RcclComm:
+    """Sum / min / max all-reduce and broadcast over RCCL without a torch process group (C ABI: efgp_comm_*).
+    `unique_id` (128 bytes) comes from `RcclComm.make_id()` on rank 0 and reaches the other ranks by the caller's channel."""
+
+    @staticmethod
+    def make_id():
+        buf = (C.c_char * 128)()
+        check(lib().efgp_comm_unique_id(buf), "efgp_comm_unique_id")
+        return bytes(buf)
+
+    def __init__(self, dev, rank, world, unique_id):
+        assert len(unique_id) == 128
+        self.dev, self.rank, self.world = dev, int(rank), int(world)
+        self._h = C.c_void_p()
+        with torch.cuda.device(dev):
+            check(lib().efgp_comm_init(C.byref(self._h), dev.index, self.rank, self.world, C.c_char_p(unique_id)), "efgp_comm_init")
+
+    def all_reduce_sum_(self, t):
+        buf = torch.view_as_real(t) if t.is_complex() else t
+        assert buf.is_cuda and buf.dtype == _RD and buf.is_contiguous()
+        with torch.cuda.device(self.dev):
+            check(lib().efgp_comm_allreduce_sum(self._h, _ptr(buf), buf.numel(), _stream(self.dev)), "efgp_comm_allreduce_sum")
+        return t
+
+    def all_reduce_minmax_(self, t, take_max):
+        assert t.is_cuda and t.dtype == _RD and t.is_contiguous()
+        with torch.cuda.device(self.dev):
+            check(lib().efgp_comm_allreduce_minmax(self._h, _ptr(t), t.numel(), int(bool(take_max)), _stream(self.dev)),
+                  "efgp_comm_allreduce_minmax")
+        return t
+
+    def broadcast_(self, t, root=0):
+        assert t.is_cuda and t.is_contiguous()
+        with torch.cuda.device(self.dev):
+            check(lib().efgp_comm_broadcast(self._h, _ptr(t), t.numel() * t.element_size(), int(root), _stream(self.dev)),
+                  "efgp_comm_broadcast")
+        return t
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().efgp_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def vdot_real(a, b):
     """Re <a, b> = Re sum conj(a) b for real or complex device vectors, reduced by the HIP kernel."""
     dev = a.device

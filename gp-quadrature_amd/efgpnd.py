@@ -31,7 +31,7 @@ from cg import ConjugateGradients
 from kernels.kernel_params import GPParams
 from utils.kernels import get_xis
 
-from efgp_hip import NufftPlan, PointSet, ToeplitzOp, lanczos, cg_solve, cg_solve_async, cg_solve_mean_async, vdot_real, compute_device, rademacher_fill
+from efgp_hip import NufftPlan, PointSet, ToeplitzOp, lanczos, lag_sums, variance_rhs, variance_contract, cg_solve, cg_solve_async, cg_solve_mean_async, vdot_real, compute_device, rademacher_fill
 from efgp_hip.dist import PointShards
 
 TWO_PI = 2.0 * math.pi
@@ -621,14 +621,8 @@ def diag_sums_nd(A_apply, J, xis_flat, max_cg_iter, cg_tol, ws, probes: Optional
     rhs = wsd[None, :] * etas
     us, _, _ = cg_solve(op.toeplitz._op, wsd, op.sigmasq, op.variant, rhs, torch.zeros_like(rhs), cg_tol,
                         max_iter=max_cg_iter, early_stop=True, diag=None, batched=True)
-    gam = (wsd[None, :] * us).view((-1,) + (m_loc,) * d_loc)
-    eta = etas.view((-1,) + (m_loc,) * d_loc)
-    s_size = (2 * m_loc - 1,) * d_loc
-    dims = tuple(range(1, d_loc + 1))
-    G = torch.fft.fftn(gam, s=s_size, dim=dims)
-    E = torch.fft.fftn(eta, s=s_size, dim=dims)
-    R = torch.fft.ifftn(G * torch.conj(E), s=s_size, dim=dims)
-    return R.mean(dim=0)
+    # zero-padded correlation of every probe pair and the mean over probes (:1660-1664): hipFFT + three small kernels
+    return lag_sums(wsd[None, :] * us, etas, m_loc, d_loc)
 
 
 def nufft_var_est_nd(est_sums, h_val, x_center, pts, eps_val):
@@ -711,16 +705,17 @@ def compute_prediction_variance(x_new, xis, ws, A_var, cg_tol, max_cg_iter, vari
         op = _unwrap_operator(A_var)
         dev = op.toeplitz._dev
         wsd = ws.to(device=dev, dtype=torch.complex128)
-        xis_d = xis.to(device=dev, dtype=torch.float64)
         xn = x_new.to(device=dev, dtype=torch.float64)
+        M_loc = wsd.numel()
+        mtot_loc = round(M_loc ** (1.0 / xn.shape[1]))
+        assert mtot_loc ** xn.shape[1] == M_loc, "ws must lie on the tensor grid"
+        hval = float(h)
         out = []
         for xb in torch.split(xn, 8192, dim=0):
-            ang = TWO_PI * (xb @ xis_d.T)
-            fx = torch.polar(torch.ones_like(ang), ang)                  # explicit feature rows (b, M)
-            rhs = wsd * fx.conj()
+            rhs = variance_rhs(xb, hval, mtot_loc, wsd)                  # ws * conj(f(x*)): explicit feature rows (b, M)
             gamma, _, _ = cg_solve(op.toeplitz._op, wsd, op.sigmasq, op.variant, rhs, torch.zeros_like(rhs), cg_tol,
                                    max_iter=max_cg_iter, early_stop=True, diag=None, batched=True)
-            out.append(torch.real((fx * (wsd * gamma)).sum(dim=-1)).clamp_min(0.0))
+            out.append(variance_contract(xb, hval, mtot_loc, wsd, gamma))
         return torch.cat(out, dim=0).to(device=device, dtype=rdtype)
     if method == "stochastic":
         t1 = time.time()
@@ -807,7 +802,9 @@ class EFGPND(nn.Module):
         self._devdata = None
         self._fit_state = None
         self._predict_plan = None
-        self._shards = PointShards(enabled=bool(self.opts.get("shard_points", False)))
+        # shard_points: True = torch.distributed default group; an efgp_hip.RcclComm = the library's own RCCL communicator
+        sp = self.opts.get("shard_points", False)
+        self._shards = PointShards(comm=sp) if (sp is not None and not isinstance(sp, bool)) else PointShards(enabled=bool(sp))
         self._update_param_cache()
 
     # -- parameter bookkeeping ------------------------------------------------------------------

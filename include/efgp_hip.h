@@ -20,6 +20,7 @@
 #ifndef EFGP_HIP_H_
 #define EFGP_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -35,6 +36,7 @@ extern "C" {
 typedef struct efgp_nufft_s efgp_nufft_t;
 typedef struct efgp_toeplitz_s efgp_toeplitz_t;
 typedef struct efgp_points_s efgp_points_t;
+typedef struct efgp_comm_s efgp_comm_t;
 
 /* ---- library ---------------------------------------------------------------------------- */
 int efgp_version(void);                      /* 1000*major + minor */
@@ -209,6 +211,37 @@ int efgp_cg_record_history(double* history_dev, int capacity);
  * Synchronises the stream (the result is a HOST double). */
 int efgp_vdot_real(int device, const void* a, int a_is_complex, const void* b, int b_is_complex,
                    int64_t count, double* out_host, void* stream);
+
+/* ---- M-scale pieces of the predictive variance (efgpnd.py:1634-1679, 1805-1820) -------------------------------------
+ * Lag sums of the stochastic variance (diag_sums_nd, :1660-1664):
+ *     out[r] = (1/nprobes) sum_j sum_{k - l = r} gamma[j, k] eta[j, l],   r in [-(mtot-1), mtot-1]^d,
+ * stored in FFT order per dimension (index r mod (2 mtot - 1)), exactly the tensor the reference builds with
+ * fftn/ifftn of size 2 mtot - 1 and feeds to the FFT-ordered type-2 transform (:1679 -> efgp_nufft_type2, modeord 1).
+ * gamma: (nprobes, mtot^d) complex, eta: (nprobes, mtot^d) real (+-1 probes), out: ((2 mtot - 1)^d) complex. */
+int efgp_lag_sums(int device, int dim, int64_t mtot, const void* gamma, const double* eta, int nprobes, void* out, void* stream);
+/* 'regular' variance (compute_prediction_variance, :1805-1820): explicit feature rows f_k(x*) = exp(2 pi i h k . x*) on the
+ * (mtot,)^d mode box (k = -(mtot-1)/2 .. (mtot-1)/2 per dimension, last dimension fastest).
+ *   efgp_variance_rhs:      rhs[b, k] = ws[k] * conj(f_k(x*_b))                       (right-hand sides of the A_var solves)
+ *   efgp_variance_contract: out[b]    = max(0, Re sum_k f_k(x*_b) ws[k] gamma[b, k])  (gamma = the solutions)
+ * x_new: (npts, dim) doubles; ws: (mtot^d) complex; rhs / gamma: (npts, mtot^d) complex; out: (npts) doubles. */
+int efgp_variance_rhs(int device, int dim, int64_t mtot, double h, const double* x_new, int64_t npts, const void* ws, void* rhs,
+                      void* stream);
+int efgp_variance_contract(int device, int dim, int64_t mtot, double h, const double* x_new, int64_t npts, const void* ws,
+                           const void* gamma, double* out, void* stream);
+
+/* ---- collectives of the point-sharded fit (one process per GPU, RCCL over xGMI) ------------------------------------
+ * The reference has no distributed code; sharding the N observation points needs exactly these sums between the spread
+ * pass and the replicated solve: the gridded partials F*y and v (efgpnd.py:118-124 / 786-790), the batched F*Z of the
+ * gradient (:186-189) and its N-length scalars (:163, 170, 239), plus MIN/MAX of the coordinates for the domain length
+ * (:752-759) and a broadcast for state that is drawn at random (probe seeds, feature-space probes).
+ * efgp_comm_unique_id: HOST buffer of 128 bytes, filled on rank 0 and carried to the other ranks by the caller.
+ * All buffers are DEVICE pointers; calls are stream-ordered (no host synchronisation). */
+int efgp_comm_unique_id(void* id_out_128_bytes);
+int efgp_comm_init(efgp_comm_t** comm_out, int device, int rank, int world_size, const void* unique_id_128_bytes);
+int efgp_comm_allreduce_sum(efgp_comm_t* comm, double* buf, size_t n_doubles, void* stream);
+int efgp_comm_allreduce_minmax(efgp_comm_t* comm, double* buf, size_t n_doubles, int take_max, void* stream);
+int efgp_comm_broadcast(efgp_comm_t* comm, void* buf, size_t nbytes, int root, void* stream);
+int efgp_comm_destroy(efgp_comm_t* comm);
 
 #ifdef __cplusplus
 }

@@ -229,6 +229,14 @@ def c5_matern32_3d_n20000():
 
 
 @case
+def c5b_matern32_3d_l02_n20000():
+    # SURVEY's C5 hyper-parameters (3-D Matern-3/2, l = 0.2): mtot = 29 at eps = 1e-2 (the c5 case above uses l = 0.3 -> mtot = 19)
+    x, y = synth(20000, 3, 1)
+    run_case("c5b_matern32_3d_l02_n20000", x, y, "matern", 0.2, 1.5, 0.2, 1e-2, nu=1.5, store_inputs=False, J=4,
+             inputs_note="synth(N=20000,d=3,seed=1) of oracle/gen_golden.py (torch CPU generator)")
+
+
+@case
 def s1_se2d_n100():
     x, y = load_pair("gp_samples_100_0.5_2_0.2.pt")
     run_case("s1_se2d_n100", x, y, "se", 0.5, 2.0, 0.2, 1e-5, inputs_note="data/gp_samples_100_0.5_2_0.2.pt")

@@ -60,6 +60,14 @@ def _worker(rank, world, port, q):
         FZ = O.nudft_type1(xs, h, Z, (mtot, mtot)).reshape(3, -1)
         sh.sum_(FZ)
         e3 = float((FZ[0] - v_full[4:13, 4:13].reshape(-1)).abs().max())
+        # replicated random state must come from one rank: broadcast_ / shared_seed with different per-rank generators
+        torch.manual_seed(100 + rank)
+        V = torch.empty(4, 9).bernoulli_(0.5)
+        sh.broadcast_(V)
+        seed = sh.shared_seed("cpu")
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (V.tolist(), seed))
+        assert all(gv == gathered[0] for gv in gathered), "broadcast_/shared_seed differ across ranks"
         tot = sh.sum_scalars([float(hi - lo), float(ys.sum())], "cpu")
         mn, mx = sh.minmax(xs.min(0).values, xs.max(0).values)
         ok = (e1 < 1e-12 and e2 < 1e-12 and e3 < 1e-9 and tot[0] == N and abs(tot[1] - float(y.sum())) < 1e-9

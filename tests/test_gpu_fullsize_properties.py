@@ -113,3 +113,86 @@ def test_fit_residual_and_mean_at_full_size():
     beta0 = st["beta"].clone()
     m._compute_common_parameters(force_recompute=True)
     assert torch.equal(m._fit_state["beta"], beta0)                       # fixed-point spreader + fixed CG: reproducible
+
+
+def test_layout_spreader_at_full_size():
+    """N = 1e7, d = 2 (the north_star configuration) through the per-model point layout (MFMA spreader): equals the plain
+    plan to the tolerance, exact on a subset of modes, counts the points in the k = 0 mode, reproducible bit for bit."""
+    from efgp_hip import NufftPlan, PointSet
+    N = 10_000_000
+    x, y = _data(N, seed=11)
+    shape, conv = (MTOT, MTOT), (2 * MTOT - 1, 2 * MTOT - 1)
+    pts = PointSet(x, values=y)
+    plan = NufftPlan(x, H, TOL, points=pts)
+    Fy, v = plan.type1_pair(y, shape, conv)
+    c = MTOT - 1
+    assert abs(complex(v[c, c]) - N) < 1e-9 * N                                 # exact integer accumulation of the ones channel
+    assert _rel(v.flip(0, 1).conj(), v) < 1e-12 and _rel(Fy.flip(0, 1).conj(), Fy) < 1e-12
+    g = torch.Generator().manual_seed(1)
+    sel = torch.randint(0, MTOT, (6, 2), generator=g)
+    k = (sel - (MTOT - 1) // 2).to(torch.float64).cuda()
+    ref = _exact_type1_modes(x, y, k)
+    assert float((Fy[sel[:, 0].cuda(), sel[:, 1].cuda()] - ref).abs().max() / Fy.abs().max()) < 5 * TOL
+    Fy0, v0 = NufftPlan(x, H, TOL).type1_pair(y, shape, conv)
+    assert _rel(Fy, Fy0) < 5 * TOL and _rel(v, v0) < 5 * TOL
+    Fy2, v2 = plan.type1_pair(y, shape, conv)
+    assert torch.equal(Fy, Fy2) and torch.equal(v, v2)
+    # generated probes through the sorted copies equal the materialised ones
+    from efgp_hip import rademacher_fill
+    Zf = plan.type1_rademacher(5, 3, shape)
+    Z = rademacher_fill(x.device, 5, 3, N)
+    assert _rel(Zf, NufftPlan(x, H, TOL).type1(Z, shape)) < 5 * TOL
+
+
+def test_c5_fullsize_3d_properties():
+    """BASELINE configs[4] at full size: 3-D Matern-3/2 (l = 0.2, eps = 1e-3 -> mtot = 57, circulant grid 128^3), N = 5e6.
+    Adjointness, the k = 0 mode, shard additivity, exact values on a subset, residual of the solve, and one
+    hyper-gradient step (finite, reproducible for a fixed probe seed)."""
+    from efgpnd import EFGPND, create_A_mean
+    from efgp_hip import NufftPlan
+    from kernels.matern import Matern
+    N, d = 5_000_000, 3
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.rand(N, d, generator=g, dtype=torch.float64, device="cuda") * 2 - 1
+    y = torch.sin(3 * x[:, 0]) * torch.cos(4 * x[:, 1]) * torch.cos(2 * x[:, 2]) + 0.3 * torch.randn(N, generator=g, dtype=torch.float64, device="cuda")
+    k = Matern(dimension=d, nu=1.5, init_lengthscale=0.2, init_variance=1.5)
+    tol, ntol = 1e-5, 1e-6
+    m = EFGPND(x, y, k, sigmasq=0.2, eps=1e-3, nufft_eps=ntol, estimate_params=False,
+               opts={"cg_tolerance": tol, "mean_cg_warm_start": False})
+    m.fit()
+    st = m._fit_state
+    mtot, h = st["mtot"], st["h"]
+    assert mtot == 57 and list(m._toeplitz.fft_shape) == [128, 128, 128]
+    shape = (mtot,) * d
+    Fy, v = st["Fy"].reshape(shape), st["v"]
+    c = 2 * ((mtot - 1) // 2)
+    assert abs(complex(v[c, c, c]) - N) < 5 * 6e-8 * N                              # the Toeplitz vector is always computed to 6e-8
+    assert _rel(v.flip(0, 1, 2).conj(), v) < 1e-12
+    # exact values of F*y on a few modes
+    gs = torch.Generator().manual_seed(2)
+    sel = torch.randint(0, mtot, (4, d), generator=gs)
+    kk = (sel - (mtot - 1) // 2).to(torch.float64).cuda()
+    ph = -2 * math.pi * h * (x @ kk.T)
+    ref = (torch.complex(torch.cos(ph), torch.sin(ph)) * y[:, None].to(torch.complex128)).sum(0)
+    got = Fy[sel[:, 0].cuda(), sel[:, 1].cuda(), sel[:, 2].cuda()]
+    assert float((got - ref).abs().max() / Fy.abs().max()) < 5 * 6e-8
+    # adjointness <F* y, f> = <y, F f> through a plan at the prediction tolerance, and additivity over two shards
+    plan = NufftPlan(x, h, ntol)
+    f = torch.complex(torch.randn(shape, generator=gs, dtype=torch.float64), torch.randn(shape, generator=gs, dtype=torch.float64)).cuda()
+    Ff = plan.type2(f, shape)
+    Fy_p = plan.type1(y, shape)
+    lhs, rhs = torch.vdot(Fy_p.reshape(-1), f.reshape(-1)), torch.vdot(y.to(torch.complex128), Ff)
+    assert abs(complex(lhs - rhs)) < 5 * ntol * float(torch.linalg.norm(y) * torch.linalg.norm(Ff))
+    half = N // 2
+    parts = NufftPlan(x[:half], h, ntol).type1(y[:half], shape) + NufftPlan(x[half:], h, ntol).type1(y[half:], shape)
+    assert _rel(parts, Fy_p) < 5 * ntol
+    # the solved beta satisfies the normal equations to the CG tolerance (cg.py:132)
+    A = create_A_mean(st["ws"], m._toeplitz, st["sig"], torch.complex128)
+    assert _rel(A(st["beta"]), st["ws"] * st["Fy"]) < 1.05 * tol
+    # one hyper-gradient step of the training loop: finite, and identical when the probe seed is fixed
+    V = torch.ones(2, st["ws"].numel(), dtype=torch.float64)
+    V[1, ::2] = -1
+    g1 = m.compute_gradients(trace_samples=2, cg_tol=1e-3, probe_seed=99, probes_V=V).detach().cpu()
+    g2 = m.compute_gradients(trace_samples=2, cg_tol=1e-3, probe_seed=99, probes_V=V).detach().cpu()
+    assert torch.isfinite(g1).all() and g1.abs().max() > 0
+    assert float((g1 - g2).abs().max()) <= 1e-9 * float(g1.abs().max())          # warm-started mean solve: same to rounding

@@ -92,3 +92,56 @@ def test_two_shards_equal_unsharded():
         scale = float(m.last_gradient_stats["term1"].abs().max()) * float(m._gp_params.pos.detach().max())
         assert float((sgrad - grad).abs().max()) < 1e-7 * scale
         assert abs(its - m.last_fit_stats["mean_cg_iters"]) <= 1
+
+
+def _worker_free(rank, world, port, q):
+    """No injected probes, DIFFERENT torch seeds per rank (the usual manual_seed(seed + rank)): the replicas must stay
+    identical -- probe seed and feature-space probes come from rank 0 -- through two optimizer steps."""
+    sys.path.insert(0, os.path.join(ROOT, "gp-quadrature_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from efgpnd import EFGPND
+        from efgp_hip.dist import shard_bounds
+        from kernels.squared_exponential import SquaredExponential
+        torch.manual_seed(1000 + rank)
+        x, y, xn = _data()
+        lo, hi = shard_bounds(x.shape[0], world, rank)
+        k = SquaredExponential(dimension=2, init_lengthscale=0.25, init_variance=1.3)
+        m = EFGPND(x[lo:hi].cuda(), y[lo:hi].cuda(), k, sigmasq=0.1, eps=1e-4, nufft_eps=1e-9, estimate_params=False,
+                   opts={"cg_tolerance": 1e-10, "shard_points": True})
+        opt = torch.optim.Adam(m._gp_params.parameters(), lr=0.1)
+        m.register_optimizer(opt)
+        grads, mtots = [], []
+        for _ in range(2):
+            opt.zero_grad()
+            g = m.compute_gradients(trace_samples=3, cg_tol=1e-10)
+            grads.append(g.detach().cpu().clone())
+            mtots.append(int(m.last_gradient_stats["mtot"]))
+            opt.step()
+        _, var = m.predict(xn.cuda(), variance_method="stochastic", hutchinson_probes=8)
+        hyp = [float(m.kernel.get_hyper(n)) for n in m.kernel.hypers] + [float(m.sigmasq.detach())]
+        q.put((rank, torch.stack(grads), mtots, hyp, var.cpu()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_shards_stay_identical_without_injected_probes():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_free, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, m0, h0, v0), (_, g1, m1, h1, v1) = res
+    assert torch.equal(g0, g1), (g0, g1)               # bit-identical gradients on both ranks, both steps
+    assert m0 == m1 and h0 == h1                       # same grids and hyper-parameters after two optimizer steps
+    assert torch.equal(v0, v1)                         # the stochastic variance uses rank 0's probes too
+    assert torch.isfinite(g0).all()
