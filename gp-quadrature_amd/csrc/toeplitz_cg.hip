@@ -136,7 +136,7 @@ struct CgRowScalars {   // one per row
     int pad_;
 };
 
-constexpr int kCgBlocksMax = 64;     // workgroups per system in the multi-kernel update (partials per reduction)
+constexpr int kCgBlocksMax = 256;    // workgroups per system in the multi-kernel update (partials per reduction; <= block size)
 
 struct CgArgs {
     ToepGeom g;
@@ -1132,7 +1132,7 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         int* d_rows = a.status + 16;
         a.counter = (int*)(scb + off_counter);
         a.partial = (double*)(scb + off_partial);
-        a.nblk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(kCgBlocksMax, (g.M + kVecThreads - 1) / kVecThreads),
+        a.nblk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(64 /* update kernels: measured optimum */, (g.M + kVecThreads - 1) / kVecThreads),
                                                             std::max<int64_t>(1, 1024 / rows)));
         EFGP_HIP_CHECK(hipMemsetAsync(a.status, 0, off_partial - off_status, stream));      // status, map, counters
 
@@ -1180,7 +1180,15 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
             EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg_rows_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
             EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg_cols_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));
         }
-        const bool use_lines3 = op->lines3_ok && std::getenv("EFGP_NO_CG_LINES") == nullptr;
+        bool use_lines3 = op->lines3_ok && std::getenv("EFGP_NO_CG_LINES") == nullptr;
+        if (use_lines3) {
+            // the line kernels keep 2 x lpb lines of F2 + 1 elements in LDS and one partial sum per workgroup: both limits must
+            // hold (found at full size: mtot = 57, F = 128 asked for 64 lines per block = 266 KB of LDS)
+            const int64_t fit = ((int64_t)ctx->max_lds / (int64_t)sizeof(double2) - g.F[2]) / (2 * (g.F[2] + 1));
+            int64_t lmax = 16;
+            while (lmax * 2 <= fit) lmax <<= 1;
+            if (fit < 16 || (g.n[0] * g.n[1] + lmax - 1) / lmax > kCgBlocksMax) use_lines3 = false;
+        }
         Line3Args l3;
         size_t lds3_c = 0, lds3_s[3] = {0, 0, 0};
         if (use_lines3) {
@@ -1189,10 +1197,10 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
             l3.b1 = pad;
             l3.b2 = pad + (int64_t)rows * g.n[0] * g.n[1] * g.F[2];
             const int64_t nlines = g.n[0] * g.n[1];
+            const int64_t fit = ((int64_t)ctx->max_lds / (int64_t)sizeof(double2) - g.F[2]) / (2 * (g.F[2] + 1));
             int lpb = 16;
-            while ((nlines + lpb - 1) / lpb > kCgBlocksMax) lpb <<= 1;
+            while ((nlines + lpb - 1) / lpb > kCgBlocksMax && lpb * 2 <= fit) lpb <<= 1;
             if (rows > 8) {                               // batched: fewer, larger workgroups (fewer reduction fences)
-                const int64_t fit = ((int64_t)ctx->max_lds / (int64_t)sizeof(double2) - g.F[2]) / (2 * (g.F[2] + 1));
                 while (lpb * 2 <= fit && lpb < 64) lpb <<= 1;
             }
             l3.lpb_c = lpb;
