@@ -301,19 +301,19 @@ static hipError_t launch_w(dim3 grid, int waves, hipStream_t s, const MfmaSpread
     const bool sorted = a.ys != nullptr;
     const size_t lds = mfma_lds_bytes(waves);
     const dim3 block(64 * waves);
-#define EFGP_GO(deg_, sorted_)                                                                                       \
+#define EFGP_GO(kern_)                                                                                               \
     do {                                                                                                             \
-        auto k = spread_mfma_kernel<W, deg_, sorted_>;                                                               \
+        auto k = kern_;                                                                                              \
         if (lds > 65536) {                                                                                           \
             hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e;                                                                           \
         }                                                                                                            \
         hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                               \
     } while (0)
-    if (fixed_deg && sorted) EFGP_GO(W + 1, true);
-    else if (fixed_deg) EFGP_GO(W + 1, false);
-    else if (sorted) EFGP_GO(0, true);
-    else EFGP_GO(0, false);
+    if (fixed_deg && sorted) EFGP_GO((spread_mfma_kernel<W, W + 1, true>));
+    else if (fixed_deg) EFGP_GO((spread_mfma_kernel<W, W + 1, false>));
+    else if (sorted) EFGP_GO((spread_mfma_kernel<W, 0, true>));
+    else EFGP_GO((spread_mfma_kernel<W, 0, false>));
 #undef EFGP_GO
     return hipGetLastError();
 }
@@ -346,6 +346,10 @@ int spread_mfma_launch(DeviceCtx* ctx, const SortedLevel* lvl, const double* ys_
     // Two workgroups of four waves per CU (176 VGPRs and 16.9 KB of LDS rows per wave: two waves per SIMD); a wave strides
     // over the chunks (points_layout.hip sizes them for 8 waves per CU and several rounds).  Measured at N = 1e7:
     // 4 x 2 221 us, 3 x 3 (LDS table) 270 us, 1 x 9 265 us.
+    // (Tried and measured at N = 1e7, all slower than 4 x 2 = 221 us: a Horner table in LDS with 3 x 3 waves 270 us / 4 x 4
+    // waves and compact rows 231-241 us; a software-pipelined one-wave-per-SIMD variant with double-buffered rows that
+    // interleaves the polynomials of batch n + 1 with the MFMAs of batch n 288-296 us -- the compiler's conservative
+    // s_waitcnt vmcnt(0) at the merge of its two paths exposes the HBM latency of the prefetched points.)
     int waves = 4, per_cu = 2;
     if (const char* e1 = std::getenv("EFGP_MFMA_WAVES")) waves = std::max(1, std::min(kMfmaMaxWaves, std::atoi(e1)));
     if (const char* e2 = std::getenv("EFGP_MFMA_BLOCKS_PER_CU")) per_cu = std::max(1, std::atoi(e2));
