@@ -55,6 +55,7 @@ DeviceCtx* device_ctx(int device) {
 
 void* scratch(DeviceCtx* ctx, Slot slot, size_t bytes) {
     if (bytes == 0) bytes = 256;
+    if (slot == SLOT_SLABS) ctx->slabs_zero_bytes = 0;      // callers that rely on it re-establish it themselves
     if (ctx->cap[slot] >= bytes) return ctx->buf[slot];
     size_t want = bytes + bytes / 4;
     want = (want + 255) & ~size_t(255);

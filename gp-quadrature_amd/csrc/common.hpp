@@ -83,6 +83,9 @@ struct DeviceCtx {
     std::map<int64_t, void*> twiddles;
     // SLOT_SCALE holds the spreader's max|c| accumulator: zeroed once, then reset by the kernel that consumes it
     bool scale_slot_ready = false;
+    // leading bytes of SLOT_SLABS known to be zero: the MFMA spreader's int64 grid is reset by the kernel that converts it,
+    // so the next spread needs no memset launch (any other request for the slot clears this)
+    size_t slabs_zero_bytes = 0;
     // side stream for hipGraph capture (capture is not allowed on the legacy default stream torch usually hands us)
     hipStream_t aux_stream = nullptr;
     hipEvent_t aux_event = nullptr;

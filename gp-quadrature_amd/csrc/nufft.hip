@@ -493,7 +493,7 @@ __global__ __launch_bounds__(1024) void maxabs_kernel(const double* __restrict__
 template <bool FIXED>
 __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const double* __restrict__ slabs, int nslab, int channels,
                                                             int64_t cells, const double* __restrict__ scale,
-                                                            double2* __restrict__ fine) {
+                                                            double2* __restrict__ fine, int reset_source = 0) {
     // 8 (512 threads) or 16 (1024 threads) slab groups per 64 cells: the many-slab integer reduction is a chain of
     // latency-bound loads, so it takes the wider block (245 slabs of 96 x 96 x 2: 12.9 -> 8.4 us)
     __shared__ double part[2][8][64];
@@ -529,6 +529,11 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const double* __rest
                 b += ipart[1][g][lane_cell];
             }
             fine[(int64_t)batch * cells + cell] = make_double2((double)a * scale[1], (double)b * scale[3]);
+            if (reset_source) {       // single int64 grid (MFMA spreader): leave it zeroed for the next pass
+                long long* src = reinterpret_cast<long long*>(const_cast<double*>(base));
+                src[cell] = 0;
+                if (channels == 2) src[cells + cell] = 0;
+            }
         }
     } else {
         part[0][grp][lane_cell] = re;
@@ -2214,6 +2219,8 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
             ys = lvl->ys;
         }
         const size_t acc_bytes = (size_t)nbatch * channels * (size_t)g.cells * sizeof(long long);
+        const size_t known_zero = ctx->slabs_zero_bytes;
+        const void* slabs_before = ctx->buf[SLOT_SLABS];
         unsigned long long* gacc = (unsigned long long*)scratch(ctx, SLOT_SLABS, acc_bytes);
         double2* fine = (double2*)scratch(ctx, SLOT_FINE, (size_t)nbatch * (size_t)g.cells * sizeof(double2));
         char* misc = scale_slot(ctx, stream);
@@ -2221,10 +2228,22 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         double* d_scale = (double*)misc;
         unsigned long long* d_cmax = (unsigned long long*)(misc + 56);
         if (scale_out) *scale_out = d_scale;
-        EFGP_HIP_CHECK(hipMemsetAsync(gacc, 0, acc_bytes, stream));
+        // the converting kernel below zeroes what it reads: back-to-back passes of this path need no memset launch
+        if (known_zero < acc_bytes || slabs_before != (const void*)gacc) EFGP_HIP_CHECK(hipMemsetAsync(gacc, 0, acc_bytes, stream));
         // the global int64 grid sums over ALL points: the scale is bounded with N
-        const ScaleJob job{floor_bound, mode == STR_REAL_AND_ONES ? 1 : 0, plan->npts, d_scale, 61};
-        if (need_max && ys && plan->points->d_values_max) {
+        ScaleJob job{floor_bound, mode == STR_REAL_AND_ONES ? 1 : 0, plan->npts, d_scale, 61};
+        if (need_max && ys && plan->points->d_values_max && mode == STR_REAL_AND_ONES) {
+            // the fit-time pair on the attached targets: max|y|, N and the bit budget are fixed per model, so the scale block is
+            // computed once per attach and kept with the layout (one launch less per fit)
+            efgp_points_s* pts = plan->points;
+            d_scale = pts->d_pair_scale;
+            job.scale = d_scale;
+            if (scale_out) *scale_out = d_scale;
+            if (!pts->pair_scale_ready) {
+                hipLaunchKernelGGL(fixed_scale_cached_kernel, dim3(1), dim3(64), 0, stream, (const unsigned long long*)pts->d_values_max, job);
+                pts->pair_scale_ready = true;
+            }
+        } else if (need_max && ys && plan->points->d_values_max) {
             hipLaunchKernelGGL(fixed_scale_cached_kernel, dim3(1), dim3(64), 0, stream,
                                (const unsigned long long*)plan->points->d_values_max, job);
         } else if (need_max) {
@@ -2240,8 +2259,9 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         if (rc != EFGP_OK) return rc;
         const int rb = (int)((g.cells + 63) / 64);
         hipLaunchKernelGGL((reduce_slabs_kernel<true>), dim3(rb, nbatch), dim3(512), 0, stream, (const double*)gacc, 1,
-                           channels, g.cells, (const double*)d_scale, fine);
+                           channels, g.cells, (const double*)d_scale, fine, 1);
         EFGP_HIP_CHECK(hipGetLastError());
+        ctx->slabs_zero_bytes = acc_bytes;
         hipfftHandle fh;
         rc = fft_plan(ctx, plan->dim, g.nf, nbatch, stream, &fh);
         if (rc != EFGP_OK) return rc;

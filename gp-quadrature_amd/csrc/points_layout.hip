@@ -331,9 +331,14 @@ int efgp_points_attach_values(efgp_points_t* pts, const double* y, void* stream_
     DeviceGuard guard(pts->device);
     hipStream_t stream = (hipStream_t)stream_;
     pts->values = y;
+    pts->pair_scale_ready = false;
     for (SortedLevel* l : pts->levels) l->ys_src = nullptr;      // sorted copies are rebuilt on next use
     if (y && pts->npts > 0) {
-        if (!pts->d_values_max) EFGP_HIP_CHECK(hipMalloc((void**)&pts->d_values_max, 8));
+        if (!pts->d_values_max) {
+            EFGP_HIP_CHECK(hipMalloc((void**)&pts->d_values_max, 128));          // [0] max|y| bits, [64..128) the pair scale block
+            pts->d_pair_scale = reinterpret_cast<double*>(reinterpret_cast<char*>(pts->d_values_max) + 64);
+        }
+        pts->pair_scale_ready = false;
         EFGP_HIP_CHECK(hipMemsetAsync(pts->d_values_max, 0, 8, stream));
         const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((pts->npts + 255) / 256, 2048));
         hipLaunchKernelGGL(values_max_kernel, dim3(blocks), dim3(256), 0, stream, y, pts->npts, pts->d_values_max);

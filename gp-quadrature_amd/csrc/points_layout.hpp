@@ -46,6 +46,8 @@ struct efgp_points_s {
     const double* x = nullptr;           // user-order coordinates (caller-owned)
     const double* values = nullptr;      // attached user-order strengths (caller-owned) or null
     unsigned long long* d_values_max = nullptr;   // device word: max|values| as an ordered bit pattern (set by attach)
+    double* d_pair_scale = nullptr;               // fixed-point scale block of the (values, ones) pass (nufft.hip fills it once)
+    bool pair_scale_ready = false;
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};   // bounding box
     efgp::DeviceCtx* ctx = nullptr;
     std::vector<efgp::SortedLevel*> levels;

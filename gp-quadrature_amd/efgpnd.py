@@ -802,6 +802,7 @@ class EFGPND(nn.Module):
         self._devdata = None
         self._fit_state = None
         self._predict_plan = None
+        self._nan_scalar = None
         # shard_points: True = torch.distributed default group; an efgp_hip.RcclComm = the library's own RCCL communicator
         sp = self.opts.get("shard_points", False)
         self._shards = PointShards(comm=sp) if (sp is not None and not isinstance(sp, bool)) else PointShards(enabled=bool(sp))
@@ -1029,7 +1030,9 @@ class EFGPND(nn.Module):
         else:
             # the reference fills a (B,) tensor with NaN (efgpnd.py:947): same values as a stride-0 view of ONE NaN, without
             # writing 8 B bytes per call (16 us and 80 MB of traffic per predict at N = 1e7)
-            var = torch.full((1,), float("nan"), device=self.device, dtype=rdtype).expand(B)
+            if self._nan_scalar is None or self._nan_scalar.device != self.device or self._nan_scalar.dtype != rdtype:
+                self._nan_scalar = torch.full((1,), float("nan"), device=self.device, dtype=rdtype)     # once per model
+            var = self._nan_scalar.expand(B)
         t2 = time.perf_counter()
         if do_profiling:
             torch.cuda.synchronize(dev)
