@@ -654,6 +654,12 @@ __device__ __forceinline__ void conj8(double2 (&v)[8]) {
 
 __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
     using namespace s64;
+    // Row pitch 72 (not s64::LD = 65): the eight butterflies of a row sit in EIGHT ADJACENT LANES of one wave (lane = row * 8 + j),
+    // so that both radix-8 stages of a row transform run inside that wave with only a wave-level fence between them (no
+    // workgroup barrier: 2 of the 10 barriers per iteration gone, and the three row waves no longer wait for each other).
+    // With that lane map a 16-lane LDS group covers two rows x eight j: pitch = 8 mod 16 (in 16-byte elements) puts them on
+    // 16 distinct slots.  Column passes read 64 consecutive elements per wave: conflict free at any pitch.
+    constexpr int LD = 72, BUF = F * LD;
     constexpr int KS = 2;                   // M = n*n <= 1024 = KS * kThreads
     extern __shared__ double2 lds2[];
     __shared__ double red[3 * kRedWaves];
@@ -666,9 +672,9 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
     const int tid = threadIdx.x;
 
     // ---- iteration-invariant per-thread data -------------------------------------------------
-    // row passes: 32 candidate lines x 8 butterflies (threads 0..255); column passes: 64 x 8 (all threads)
-    const int r_row = tid & 31, j_row = tid >> 5;
-    const bool row_act = j_row < 8 && r_row < n;
+    // row passes: lane = row * 8 + butterfly (rows 8w..8w+7 in wave w); column passes: 64 columns x 8 (all threads)
+    const int j_row = tid & 7, r_row = tid >> 3;
+    const bool row_act = r_row < n;
     const int c_col = tid & 63, j_col = tid >> 6;
     // valid leading inputs of the pruned first stages: positions j + 8t < n
     const int nv_row = j_row < n ? (n - 1 - j_row) / 8 + 1 : 0;
@@ -723,15 +729,16 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
         __syncthreads();
         EFGP_STAMP(0);
         double2 v[8];
-        // P1/P2: forward FFT along dim 1 of the n non-zero rows (A -> B -> A)
+        // P1/P2: forward FFT along dim 1 of the n non-zero rows (A -> B -> A); a row lives in one wave: wave-level fence only
         if (row_act) {
             load8<8>(bufA + r_row * LD + j_row, nv_row, v);
             dft_fwd<8>(v);
-            store8_all<1>(bufB + r_row * LD + j_row * 8, v);
+            store8_all<1>(bufB + r_row * LD + j_row * 9, v);      // butterfly j at [9 j, 9 j + 8): both sides conflict free
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         if (row_act) {
-            load8_all<8>(bufB + r_row * LD + j_row, v);
+            load8_all<9>(bufB + r_row * LD + j_row, v);
             twiddle8(v, twr);
             dft_fwd<8>(v);
             store8_all<8>(bufA + r_row * LD + j_row, v);
@@ -771,11 +778,12 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
             conj8(v);
             dft_fwd<8>(v);
             conj8(v);
-            store8_all<1>(bufA + wrow * LD + j_row * 8, v);
+            store8_all<1>(bufA + wrow * LD + j_row * 9, v);
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         if (row_act) {
-            load8_all<8>(bufA + wrow * LD + j_row, v);
+            load8_all<9>(bufA + wrow * LD + j_row, v);
             conj8(v);
             twiddle8(v, twr);
             dft_fwd<8>(v);
@@ -1196,7 +1204,7 @@ int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, con
             attr64 = true;
         }
         KernelTimer timer("cg_solve", stream);
-        hipLaunchKernelGGL(cg_persistent_2d64_kernel, dim3(rows), dim3(kThreads), (size_t)2 * s64::BUF * sizeof(double2),
+        hipLaunchKernelGGL(cg_persistent_2d64_kernel, dim3(rows), dim3(kThreads), (size_t)2 * 64 * 72 * sizeof(double2),
                            stream, a);
     } else {
         KernelTimer timer("cg_solve", stream);
