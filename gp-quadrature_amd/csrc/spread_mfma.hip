@@ -357,6 +357,9 @@ int spread_mfma_launch(DeviceCtx* ctx, const SortedLevel* lvl, const double* ys_
     a.total_waves = blocks * waves;
     a.diag = std::getenv("EFGP_MFMA_DIAG") ? std::atoi(std::getenv("EFGP_MFMA_DIAG")) : 0;
     hipError_t e;
+    // (Several channel pairs in ONE pass -- windows evaluated once, one accumulator tile per pair, A = c wx formed per step --
+    // was measured for the probe transforms of the gradient: 0.876 ms instead of 0.779 ms for T = 5 at N = 1e7; the pass is
+    // bound by its MFMA phase, which that variant lengthens.  Pairs stay separate launches of grid.y.)
     {
         KernelTimer timer("spread", stream);
         switch (W) {

@@ -127,3 +127,29 @@ def test_model_fit_uses_layout_and_matches_plain(monkeypatch):
     mean_b, grad_b, _ = run()
     assert float((mean_a - mean_b).abs().max() / mean_b.abs().max()) < 1e-5
     assert float((grad_a - grad_b).abs().max() / grad_b.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("T", [4, 5, 7, 9])
+def test_many_probe_rows_in_one_pass(T):
+    """Many probe rows (pairs of real rows per fine grid, an odd last row alone): generated probes and rows from memory, even
+    and odd counts, against the plain plan and the exact sums."""
+    from efgp_hip import NufftPlan, PointSet, rademacher_fill
+    from oracle import efgp_oracle as O
+    N, h, nm, tol = 50000, 0.31, 23, 1e-5
+    x, y = _data(N, 31 + T)
+    xd = x.cuda()
+    plan = NufftPlan(xd, h, tol, points=PointSet(xd))
+    plain = NufftPlan(xd, h, tol)
+    seed, off = 99 + T, 7
+    FR = plan.type1_rademacher(seed, T, (nm, nm), index_offset=off)
+    R = rademacher_fill(xd.device, seed, T, N, index_offset=off)
+    assert _rel(FR, plain.type1(R, (nm, nm))) < 5 * tol
+    assert torch.equal(FR, plan.type1_rademacher(seed, T, (nm, nm), index_offset=off))
+    g = torch.Generator().manual_seed(T)
+    Z = torch.randn(T, N, generator=g, dtype=torch.float64)
+    out = plan.type1(Z.cuda(), (nm, nm))
+    for b in (0, T // 2, T - 1):
+        assert _rel(out[b], O.nudft_type1(x, h, Z[b], (nm, nm))) < 5 * tol
+    C = torch.complex(Z[:3], Z[1:4])
+    outc = plan.type1(C.cuda(), (nm, nm))
+    assert _rel(outc, plain.type1(C.cuda(), (nm, nm))) < 5 * tol
