@@ -414,6 +414,17 @@ struct ScaleJob {            // what fixed_scale_write needs besides max|c|
 };
 __device__ __forceinline__ void fixed_scale_write(double cmax, double floor_bound, int ones_channel, int64_t per,
                                                   double* __restrict__ scale, int sum_bits) {
+    if (!isfinite(cmax)) {
+        // NaN / Inf among the strengths: the fixed-point sums are meaningless; a NaN inverse scale turns every output of the
+        // transform into NaN, which is what the reference's floating-point sums give (FINUFFT propagates them)
+        const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+        scale[0] = 1.0;
+        scale[1] = qnan;
+        scale[2] = 1.0;
+        scale[3] = ones_channel ? 1.0 : qnan;
+        scale[4] = 1.0;
+        return;
+    }
     if (!ones_channel) {
         const double S0 = fixed_scale_for(fmax(cmax, floor_bound), per, sum_bits);
         scale[0] = S0;
@@ -467,9 +478,10 @@ __global__ __launch_bounds__(1024) void maxabs_kernel(const double* __restrict__
     const double2* c2 = reinterpret_cast<const double2*>(c);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
         const double2 v = c2[i];
-        m = fmax(m, fmax(fabs(v.x), fabs(v.y)));
+        // fmax drops NaN: a non-finite strength must poison the transform (the reference returns NaN), not vanish
+        m = fmax(m, fmax(isfinite(v.x) ? fabs(v.x) : INFINITY, isfinite(v.y) ? fabs(v.y) : INFINITY));
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) m = fmax(m, fabs(c[n - 1]));
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) m = fmax(m, isfinite(c[n - 1]) ? fabs(c[n - 1]) : INFINITY);
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
     __syncthreads();

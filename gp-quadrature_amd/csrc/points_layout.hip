@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void gather_values_kernel(const double* __rest
 // max|y| of the attached strengths as an ordered bit pattern (non-negative doubles compare like integers)
 __global__ __launch_bounds__(256) void values_max_kernel(const double* __restrict__ y, int64_t n, unsigned long long* __restrict__ out) {
     double m = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmax(m, fabs(y[i]));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmax(m, isfinite(y[i]) ? fabs(y[i]) : INFINITY);            // non-finite targets poison the fit (see fixed_scale_write)
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
 }

@@ -52,7 +52,13 @@ def apply():
         ranks = 1
     want = max(1, int(math.floor(cores / ranks / 2.0)))
     import torch
-    if torch.get_num_threads() <= want:
+    before = torch.get_num_threads()
+    if before <= want:
         return None
     torch.set_num_threads(want)
+    # a process-wide setting changed at import: say so once (logging, level INFO; EFGP_KEEP_TORCH_THREADS=1 opts out)
+    import logging
+    logging.getLogger("efgp_hip").info("torch CPU threads %d -> %d (cgroup CPU quota %.1f cores, %d rank(s) per node); "
+                                       "set EFGP_KEEP_TORCH_THREADS=1 or OMP_NUM_THREADS to keep your own value",
+                                       before, want, cores, ranks)
     return want

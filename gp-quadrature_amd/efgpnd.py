@@ -364,7 +364,7 @@ def efgpnd_gradient_batched(
         probes_Z: Optional[torch.Tensor] = None, probes_V: Optional[torch.Tensor] = None,
         shards: Optional[PointShards] = None, trace_mode: str = "adjoint", probe_seed: Optional[int] = None,
         domain_length: Optional[float] = None, y_norm_sq: Optional[float] = None, points: Optional[PointSet] = None,
-        log_marginal_probe_vectors: Optional[torch.Tensor] = None):
+        log_marginal_probe_vectors: Optional[torch.Tensor] = None, pointwise_alpha: bool = False):
     """d(negative log marginal likelihood)/d(kernel hypers..., sigma^2) = (term1 - term2)/2 with
     Hutchinson trace estimates (data-space probes Z for non-variance kernel hypers, feature-space
     probes V for the noise) and CG solves.  ``x0, x1`` are ignored as in the reference (:72-73).
@@ -388,6 +388,11 @@ def efgpnd_gradient_batched(
         generated inside the spread kernel (``probe_seed``) so Z never exists in memory.  Agrees with the
         literal sequence to the NUFFT tolerance.
       * ``"reference"`` follows the reference's operation sequence literally (type-2 passes included).
+
+    ``pointwise_alpha`` (adjoint mode only): the adjoint form obtains |y - F g|^2 as yy - 2 Re<F*y, g> + <g, T g>, i.e. by
+    cancellation: the 6e-8 transform error is amplified by yy / |y - F g|^2 (the reference's pointwise alpha only by the
+    square root of that).  For high-SNR data (sigma^2 << signal variance) set it to get alpha = (y - F g)/sigma^2 from ONE
+    real type-2 pass and the two N-length reductions of the reference (:163, :170); everything else stays adjoint.
     """
     if trace_mode not in ("adjoint", "reference"):
         raise ValueError(f"trace_mode must be 'adjoint' or 'reference', got {trace_mode!r}")
@@ -472,8 +477,13 @@ def efgpnd_gradient_batched(
         yy = float(y_norm_sq) if y_norm_sq is not None else shards.sum_scalars([vdot_real(yd, yd)], dev)[0]
         y_z = vdot_m(Fy, beta_s)                               # Re sum_n y_n z_n          (0-dim device tensors:
         z_z = vdot_m(beta_s, Tg)                               # |F g|^2 = <g, T g>         no host round trip)
-        a_norm = (yy - 2.0 * y_z + z_z) / (sig * sig)
-        y_alpha = (yy - y_z) / sig
+        if pointwise_alpha:
+            zr = plan_p.type2(beta_s, grid.shape, real_only=True)          # Re F g at the N points: one real gather
+            alpha_r = (yd - zr) / sig
+            a_norm, y_alpha = shards.sum_scalars([vdot_real(alpha_r, alpha_r), vdot_real(yd, alpha_r)], dev)
+        else:
+            a_norm = (yy - 2.0 * y_z + z_z) / (sig * sig)
+            y_alpha = (yy - y_z) / sig
     else:
         a_norm, y_alpha = shards.sum_scalars([vdot_real(alpha, alpha), vdot_real(yd, alpha)], dev)
     if variance_idx is not None:

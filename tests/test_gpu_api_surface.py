@@ -311,3 +311,30 @@ def test_edge_inputs():
         m.predict(torch.zeros(5, 3, dtype=torch.float64).cuda(), return_variance=False)
     with pytest.raises(ValueError):
         m.predict(None)
+
+
+def test_pointwise_alpha_matches_adjoint_and_nan_targets_poison_the_fit():
+    """`pointwise_alpha` (one real type-2 pass for |alpha|^2, y.alpha) agrees with the adjoint identities at moderate SNR; a
+    NaN among the targets yields NaN predictions (as the reference's sums do), not finite garbage."""
+    from efgpnd import EFGPND
+    from kernels.squared_exponential import SquaredExponential
+    g = torch.Generator().manual_seed(8)
+    N = 40000
+    x = torch.rand(N, 2, generator=g, dtype=torch.float64) * 2 - 1
+    y = torch.sin(3 * x[:, 0]) * torch.cos(4 * x[:, 1]) + 0.2 * torch.randn(N, generator=g, dtype=torch.float64)
+
+    def model(yy):
+        k = SquaredExponential(dimension=2, init_lengthscale=0.2, init_variance=2.0)
+        return EFGPND(x.cuda(), yy.cuda(), k, sigmasq=0.2, eps=1e-4, nufft_eps=1e-7, estimate_params=False,
+                      opts={"cg_tolerance": 1e-10, "mean_cg_warm_start": False})
+    m = model(y)
+    V = torch.ones(2, 529, dtype=torch.float64)
+    V[1, ::2] = -1
+    ga = m.compute_gradients(trace_samples=2, cg_tol=1e-10, probe_seed=5, probes_V=V).detach().cpu()
+    gp = m.compute_gradients(trace_samples=2, cg_tol=1e-10, probe_seed=5, probes_V=V, pointwise_alpha=True).detach().cpu()
+    assert float((ga - gp).abs().max() / ga.abs().max()) < 1e-5
+    ybad = y.clone()
+    ybad[17] = float("nan")
+    mb = model(ybad)
+    mean, _ = mb.predict(x[:100].cuda(), return_variance=False)
+    assert torch.isnan(mean).all()

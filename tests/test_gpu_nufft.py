@@ -288,3 +288,23 @@ def test_type1_ones_many_slabs_no_fixed_point_overflow():
     y = torch.full((N,), 3.0, dtype=torch.float64)
     Fy = plan.type1(y.cuda(), (nm,))
     assert _rel(Fy, 3.0 * v) < 1e-9
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+@pytest.mark.parametrize("N,d,layout", [(3000, 2, False), (50000, 2, True), (3000, 1, False), (40000, 3, False)])
+def test_nonfinite_strengths_propagate(bad, N, d, layout):
+    """A NaN / Inf among the strengths (missing data in y) must poison the transform as the reference's floating-point sums
+    do, on every spreader (LDS fixed point, tiles, MFMA layout) -- not vanish in an fmax or become a finite garbage value."""
+    from efgp_hip import NufftPlan, PointSet
+    x = _points(N, d, 5)
+    y = torch.randn(N, dtype=torch.float64)
+    y[N // 3] = bad
+    xd, yd = x.cuda(), y.cuda()
+    nm = 23 if d < 3 else 9
+    plan = NufftPlan(xd, 0.31, 1e-7, points=PointSet(xd, values=yd)) if layout else NufftPlan(xd, 0.31, 1e-7)
+    Fy, v = plan.type1_pair(yd, (nm,) * d, (2 * nm - 1,) * d)
+    assert not torch.isfinite(Fy).any()
+    out = plan.type1(yd, (nm,) * d)
+    assert not torch.isfinite(out).any()
+    ok = plan.type1(torch.ones(N, dtype=torch.float64).cuda(), (nm,) * d)      # the plan is not left in a bad state
+    assert torch.isfinite(ok).all() and abs(float(ok.reshape(-1)[ok.numel() // 2].real) - N) < 1e-6 * N
