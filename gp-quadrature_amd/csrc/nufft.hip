@@ -23,6 +23,7 @@
 #include "nufft_dev.hpp"
 #include "points_layout.hpp"
 #include "spread_mfma.hpp"
+#include "small_dft.hpp"
 
 namespace efgp {
 
@@ -2780,18 +2781,25 @@ static int type2_impl(efgp_nufft_t* plan, const void* f, const void* mode_scale,
     double2* fine = (double2*)scratch(ctx, SLOT_FINE, (size_t)nbatch * (size_t)g.cells * sizeof(double2));
     if (!fine) return EFGP_ENOMEM;
     ModeGeom m = make_modes(plan, w, n_modes, modeord);
-    {
+    // small 2-D real-output transforms: the real fine grid by ONE dense-DFT launch instead of precorrect + two rocFFT kernels
+    const bool direct_grid = real_only && nbatch == 1 && plan->dim == 2 &&
+                             modes_to_grid_real_eligible((int)g.nf[0], (int)g.nf[1], (int)n_modes[0], (int)n_modes[1]);
+    if (direct_grid) {
+        rc = modes_to_grid_real_launch(ctx, (const double2*)f, (const double2*)mode_scale, (int)n_modes[0], (int)n_modes[1], modeord, isign,
+                                       w->d_fac[0], w->d_fac[1], (int)g.nf[0], (int)g.nf[1], fine, stream);
+        if (rc != EFGP_OK) return rc;
+    } else {
         int threads = 256;
         int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((g.cells + threads - 1) / threads, 2048));
         hipLaunchKernelGGL(precorrect_kernel, dim3(blocks, nbatch), dim3(threads), 0, stream, (const double2*)f,
                            (const double2*)mode_scale, m, real_only ? 1 : 0, g.cells, fine);
         EFGP_HIP_CHECK(hipGetLastError());
+        hipfftHandle fh;
+        rc = fft_plan(ctx, plan->dim, g.nf, nbatch, stream, &fh);
+        if (rc != EFGP_OK) return rc;
+        EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)fine, (hipfftDoubleComplex*)fine,
+                                     isign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
     }
-    hipfftHandle fh;
-    rc = fft_plan(ctx, plan->dim, g.nf, nbatch, stream, &fh);
-    if (rc != EFGP_OK) return rc;
-    EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)fine, (hipfftDoubleComplex*)fine,
-                                 isign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
     const bool cplx = !real_only;
     size_t lds_bytes = (size_t)g.cells * (cplx ? sizeof(double2) : sizeof(double));
     // real outputs: halo-padded LDS copy when it fits (no wrap arithmetic in the gather)

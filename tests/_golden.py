@@ -24,7 +24,8 @@ def synth(N, d, seed):
     return x, y
 
 
-_SEEDED = {"c4_se2d_hard_n100000": (100000, 2, 0), "c5_matern32_3d_n20000": (20000, 3, 1)}
+_SEEDED = {"c4_se2d_hard_n100000": (100000, 2, 0), "c5_matern32_3d_n20000": (20000, 3, 1),
+           "c5b_matern32_3d_l02_n20000": (20000, 3, 1)}
 
 
 def load_case(name):

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 NOMINAL = {"c1_se1d_n5000": ("se", 0.1, 2.0, 0.1, 2.5), "c2_se2d_n100000": ("se", 0.2, 2.0, 0.2, 2.5),
            "c3_matern52_usatemp": ("matern", 0.1, 1.0, 0.05, 2.5), "c4_se2d_hard_n100000": ("se", 0.05, 3.0, 0.2, 2.5),
-           "c5_matern32_3d_n20000": ("matern", 0.3, 1.5, 0.2, 1.5), "s1_se2d_n100": ("se", 0.5, 2.0, 0.2, 2.5),
+           "c5_matern32_3d_n20000": ("matern", 0.3, 1.5, 0.2, 1.5), "c5b_matern32_3d_l02_n20000": ("matern", 0.2, 1.5, 0.2, 1.5),
+           "s1_se2d_n100": ("se", 0.5, 2.0, 0.2, 2.5),
            "s2_matern12_1d_n200": ("matern", 0.3, 1.2, 0.1, 0.5)}
 
 
@@ -35,7 +36,7 @@ def make_model(name, g, x, y, cg_tol, nufft_eps=1e-9, **opts):
 
 
 CASES = ["s1_se2d_n100", "s2_matern12_1d_n200", "c1_se1d_n5000", "c2_se2d_n100000", "c3_matern52_usatemp",
-         "c4_se2d_hard_n100000", "c5_matern32_3d_n20000"]
+         "c4_se2d_hard_n100000", "c5_matern32_3d_n20000", "c5b_matern32_3d_l02_n20000"]
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -8,7 +8,7 @@ from _golden import load_case, oracle_kernel, rel
 from oracle import efgp_oracle as O
 
 SMALL = ["s1_se2d_n100", "s2_matern12_1d_n200", "c1_se1d_n5000", "c3_matern52_usatemp"]
-ALL = SMALL + ["c2_se2d_n100000", "c4_se2d_hard_n100000", "c5_matern32_3d_n20000"]
+ALL = SMALL + ["c2_se2d_n100000", "c4_se2d_hard_n100000", "c5_matern32_3d_n20000", "c5b_matern32_3d_l02_n20000"]
 
 
 @pytest.mark.parametrize("name", ALL)
