@@ -239,11 +239,13 @@ def main():
     st = model._fit_state
     rhs = st["ws"] * st["Fy"]
     diag = (float(NG) * st["ws"].abs().pow(2).real + SIG2)
-    cg_solve(model._toeplitz._op, st["ws"], SIG2, 0, rhs, torch.zeros_like(rhs), 1e-30, max_iter=50, diag=diag, batched=False)
+    # the model's own systems: rhs = D F*y of the real y, i.e. coefficients of real functions (hermitian=True, as the fit uses)
+    cg_solve(model._toeplitz._op, st["ws"], SIG2, 0, rhs, torch.zeros_like(rhs), 1e-30, max_iter=50, diag=diag, batched=False,
+             hermitian=True)
     torch.cuda.synchronize(dev)
     t2 = time.perf_counter()
     _, its, _ = cg_solve(model._toeplitz._op, st["ws"], SIG2, 0, rhs, torch.zeros_like(rhs), 1e-300, max_iter=400,
-                         early_stop=False, diag=diag, batched=False)
+                         early_stop=False, diag=diag, batched=False, hermitian=True)
     torch.cuda.synchronize(dev)
     cg_iter_per_s = its / (time.perf_counter() - t2)
     # batched rate: 64 independent right-hand sides
@@ -252,7 +254,7 @@ def main():
     torch.cuda.synchronize(dev)
     t3 = time.perf_counter()
     _, itb, _ = cg_solve(model._toeplitz._op, st["ws"], SIG2, 0, rb, torch.zeros_like(rb), 1e-300, max_iter=200,
-                         early_stop=False, diag=diag, batched=True)
+                         early_stop=False, diag=diag, batched=True, hermitian=True)
     torch.cuda.synchronize(dev)
     cg_rhs_iter_per_s = B * itb / (time.perf_counter() - t3)
 
@@ -341,7 +343,7 @@ def main():
                        "achieved_GBs": interp_bytes / (1e-3 * interp_ms / max(interp_n, 1)) / 1e9 if interp_n else None},
             # the mean solve is ONE persistent launch (one CU): largest share of the step, latency/VALU bound by design,
             # priced here against the survey's per-iteration bytes 16*(F_tot + 8M) x the iterations of the launch
-            "cg_solve": {"kernel": "cg_persistent_2d64_kernel (whole mean solve, one launch)",
+            "cg_solve": {"kernel": "cg_herm64_kernel (whole mean solve, one launch; real transforms on the 64 x 64 grid)",
                          "avg_launch_us": 1e3 * cgs_ms / max(cgs_n, 1), "iterations": mean_iters,
                          "bytes_per_launch": cg_bytes,
                          "achieved_GBs": cg_bytes / (1e-3 * cgs_ms / max(cgs_n, 1)) / 1e9 if cgs_n else None,

@@ -870,6 +870,365 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
     if (tid == 0) a.iters[row] = it;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Hermitian specialisation of the 64 x 64 solve (the fit's mean system, efgpnd.py:786-814).
+//
+// The right-hand side D F*y of a REAL y, the Toeplitz vector of real weights and the symmetric real ws make every CG
+// vector the coefficient array of a real function: u[-k] = conj u[k] on the centred modes k in [-h, h]^2, h = (n-1)/2.
+// The operator then is   coefficients -> real function on the 64 x 64 torus -> times a REAL spectrum -> coefficients,
+// and real transforms cost half:
+//   * only the rows k0 = 0..h of a vector are stored and transformed (A: h + 1 row lines instead of n),
+//   * two real columns f1 = q, q + 32 ride through ONE complex column transform as real and imaginary part
+//     (B/C: 32 column lines instead of 64; the spectrum multiply is two real multiplies),
+//   * the rows of the result for k0 = 0..h come from the packed columns at +k0 and -k0 (D: h + 1 row lines).
+// 88 line transforms per operator instead of 174.  Every line transform runs inside ONE wave (8 adjacent lanes x 8
+// points, radix 8 x 8, one exchange through wave-private LDS), so an iteration has 4 workgroup barriers: A | B C | D |
+// <p,Ap> | <r,r>,<r,z>.  The CG vectors live in the registers of the row lanes in exactly the positions the first
+// radix-8 stage of A consumes and the last stage of D produces (position j + 8t of lane j, t in {0,1,6,7}: modes k1 and
+// k1 - 64), so neither the load of ws.*p nor the crop touches LDS.  Dot products weigh the rows k0 > 0 twice.
+// Same recurrences, stopping rule and preconditioner as the kernels above; the arithmetic differs from them (and from
+// the reference's complex FFTs) by rounding only: the spectrum's rotated imaginary part (|.| ~ 1e-16 relative) and the
+// anti-Hermitian rounding noise of the inputs are dropped.
+// ------------------------------------------------------------------------------------------------
+namespace h64 {
+constexpr int kThreadsH = 256, kWavesH = kThreadsH / 64;
+constexpr int LDR = 72;                  // pitch of the G rows and of the row lanes' exchange scratch (8 mod 16: conflict free)
+constexpr int LT = 40;                   // pitch of the T rows (32 packed columns)
+constexpr int LQ = 82;                   // column lanes' exchange scratch per line (2 mod 16)
+constexpr int G_ELEMS = 16 * LDR, T_ELEMS = 32 * LT, Q_ELEMS = kWavesH * 8 * LQ;
+constexpr int kLdsElems = G_ELEMS + T_ELEMS + Q_ELEMS;     // 80.9 KB
+
+// DFT-8 of (a0, a1, 0, 0, 0, 0, a6, a7): the zero-padded first stage (modes 0..15 and -16..-1 of a 64-point line)
+__device__ __forceinline__ void dft8_in4(double2 a0, double2 a1, double2 a6, double2 a7, double2 (&v)[8]) {
+    const double2 ia6 = make_double2(-a6.y, a6.x), ia7 = make_double2(-a7.y, a7.x);
+    const double2 e0 = cadd(a0, a6), e1 = cadd(a0, ia6), e2 = csub(a0, a6), e3 = csub(a0, ia6);
+    const double2 o0 = cadd(a1, a7), o1r = cadd(a1, ia7), o2r = csub(a1, a7), o3r = csub(a1, ia7);
+    const double hh = 0.70710678118654752440;
+    const double2 o1 = make_double2(hh * (o1r.x + o1r.y), hh * (o1r.y - o1r.x));
+    const double2 o2 = mul_mi(o2r);
+    const double2 o3 = make_double2(hh * (o3r.y - o3r.x), -hh * (o3r.x + o3r.y));
+    v[0] = cadd(e0, o0);
+    v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1);
+    v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2);
+    v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3);
+    v[7] = csub(e3, o3);
+}
+
+// DFT-8 of which only the outputs 0, 1, 6, 7 are wanted (positions 0..15 and 48..63 of a cropped 64-point line)
+__device__ __forceinline__ void dft8_out4(double2 (&v)[8]) {
+    double2 e[4] = {v[0], v[2], v[4], v[6]};
+    double2 o[4] = {v[1], v[3], v[5], v[7]};
+    dft_fwd<4>(e);
+    dft_fwd<4>(o);
+    const double hh = 0.70710678118654752440;
+    const double2 o1 = make_double2(hh * (o[1].x + o[1].y), hh * (o[1].y - o[1].x));
+    const double2 o2 = mul_mi(o[2]);
+    const double2 o3 = make_double2(hh * (o[3].y - o[3].x), -hh * (o[3].x + o[3].y));
+    v[0] = cadd(e[0], o[0]);
+    v[1] = cadd(e[1], o1);
+    v[6] = csub(e[2], o2);
+    v[7] = csub(e[3], o3);
+}
+
+// a / b from the correctly rounded reciprocal rb = 1 / b: one residual step (Markstein) -- the quotient the hardware division
+// sequence returns for operands in the normal range, in 3 instructions instead of ~30
+__device__ __forceinline__ double div_rcp(double a_, double b_, double rb) {
+    const double q0 = a_ * rb;
+    return fma(fma(-q0, b_, a_), rb, q0);
+}
+
+// second half of a 64-point line transform inside a wave: the 8 lanes of a line swap their first-stage outputs through
+// `wr` (lane's own 8 slots, stride 1) / `rd` (stride 9), twiddle, second radix-8 stage.  v[t] = X[j + 8 t] on return.
+template <bool OUT4 = false>
+__device__ __forceinline__ void exchange_stage2(double2 (&v)[8], double2* __restrict__ wr, const double2* __restrict__ rd,
+                                                const double2 (&tw)[7]) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    s64::store8_all<1>(wr, v);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    s64::load8_all<9>(rd, v);
+    s64::twiddle8(v, tw);
+    if (OUT4) dft8_out4(v);
+    else dft_fwd<8>(v);
+}
+
+__device__ __forceinline__ double block_sum_h(double v, double* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double* r1 = red + 2 * kWavesH;
+    if (lane == 0) r1[wid] = v;
+    __syncthreads();
+    return (r1[0] + r1[1]) + (r1[2] + r1[3]);
+}
+__device__ __forceinline__ void block_sum_pair_h(double& u, double& v, double* red) {
+    u = wave_sum(u);
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wid] = u;
+        red[kWavesH + wid] = v;
+    }
+    __syncthreads();
+    u = (red[0] + red[1]) + (red[2] + red[3]);
+    v = (red[kWavesH] + red[kWavesH + 1]) + (red[kWavesH + 2] + red[kWavesH + 3]);
+}
+}  // namespace h64
+
+template <int VARIANT>
+__global__ __launch_bounds__(h64::kThreadsH) void cg_herm64_kernel(Args a) {
+    using namespace h64;
+    constexpr int F = 64, KS = 4;
+    extern __shared__ double2 lds2[];
+    __shared__ double red[4 * kWavesH];
+    __shared__ double s_rcp;             // 1 / (<r,z> + 1e-16) for the next beta, computed by an idle wave during A
+    __shared__ int s_stop;               // convergence decision of the last completed iteration, taken by an idle wave during A
+    double2* const Gb = lds2;                    // G[k0][f1], k0 = 0..15 (rows beyond h are zero)
+    double2* const Tb = lds2 + G_ELEMS;          // conj T[row(p)][q]: rows p = 0..15 and 48..63 (stored at p - 32)
+    double2* const Qb = Tb + T_ELEMS;            // exchange scratch: column lines (B/C), aliased by the row lines (A, D)
+    const int n = a.g.n[0], h = (n - 1) / 2, M = a.g.M;
+    const int row = blockIdx.x;
+    const int64_t base = (int64_t)row * M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // row role (waves 0, 1): lane = k0 * 8 + j; column role (all waves): lane = jc * 8 + ql, packed column q = 8 wave + ql
+    const int k0 = tid >> 3, j = tid & 7;
+    const bool row_role = tid < 128;
+    const int jc = lane >> 3, ql = lane & 7, q = wave * 8 + ql;
+    double2* const xw = Qb + (k0 & 15) * LDR + 9 * j;
+    const double2* const xr = Qb + (k0 & 15) * LDR + j;
+    double2* const qw = Qb + (wave * 8 + ql) * LQ + 9 * jc;
+    const double2* const qr = Qb + (wave * 8 + ql) * LQ + jc;
+
+    double2 twr[7], twc[7];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) {
+        twr[t - 1] = a.g.tw[0][j * t];
+        twc[t - 1] = a.g.tw[0][jc * t];
+    }
+    // real spectrum of the centred lags, halved (the unpacking of D averages two terms): vhat = w^((n-1)(f0+f1)) S
+    double sa[8], sb[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int f0 = jc + 8 * t;
+        const double2 va = a.vhat[f0 * F + q], vb = a.vhat[f0 * F + q + 32];
+        const double2 wa = a.g.tw[0][((n - 1) * (f0 + q)) & 63], wb = a.g.tw[0][((n - 1) * (f0 + q + 32)) & 63];
+        sa[t] = 0.5 * (va.x * wa.x + va.y * wa.y);
+        sb[t] = -0.5 * (vb.x * wb.x + vb.y * wb.y);      // sign: conjugation in front of the inverse transform
+    }
+    const bool z6_ok = jc > 0;                            // row 16 - jc exists
+
+    // vector slots of a row lane: positions j + 8 t, t in {0, 1, 6, 7} <-> k1 = j, j + 8, j - 16, j - 8
+    double2 xv[KS], rv[KS], pv[KS];
+    double wsr[KS], dg[KS], rdg[KS];     // ws is real here (checked below): ws * u costs two multiplies
+    bool ok[KS];
+    int idx[KS];
+    const bool precond = a.diag != nullptr || a.diag_scale != nullptr;
+    const double wgt = k0 == 0 ? 1.0 : 2.0;
+    double ws_bad = 0.0;                 // > 0: ws is not real and even
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k1 = s == 0 ? j : (s == 1 ? j + 8 : (s == 2 ? j - 16 : j - 8));
+        ok[s] = row_role && k0 <= h && k1 <= h && -k1 <= h;
+        idx[s] = ok[s] ? (k0 + h) * n + (k1 + h) : 0;
+        double ws_im = 0.0;
+        if (ok[s]) {
+            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x[base + idx[s]];
+            const double2 w = a.ws[idx[s]], wm = a.ws[M - 1 - idx[s]];
+            wsr[s] = w.x;
+            ws_im = w.y * w.y + (w.x - wm.x) * (w.x - wm.x) + wm.y * wm.y;
+            dg[s] = jacobi_entry(a, w, idx[s]);
+        } else {
+            xv[s] = make_double2(0.0, 0.0);
+            wsr[s] = 0.0;
+            dg[s] = 1.0;
+        }
+        ws_bad += ws_im;
+        rdg[s] = 1.0 / dg[s];
+        rv[s] = pv[s] = make_double2(0.0, 0.0);
+    }
+
+#ifdef EFGP_CG_STAMPS
+    long long stamp_prev = (long long)__builtin_readcyclecounter();
+#endif
+    int stop = 0;
+    double rcp_rz = 0.0;
+    auto apply_A = [&](const double2 (&u)[KS], double2 (&Au)[KS]) __attribute__((always_inline)) {
+        double2 v[8];
+        EFGP_STAMP(7);
+        // A: rows k0 >= 0, modes k1 wrapped to positions k1 mod 64 -> G[k0][f1]
+        if (row_role) {
+            dft8_in4(make_double2(wsr[0] * u[0].x, wsr[0] * u[0].y), make_double2(wsr[1] * u[1].x, wsr[1] * u[1].y),
+                     make_double2(wsr[2] * u[2].x, wsr[2] * u[2].y), make_double2(wsr[3] * u[3].x, wsr[3] * u[3].y), v);
+            exchange_stage2(v, xw, xr, twr);
+            s64::store8_all<8>(Gb + k0 * LDR + j, v);
+        }
+        __syncthreads();
+        stop = s_stop;
+        rcp_rz = s_rcp;
+        if (stop) return;                                 // uniform: the iteration that just started is abandoned
+        EFGP_STAMP(0);
+        // B: packed columns z[k0] = G[k0][q] + i G[k0][q + 32] (k0 >= 0), conj G[-k0][q] + i conj G[-k0][q + 32] (k0 < 0)
+        {
+            const double2* g0 = Gb + q;
+            const double2 a0 = g0[jc * LDR], b0 = g0[jc * LDR + 32];
+            const double2 a1 = g0[(jc + 8) * LDR], b1 = g0[(jc + 8) * LDR + 32];
+            const double2 a6 = g0[((16 - jc) & 15) * LDR], b6 = g0[((16 - jc) & 15) * LDR + 32];
+            const double2 a7 = g0[(8 - jc) * LDR], b7 = g0[(8 - jc) * LDR + 32];
+            const double2 z0 = make_double2(a0.x - b0.y, a0.y + b0.x);
+            const double2 z1 = make_double2(a1.x - b1.y, a1.y + b1.x);
+            double2 z6 = make_double2(a6.x + b6.y, b6.x - a6.y);
+            const double2 z7 = make_double2(a7.x + b7.y, b7.x - a7.y);
+            if (!z6_ok) z6 = make_double2(0.0, 0.0);
+            dft8_in4(z0, z1, z6, z7, v);
+            exchange_stage2(v, qw, qr, twc);              // v[t] = R_q[f0] + i R_{q+32}[f0], f0 = jc + 8 t
+            // C: times the real spectrum, conjugate, forward transform = conj of the inverse transform
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = make_double2(v[t].x * sa[t], v[t].y * sb[t]);
+            dft_fwd<8>(v);
+            exchange_stage2<true>(v, qw, qr, twc);        // v[t] = conj T[jc + 8 t], t in {0, 1, 6, 7}
+            double2* t0 = Tb + jc * LT + q;
+            t0[0] = v[0];
+            t0[8 * LT] = v[1];
+            t0[16 * LT] = v[6];
+            t0[24 * LT] = v[7];
+        }
+        __syncthreads();
+        EFGP_STAMP(1);
+        // D: row k0 >= 0 of the result from the packed columns at +k0 and -k0; conjugated inputs, forward transform
+        if (row_role) {
+            const double2* tp = Tb + (k0 & 15) * LT + j;
+            const double2* tm = Tb + ((k0 & 15) == 0 ? 0 : 32 - (k0 & 15)) * LT + j;
+#pragma unroll
+            for (int u4 = 0; u4 < 4; ++u4) {
+                const double2 P = tp[8 * u4], Mv = tm[8 * u4];
+                v[u4] = make_double2(P.x + Mv.x, P.y - Mv.y);
+                v[u4 + 4] = make_double2(-P.y - Mv.y, P.x - Mv.x);
+            }
+            dft_fwd<8>(v);
+            exchange_stage2<true>(v, xw, xr, twr);        // v[t] = conj Y[k0][j + 8 t], t in {0, 1, 6, 7}
+            const double2 y[KS] = {s64::conjd(v[0]), s64::conjd(v[1]), s64::conjd(v[6]), s64::conjd(v[7])};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const double2 gg = make_double2(wsr[s] * y[s].x, wsr[s] * y[s].y);
+                if (VARIANT == 0) Au[s] = make_double2(gg.x + a.sigmasq * u[s].x, gg.y + a.sigmasq * u[s].y);
+                else Au[s] = make_double2(gg.x / a.sigmasq + u[s].x, gg.y / a.sigmasq + u[s].y);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) Au[s] = make_double2(0.0, 0.0);
+        }
+        EFGP_STAMP(2);
+    };
+
+    if (tid == 0) {
+        s_stop = 0;
+        s_rcp = 0.0;
+    }
+    double2 Ap[KS];
+    if (a.zero_x0) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) Ap[s] = make_double2(0.0, 0.0);
+    } else {
+        apply_A(xv, Ap);
+    }
+    double rz = 0.0, bb = 0.0, asym = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (ok[s]) {
+            double2 bv = a.b[base + idx[s]];
+            double2 bm = a.b[base + (M - 1 - idx[s])];                 // mode -k: must be the conjugate
+            if (a.b_times_ws) {
+                bv = make_double2(wsr[s] * bv.x, wsr[s] * bv.y);
+                bm = make_double2(wsr[s] * bm.x, wsr[s] * bm.y);
+            }
+            asym += (bv.x - bm.x) * (bv.x - bm.x) + (bv.y + bm.y) * (bv.y + bm.y);
+            rv[s] = csub(bv, Ap[s]);
+            pv[s] = precond ? make_double2(div_rcp(rv[s].x, dg[s], rdg[s]), div_rcp(rv[s].y, dg[s], rdg[s])) : rv[s];
+            rz += rv[s].x * pv[s].x + rv[s].y * pv[s].y;
+            bb += bv.x * bv.x + bv.y * bv.y;
+        }
+    }
+    rz *= wgt;
+    bb *= wgt;
+    block_sum_pair_h(rz, bb, red);
+    asym = block_sum_h(asym, red);
+    ws_bad = block_sum_h(ws_bad, red + kWavesH);      // (disjoint scratch: no barrier between the two sums' reads and writes)
+    if (!(asym <= 1e-16 * bb) || ws_bad != 0.0) {
+        // not the coefficients of a real function (rounding leaves ~1e-32 |b|^2): refuse loudly instead of solving another system
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (ok[s]) {
+                a.x[base + idx[s]] = make_double2(__builtin_nan(""), __builtin_nan(""));
+                a.x[base + (M - 1 - idx[s])] = make_double2(__builtin_nan(""), __builtin_nan(""));
+            }
+        }
+        if (tid == 0) a.iters[row] = -2;
+        return;
+    }
+    const double bn = sqrt(bb);
+    const double den = bn > 0.0 ? bn : 1.0;
+    const double den_eps = den + 1e-16, rcp_den = 1.0 / den_eps;
+    // Per iteration the row waves (0, 1) carry the dependent chain  A -> B/C -> D -> <p,Ap> -> alpha -> r -> <r,r>,<r,z> ->
+    // beta -> p -> A;  everything that is not on it is done by wave 3, idle during A: the norm test of iteration i (sqrt and a
+    // division) and the reciprocal for the next beta.  Its decision is read behind the first barrier of the next operator
+    // application, whose A phase has then run speculatively (LDS only; x is final, p is not an output).
+    if (wave == 3 && lane == 0) s_rcp = 1.0 / (rz + 1e-16);
+    int it = 0;
+    for (; it < a.max_iter;) {
+        apply_A(pv, Ap);
+        if (stop) break;
+        double pAp = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pAp += pv[s].x * Ap[s].x + pv[s].y * Ap[s].y;
+        pAp = block_sum_h(pAp * wgt, red) + 1e-16;
+        EFGP_STAMP(3);
+        const double alpha = rz / pAp;
+        double rr = 0.0, rzn = 0.0;
+        double2 zv[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            xv[s].x += alpha * pv[s].x;
+            xv[s].y += alpha * pv[s].y;
+            rv[s].x -= alpha * Ap[s].x;
+            rv[s].y -= alpha * Ap[s].y;
+            zv[s] = precond ? make_double2(div_rcp(rv[s].x, dg[s], rdg[s]), div_rcp(rv[s].y, dg[s], rdg[s])) : rv[s];
+            rr += rv[s].x * rv[s].x + rv[s].y * rv[s].y;
+            rzn += rv[s].x * zv[s].x + rv[s].y * zv[s].y;
+        }
+        rr *= wgt;
+        rzn *= wgt;
+        EFGP_STAMP(4);
+        block_sum_pair_h(rr, rzn, red);
+        EFGP_STAMP(5);
+        ++it;
+        if (wave == 3) {
+            const double ratio = div_rcp(sqrt(rr), den_eps, rcp_den);
+            const bool conv = a.early_stop && ((ratio < a.tol) || (a.batched && sqrt(rr) < 1e-12));
+            if (lane == 0) {
+                if (a.hist && row == 0 && it <= a.hist_cap) a.hist[it - 1] = ratio;
+                s_stop = conv ? 1 : 0;
+                s_rcp = 1.0 / (rzn + 1e-16);
+            }
+        }
+        // cg.py:132 / 229: the test sits before (single) or after (batched) this update; p is not an output
+        const double beta = div_rcp(rzn, rz + 1e-16, rcp_rz);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pv[s] = make_double2(zv[s].x + beta * pv[s].x, zv[s].y + beta * pv[s].y);
+        rz = rzn;
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (ok[s]) {
+            a.x[base + idx[s]] = xv[s];
+            if (k0 > 0) a.x[base + (M - 1 - idx[s])] = s64::conjd(xv[s]);     // mode -k
+        }
+    }
+    if (tid == 0) a.iters[row] = it;
+}
+
 // Spectrum of the Toeplitz vector for the 64 x 64 circulant grid in ONE launch (efgpnd.py:1283-1290: pad to the FFT
 // box, forward fftn): `factor * v` zero-padded into LDS, four radix-8 Stockham stages as in the solver above, result
 // in natural order.  Replaces pad_scale_kernel + two rocFFT launches (~14 us of dependent 4-5 us launches per fit).
@@ -999,7 +1358,7 @@ bool persistent_cg_eligible(const ToepGeom& tg) {
 int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, const double2* vhat, const double2* ws,
                          const double* diag, double sigmasq, int variant, double tol, int early_stop, int batched,
                          int max_iter, const double2* b, double2* x, int rows, int* d_iters, hipStream_t stream,
-                         const double* diag_scale, int b_times_ws, int zero_x0, const LanczosOut* lz) {
+                         const double* diag_scale, int b_times_ws, int zero_x0, const LanczosOut* lz, int hermitian) {
     using namespace pcg;
     Args a;
     Geom& g = a.g;
@@ -1192,7 +1551,23 @@ int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, con
     }
     const bool fast64 = tg.d == 2 && g.F[0] == 64 && g.F[1] == 64 && g.n[0] == g.n[1] && g.n[0] <= 32 &&
                         std::getenv("EFGP_NO_CG64") == nullptr;
-    if (fast64) {
+    const bool herm64 = fast64 && hermitian && !lz && (g.n[0] & 1) && g.n[0] <= 31 && std::getenv("EFGP_NO_CG_HERM") == nullptr;
+    if (herm64) {
+        static bool attr_h = false;
+        const size_t lds_h = (size_t)h64::kLdsElems * sizeof(double2);
+        if (!attr_h) {
+            hipError_t e2 = hipFuncSetAttribute((const void*)cg_herm64_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
+            if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)cg_herm64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
+            if (e2 != hipSuccess) {
+                set_error("persistent CG (64x64, Hermitian): hipFuncSetAttribute failed: %s", hipGetErrorString(e2));
+                return EFGP_EHIP;
+            }
+            attr_h = true;
+        }
+        KernelTimer timer("cg_solve", stream);
+        if (variant == 0) hipLaunchKernelGGL(cg_herm64_kernel<0>, dim3(rows), dim3(h64::kThreadsH), lds_h, stream, a);
+        else hipLaunchKernelGGL(cg_herm64_kernel<1>, dim3(rows), dim3(h64::kThreadsH), lds_h, stream, a);
+    } else if (fast64) {
         static bool attr64 = false;
         if (!attr64) {
             hipError_t e2 = hipFuncSetAttribute((const void*)cg_persistent_2d64_kernel,

@@ -1358,9 +1358,27 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
     return EFGP_OK;
 }
 
+static int cg_solve_async_impl(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
+                               const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop,
+                               int batched_semantics, int* row_iters_dev, void* stream_, int hermitian);
+
 int efgp_cg_solve_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
                         const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop,
                         int batched_semantics, int* row_iters_dev, void* stream_) {
+    return cg_solve_async_impl(op, ws, sigmasq, variant, precond_diag, b, x, nbatch, tol, max_iter, early_stop, batched_semantics,
+                               row_iters_dev, stream_, 0);
+}
+
+int efgp_cg_solve_hermitian_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
+                                  const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop,
+                                  int batched_semantics, int* row_iters_dev, void* stream_) {
+    return cg_solve_async_impl(op, ws, sigmasq, variant, precond_diag, b, x, nbatch, tol, max_iter, early_stop, batched_semantics,
+                               row_iters_dev, stream_, 1);
+}
+
+static int cg_solve_async_impl(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
+                               const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop,
+                               int batched_semantics, int* row_iters_dev, void* stream_, int hermitian) {
     EFGP_REQUIRE(op && ws && b && x && row_iters_dev, "efgp_cg_solve_async: null argument");
     EFGP_REQUIRE(nbatch >= 1, "efgp_cg_solve_async: nbatch must be >= 1");
     EFGP_REQUIRE(variant == 0 || variant == 1, "efgp_cg_solve_async: variant must be 0 or 1");
@@ -1376,7 +1394,7 @@ int efgp_cg_solve_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int
     KernelTimer timer("cg_persistent", stream);
     return persistent_cg_launch(op->g, (const double2* const*)op->tw, op->vhat, (const double2*)ws, precond_diag, sigmasq,
                                 variant, tol, early_stop, batched_semantics, max_iter, (const double2*)b, (double2*)x, nbatch,
-                                row_iters_dev, stream);
+                                row_iters_dev, stream, nullptr, 0, 0, nullptr, hermitian);
 }
 
 int efgp_lanczos(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const void* z, int nprobes, int steps,
@@ -1409,7 +1427,7 @@ int efgp_cg_solve_mean_async(efgp_toeplitz_t* op, const void* ws, double sigmasq
     KernelTimer timer("cg_persistent", stream);
     return persistent_cg_launch(op->g, (const double2* const*)op->tw, op->vhat, (const double2*)ws, nullptr, sigmasq, 0, tol,
                                 early_stop, 0, max_iter, (const double2*)fy, (double2*)x, 1, iters_dev, stream, diag_scale_dev,
-                                1, 1);
+                                1, 1, nullptr, /*hermitian: F*y of a real y, Toeplitz vector of real weights*/ 1);
 }
 
 int efgp_vdot_real(int device, const void* a, int a_is_complex, const void* b, int b_is_complex, int64_t count,

@@ -27,7 +27,8 @@ bool persistent_cg_eligible(const ToepGeom& g);
 int persistent_cg_launch(const ToepGeom& g, const double2* const* twiddles, const double2* vhat, const double2* ws,
                          const double* diag, double sigmasq, int variant, double tol, int early_stop, int batched,
                          int max_iter, const double2* b, double2* x, int rows, int* d_iters, hipStream_t stream,
-                         const double* diag_scale = nullptr, int b_times_ws = 0, int zero_x0 = 0, const LanczosOut* lz = nullptr);
+                         const double* diag_scale = nullptr, int b_times_ws = 0, int zero_x0 = 0, const LanczosOut* lz = nullptr,
+                         int hermitian = 0 /* b, x0 and the Toeplitz vector are coefficient arrays of real functions */);
 
 // spectrum of the Toeplitz vector on the 64 x 64 circulant grid in one launch (cg_persistent.hip)
 bool toeplitz_vhat_fused_eligible(const ToepGeom& g);

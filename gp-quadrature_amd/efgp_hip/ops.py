@@ -236,11 +236,18 @@ class ToeplitzOp:
         return out.reshape(u.shape)
 
 
-def cg_solve(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=True, diag=None, batched=None):
-    """Fused device CG on ws*T(ws*.) (+sigma^2 | /sigma^2 + 1).  Returns (x, iters, row_iters)."""
+def cg_solve(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=True, diag=None, batched=None, hermitian=False):
+    """Fused device CG on ws*T(ws*.) (+sigma^2 | /sigma^2 + 1).  Returns (x, iters, row_iters).
+    hermitian=True: see cg_solve_async (the systems are transforms of real data; grids without a specialised kernel run
+    the general solver)."""
     dev = op.dev
     if batched is None:
         batched = b.ndim > 1
+    if hermitian:
+        res = cg_solve_async(op, ws, sigmasq, variant, b, x0, tol, max_iter=max_iter, early_stop=early_stop, diag=diag,
+                             batched=batched, hermitian=True)
+        if res is not None:
+            return res[0], int(res[1]), list(res[1].rows)
     bb = b.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous()
     x = x0.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous().clone()
     wsd = ws.to(device=dev, dtype=_CD).contiguous()
@@ -269,6 +276,9 @@ class LazyIterations:
     def rows(self):
         if self._rows is None:
             self._rows = [int(v) for v in self._rows_dev.tolist()]
+            if any(v == -2 for v in self._rows):
+                raise RuntimeError("efgp_hip: a system given to the Hermitian CG kernel is not the transform of real data "
+                                   "(right-hand side not conjugate-even, or ws not real and even); its solution is NaN")
         return self._rows
 
     def __int__(self):
@@ -282,9 +292,12 @@ class LazyIterations:
         return str(int(self))
 
 
-def cg_solve_async(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=True, diag=None, batched=None):
+def cg_solve_async(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=True, diag=None, batched=None,
+                   hermitian=False):
     """Like cg_solve but without host synchronisation: returns (x, LazyIterations) or None when the operator's
-    grid does not fit the persistent kernel (the caller then uses cg_solve)."""
+    grid does not fit the persistent kernel (the caller then uses cg_solve).  hermitian=True: b, x0 are Fourier
+    coefficients of real functions and ws is real and even (efgp_cg_solve_hermitian_async; refused with an error when
+    the data say otherwise)."""
     from .lib import EFGP_EUNSUPPORTED
     dev = op.dev
     if batched is None:
@@ -297,9 +310,9 @@ def cg_solve_async(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_st
     mi = int(max_iter) if max_iter is not None else 2 * op.size
     rows_dev = torch.empty(B, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        rc = lib().efgp_cg_solve_async(op._h, _ptr(wsd), float(sigmasq), int(variant), _ptr(dg) if dg is not None else None,
-                                       _ptr(bb), _ptr(x), B, float(tol), mi, int(bool(early_stop)), int(bool(batched)),
-                                       _ptr(rows_dev), _stream(dev))
+        fn = lib().efgp_cg_solve_hermitian_async if hermitian else lib().efgp_cg_solve_async
+        rc = fn(op._h, _ptr(wsd), float(sigmasq), int(variant), _ptr(dg) if dg is not None else None, _ptr(bb), _ptr(x), B,
+                float(tol), mi, int(bool(early_stop)), int(bool(batched)), _ptr(rows_dev), _stream(dev))
     if rc == EFGP_EUNSUPPORTED:
         return None
     check(rc, "efgp_cg_solve_async")

@@ -455,8 +455,9 @@ def efgpnd_gradient_batched(
     rhs = ws * Fy
     warm = mean_cg_init is not None and tuple(mean_cg_init.shape) == tuple(rhs.shape)
     b0 = mean_cg_init.detach().to(device=dev, dtype=torch.complex128) if warm else torch.zeros_like(rhs)
+    # rhs = D F*y of the real y (and a warm start from an earlier solve of the same kind): coefficients of real functions
     res_m = cg_solve_async(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping,
-                           diag=diag if use_mean_cg_preconditioner else None, batched=False)
+                           diag=diag if use_mean_cg_preconditioner else None, batched=False, hermitian=True)
     if res_m is None:
         res_m = cg_solve(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping,
                          diag=diag if use_mean_cg_preconditioner else None, batched=False)[:2]
@@ -724,7 +725,8 @@ def compute_prediction_variance(x_new, xis, ws, A_var, cg_tol, max_cg_iter, vari
         for xb in torch.split(xn, 8192, dim=0):
             rhs = variance_rhs(xb, hval, mtot_loc, wsd)                  # ws * conj(f(x*)): explicit feature rows (b, M)
             gamma, _, _ = cg_solve(op.toeplitz._op, wsd, op.sigmasq, op.variant, rhs, torch.zeros_like(rhs), cg_tol,
-                                   max_iter=max_cg_iter, early_stop=True, diag=None, batched=True)
+                                   max_iter=max_cg_iter, early_stop=True, diag=None, batched=True,
+                                   hermitian=True)     # feature rows of real points: conjugate-even
             out.append(variance_contract(xb, hval, mtot_loc, wsd, gamma))
         return torch.cat(out, dim=0).to(device=device, dtype=rdtype)
     if method == "stochastic":
@@ -972,7 +974,8 @@ class EFGPND(nn.Module):
             rhs = grid.ws * Fy
             diag = _center_value(v) * grid.ws.abs().pow(2).real + sig if use_precond else None
             b0 = self._beta.detach().to(device=dev, dtype=torch.complex128) if warm else torch.zeros_like(rhs)
-            res = cg_solve_async(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False)
+            res = cg_solve_async(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False,
+                                 hermitian=True)
             if res is None:
                 res = cg_solve(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False)[:2]
         beta, iters = res

@@ -179,12 +179,28 @@ int efgp_cg_solve_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int
                         const double* precond_diag, const void* b, void* x, int nbatch, double tol,
                         int max_iter, int early_stop, int batched_semantics, int* row_iters_dev, void* stream);
 
+/* efgp_cg_solve_async for systems whose vectors are Fourier coefficients of REAL functions on the symmetric mode grid:
+ * every right-hand side and start vector satisfies u[-k] = conj u[k], ws is real and even, the Toeplitz vector comes
+ * from real weights.  All CG systems of an EFGP model are of this kind (right-hand sides are D F* of real vectors:
+ * y, Rademacher probes, kernel-derivative terms; efgpnd.py:186-189, 792, 1657).  On the 2-D 64 x 64 circulant grid
+ * (odd mtot <= 31) the operator then runs on real transforms -- rows k0 >= 0 only, two real columns per complex
+ * transform: 88 line transforms per application instead of 174 -- with the same recurrences and stopping rules; on every
+ * other grid this is efgp_cg_solve_async.  A right-hand side that is not Hermitian to 1e-8 |b| is refused: its
+ * row_iters_dev entry is -2 and its solution NaN.  precond_diag must be even as well (it is: a function of |ws|). */
+int efgp_cg_solve_hermitian_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant,
+                                  const double* precond_diag, const void* b, void* x, int nbatch, double tol,
+                                  int max_iter, int early_stop, int batched_semantics, int* row_iters_dev, void* stream);
+
 /* The fit's mean system in one launch, straight from the transform outputs (efgpnd.py:792-803):
  *     (D T D + sigmasq I) beta = D fy,   D = diag(ws),   beta_0 = 0,
  * Jacobi diagonal (*diag_scale_dev) * |ws|^2 + sigmasq when diag_scale_dev is not NULL (device pointer to the
  * real centre value of the Toeplitz vector, efgpnd.py:795-799), single-system stopping rule of cg.py:116-150.
  * Replaces the reference's separate ws*Fy, |ws|^2 diagonal and zeros(x0) tensor ops plus efgp_cg_solve_async.
- * EFGP_EUNSUPPORTED when the grid does not fit the single-launch kernel (callers fall back to efgp_cg_solve). */
+ * EFGP_EUNSUPPORTED when the grid does not fit the single-launch kernel (callers fall back to efgp_cg_solve).
+ * CONTRACT: fy is the type-1 transform of REAL strengths (fy[-k] = conj fy[k]), ws is real and even and the operator's
+ * Toeplitz vector comes from real weights -- true for every EFGP model (efgpnd.py:786-790).  On the 64 x 64 circulant
+ * grid the solve then runs on real transforms (half the lines, see efgp_cg_solve_hermitian_async); an input that breaks
+ * the contract is refused: iters_dev[0] = -2 and beta = NaN. */
 int efgp_cg_solve_mean_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, const double* diag_scale_dev, const void* fy,
                              void* x, double tol, int max_iter, int early_stop, int* iters_dev, void* stream);
 

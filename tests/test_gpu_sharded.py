@@ -88,7 +88,9 @@ def test_two_shards_equal_unsharded():
         Zs.append(z)
     grad = m.compute_gradients(trace_samples=2, cg_tol=1e-10, probes_Z=torch.cat(Zs, dim=1), probes_V=V).detach().cpu()
     for rank, smean, sgrad, its in res:
-        assert float((smean - mean.cpu()).abs().max() / mean.cpu().abs().max()) < 1e-9
+        # both solves stop at |r| < 1e-10 |b|, possibly one iteration apart (asserted below): the means agree to a small
+        # multiple of cond(A) * tol, not to rounding
+        assert float((smean - mean.cpu()).abs().max() / mean.cpu().abs().max()) < 3e-8
         scale = float(m.last_gradient_stats["term1"].abs().max()) * float(m._gp_params.pos.detach().max())
         assert float((sgrad - grad).abs().max()) < 1e-7 * scale
         assert abs(its - m.last_fit_stats["mean_cg_iters"]) <= 1
