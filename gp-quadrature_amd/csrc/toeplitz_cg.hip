@@ -414,7 +414,12 @@ __device__ __forceinline__ double2* line_fft(double2* A, double2* B, int F, int 
     double2* y = B;
     int Ns = 1;
     while (Ns < F) {
-        const int R = ((F / Ns) & 3) == 0 ? 4 : 2;
+        // radix 8 for the LATER stages where the remaining length allows it (a first radix-8 stage writes with a stride of 8
+        // elements: 8-way bank conflicts): a stage is one LDS round trip and one barrier, and a radix-8 butterfly gives
+        // its thread 8 independent loads (radix-4 stages are bound by the LDS latency of dependent work items)
+        const int rem = F / Ns;
+        const int R = (F >= 256 && (rem == 512 || rem == 64 || rem == 8)) ? 8 : ((rem & 3) == 0 ? 4 : 2);   // 256 = 4 8 8, 512 = 8 8 8
+        // (measured, cooperative solve: 512^2 49.8 -> 40.4 us per iteration, 256^2 neutral, 128^2 = 4 4 8 slower than 4 4 4 2)
         const int per = F / R;                       // butterflies per line (a power of two)
         const int lper = ilog2(per);
         const int mult = F / (Ns * R);               // twiddle index step: angle = -2 pi r k / (Ns R)
@@ -424,7 +429,37 @@ __device__ __forceinline__ double2* line_fft(double2* A, double2* B, int F, int 
             const double2* xl = x + l * ld;
             double2* yl = y + l * ld;
             const int j0 = (j - k) * R + k;
-            if (R == 4) {
+            if (R == 8) {
+                double2 v[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = xl[j + m * per];
+                if (Ns > 1) {
+                    const int q = k * mult;          // 7 q < F: no wrap
+#pragma unroll
+                    for (int m = 1; m < 8; ++m) v[m] = cmul(v[m], tw[m * q]);
+                }
+                // DFT-8: two DFT-4 (even / odd inputs), odd outputs times w8^m, combine
+                const double2 e0 = make_double2(v[0].x + v[4].x, v[0].y + v[4].y), e1 = make_double2(v[0].x - v[4].x, v[0].y - v[4].y);
+                const double2 e2 = make_double2(v[2].x + v[6].x, v[2].y + v[6].y), e3 = make_double2(v[2].y - v[6].y, v[6].x - v[2].x);
+                const double2 E0 = make_double2(e0.x + e2.x, e0.y + e2.y), E1 = make_double2(e1.x + e3.x, e1.y + e3.y);
+                const double2 E2 = make_double2(e0.x - e2.x, e0.y - e2.y), E3 = make_double2(e1.x - e3.x, e1.y - e3.y);
+                const double2 o0 = make_double2(v[1].x + v[5].x, v[1].y + v[5].y), o1 = make_double2(v[1].x - v[5].x, v[1].y - v[5].y);
+                const double2 o2 = make_double2(v[3].x + v[7].x, v[3].y + v[7].y), o3 = make_double2(v[3].y - v[7].y, v[7].x - v[3].x);
+                const double2 O0 = make_double2(o0.x + o2.x, o0.y + o2.y), O1r = make_double2(o1.x + o3.x, o1.y + o3.y);
+                const double2 O2r = make_double2(o0.x - o2.x, o0.y - o2.y), O3r = make_double2(o1.x - o3.x, o1.y - o3.y);
+                const double hh = 0.70710678118654752440;
+                const double2 O1 = make_double2(hh * (O1r.x + O1r.y), hh * (O1r.y - O1r.x));
+                const double2 O2 = make_double2(O2r.y, -O2r.x);
+                const double2 O3 = make_double2(hh * (O3r.y - O3r.x), -hh * (O3r.x + O3r.y));
+                yl[j0] = make_double2(E0.x + O0.x, E0.y + O0.y);
+                yl[j0 + Ns] = make_double2(E1.x + O1.x, E1.y + O1.y);
+                yl[j0 + 2 * Ns] = make_double2(E2.x + O2.x, E2.y + O2.y);
+                yl[j0 + 3 * Ns] = make_double2(E3.x + O3.x, E3.y + O3.y);
+                yl[j0 + 4 * Ns] = make_double2(E0.x - O0.x, E0.y - O0.y);
+                yl[j0 + 5 * Ns] = make_double2(E1.x - O1.x, E1.y - O1.y);
+                yl[j0 + 6 * Ns] = make_double2(E2.x - O2.x, E2.y - O2.y);
+                yl[j0 + 7 * Ns] = make_double2(E3.x - O3.x, E3.y - O3.y);
+            } else if (R == 4) {
                 double2 v0 = xl[j], v1 = xl[j + per], v2 = xl[j + 2 * per], v3 = xl[j + 3 * per];
                 if (Ns > 1) {
                     const int q = k * mult;          // 3 q < F: no wrap
@@ -610,6 +645,336 @@ __global__ __launch_bounds__(kLineThreads) void cg_rows_inv_kernel(LineArgs a) {
         for (int i = 0; i < a.nblk_rows; ++i) t += fin[i];
         c.sc[row].pAp = t + kDivEps;
     }
+}
+
+// ==========================================================================================================
+// Cooperative single-launch solve for the same 2-D grids: the WHOLE CG loop in one kernel spread over G workgroups
+// (one per CU) per system, with grid barriers between the phases instead of kernel boundaries -- no launch latency
+// (3-4 us x 4 launches per iteration above), no host poll, no hipGraph.
+//   phase R  : own rows  -- ws .* p (from registers), zero-padded, forward FFT along dim 1           -> B1 (write-through)
+//   barrier
+//   phase C  : own column block -- forward FFT along dim 0 of the n non-zero inputs, .* vhat, inverse, crop rows -> B2
+//   barrier
+//   phase Ri : own rows  -- inverse FFT along dim 1, crop, A p (registers), partial <p, A p>
+//   barrier  : every workgroup adds the G partials in index order (same bits everywhere: uniform control flow)
+//   update   : own rows  -- x, r, z in registers, partial <r,r>, <r,z>
+//   barrier  : sums, stopping rule, beta, p
+// Ownership is fixed for the whole solve: workgroup g owns rows [g L, (g+1) L) of the mode block in the row phases and
+// the vector elements of those rows (x, r, p, A p, ws, diag stay in ITS registers: 4 per thread), and columns
+// [g c, (g+1) c) in the column phase.  Only B1, B2 and the partial sums cross workgroups; they are written and read
+// with agent-scope accesses (write-through stores / cache-bypassing loads: the XCDs' L2 caches are not coherent with
+// each other), so a barrier needs no cache write-back or invalidate: the stores are waited for (s_waitcnt) before the
+// workgroup's arrival is counted.  A barrier is one agent-scope atomic add on a monotone counter and a bounded poll;
+// a poll that runs out (a co-resident workgroup never arrived) sets a status flag on which every workgroup leaves and
+// the host falls back to the multi-launch iteration above.  All G x systems workgroups must be resident at once:
+// the host launches at most one workgroup per CU.
+// ==========================================================================================================
+constexpr int kCoopSlots = 4;                 // vector elements per thread (own rows x n1 <= 4 x 256)
+constexpr unsigned kCoopPollLimit = 1u << 22; // ~ seconds of polling before a barrier is declared dead
+constexpr int kCoopMaxG = 64;
+constexpr int kCoopLoads = 16;                // grid elements a thread brings in per phase (lpbc F0 / 256 and lines F1 / 256 at most)
+
+struct CoopArgs {
+    ToepGeom g;
+    const double2* ws;
+    const double* diag;
+    double sigmasq;
+    int variant;
+    double tol;
+    int early_stop;
+    int batched;
+    int max_iter;
+    const double2* b;         // [systems][M]
+    double2* x;               // in: x0, out: solution
+    const double2* vhat;
+    const double2* tw0;
+    const double2* tw1;
+    double2* b1;              // [systems][n0][F1]
+    double2* b2;              // [systems][n0][F1]
+    double* partial;          // [systems][3][kCoopMaxG]
+    unsigned* bar;            // [systems] arrival counters, 64 bytes apart, zero at launch
+    int* iters;               // [systems]
+    int* status;              // [0] != 0: a barrier timed out
+    double* hist;
+    int hist_cap;
+    int G;                    // workgroups per system == column blocks
+    int lines;                // rows owned per workgroup
+    int lpbc;                 // columns per workgroup
+    int dbg;                  // EFGP_COOP_DBG=2: cycle counters per phase (workgroup 0 of system 0)
+    double* stamps;
+};
+
+__device__ __forceinline__ void store_agent2(double2* p, double2 v) {
+    __hip_atomic_store(&p->x, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double2 load_agent2(const double2* p) {
+    return make_double2(__hip_atomic_load(&p->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                        __hip_atomic_load(&p->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// returns false (in every thread of the workgroup) when the barrier is dead
+__device__ __forceinline__ bool coop_barrier(unsigned* bar, unsigned& epoch, int G, int* status, int* sflag) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);                       // this thread's write-through stores have been acknowledged
+    __syncthreads();
+    ++epoch;
+    if (threadIdx.x == 0) {
+        // release: an acknowledged write-through store has left this XCD's L2 only once the L2 write-back the release
+        // performs has drained (a relaxed arrival let another XCD read B1 / B2 before the data: 1 wrong system in ~30)
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = epoch * (unsigned)G;
+        int ok = 1;
+        unsigned polls = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            ++polls;
+            if (polls > kCoopPollLimit || ((polls & 255u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *sflag = ok;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return *sflag != 0;
+}
+
+__global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
+    extern __shared__ double2 lsm[];
+    __shared__ double red[kLineThreads / 64];
+    __shared__ double fin[3 * kCoopMaxG];
+    __shared__ int sflag;
+    const int tid = threadIdx.x, wg = blockIdx.x, sys = blockIdx.y, G = a.G;
+    const int n0 = (int)a.g.n[0], n1 = (int)a.g.n[1], F0 = (int)a.g.F[0], F1 = (int)a.g.F[1];
+    const int ldr = F1 + 1, ldc = F0 + 1;
+    const int lgF1 = ilog2(F1), lgC = ilog2(a.lpbc);
+    const int bufsz = max(a.lines * ldr, a.lpbc * ldc);
+    double2* A = lsm;
+    double2* B = lsm + bufsz;
+    double2* tw1s = B + bufsz;
+    double2* tw0s = F0 == F1 ? tw1s : tw1s + F1;
+    load_twiddles(tw1s, a.tw1, F1);
+    if (F0 != F1) load_twiddles(tw0s, a.tw0, F0);
+    __syncthreads();
+    const int64_t M = a.g.M;
+    const int r0 = wg * a.lines;
+    const int nl = max(0, min(a.lines, n0 - r0));       // rows owned (0 for the trailing workgroups)
+    const int cnt = nl * n1;
+    const int64_t base = (int64_t)sys * M + (int64_t)r0 * n1;    // the owned elements are contiguous in the flat vector
+    const int c0 = wg * a.lpbc;
+    double2* b1 = a.b1 + (int64_t)sys * n0 * F1;
+    double2* b2 = a.b2 + (int64_t)sys * n0 * F1;
+    double* part = a.partial + (int64_t)sys * 3 * kCoopMaxG;
+    unsigned* bar = a.bar + (int64_t)sys * 16;
+    unsigned epoch = 0;
+    long long st_prev = (long long)__builtin_readcyclecounter();
+#define COOP_STAMP(slot_)                                                                     \
+    do {                                                                                      \
+        if (a.dbg == 2 && wg == 0 && sys == 0 && tid == 0) {                                  \
+            const long long now_ = (long long)__builtin_readcyclecounter();                   \
+            a.stamps[slot_] += (double)(now_ - st_prev);       \
+            st_prev = now_;                                                                   \
+        }                                                                                     \
+    } while (0)
+
+    double2 xv[kCoopSlots], rv[kCoopSlots], pv[kCoopSlots], wsv[kCoopSlots];
+    double dg[kCoopSlots];
+    int lo_[kCoopSlots], lidx[kCoopSlots];              // LDS offsets: padded input position, cropped output position
+    bool ok[kCoopSlots];
+#pragma unroll
+    for (int s = 0; s < kCoopSlots; ++s) {
+        const int e = tid + s * kLineThreads;
+        ok[s] = e < cnt;
+        const int l = ok[s] ? e / n1 : 0, i1 = ok[s] ? e - l * n1 : 0;
+        lo_[s] = l * ldr + i1;
+        lidx[s] = l * ldr + (n1 - 1) + i1;
+        if (ok[s]) {
+            const int t = r0 * n1 + e;
+            xv[s] = a.x[base + e];
+            wsv[s] = a.ws[t];
+            dg[s] = a.diag ? a.diag[t] : 1.0;
+        } else {
+            xv[s] = wsv[s] = make_double2(0.0, 0.0);
+            dg[s] = 1.0;
+        }
+        rv[s] = pv[s] = make_double2(0.0, 0.0);
+    }
+
+    // Au = A u for the owned elements; false when a barrier died
+    auto apply = [&](const double2 (&u)[kCoopSlots], double2 (&Au)[kCoopSlots]) __attribute__((always_inline)) -> bool {
+        // R
+        if (nl > 0) {
+            for (int l = 0; l < nl; ++l)                                      // zero padding behind the n1 inputs of each row
+                for (int i1 = n1 + tid; i1 < F1; i1 += kLineThreads) A[l * ldr + i1] = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int s = 0; s < kCoopSlots; ++s)
+                if (ok[s]) A[lo_[s]] = cmul(u[s], wsv[s]);
+            __syncthreads();
+            const double2* X = line_fft(A, B, F1, ldr, nl, tw1s);
+            for (int w = tid; w < (nl << lgF1); w += kLineThreads) {
+                const int l = w >> lgF1, i1 = w & (F1 - 1);
+                store_agent2(b1 + (int64_t)(r0 + l) * F1 + i1, X[l * ldr + i1]);
+            }
+        }
+        COOP_STAMP(0);
+        if (!coop_barrier(bar, epoch, G, a.status, &sflag)) return false;
+        COOP_STAMP(1);
+        // C
+        {
+            // every thread's loads are issued before the first is consumed (one at a time costs a memory round trip each)
+            double2 tmp[kCoopLoads];
+#pragma unroll
+            for (int q = 0; q < kCoopLoads; ++q) {
+                const int w = tid + q * kLineThreads, i0 = w >> lgC;
+                tmp[q] = (w < (F0 << lgC) && i0 < n0) ? load_agent2(b1 + (int64_t)i0 * F1 + c0 + (w & (a.lpbc - 1))) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int q = 0; q < kCoopLoads; ++q) {
+                const int w = tid + q * kLineThreads;
+                if (w < (F0 << lgC)) A[(w & (a.lpbc - 1)) * ldc + (w >> lgC)] = tmp[q];
+            }
+            __syncthreads();
+            COOP_STAMP(8);
+            double2* X = line_fft(A, B, F0, ldc, a.lpbc, tw0s);
+            COOP_STAMP(9);
+            double2* Y = X == A ? B : A;
+            for (int w = tid; w < (F0 << lgC); w += kLineThreads) {
+                const int i0 = w >> lgC, l = w & (a.lpbc - 1);
+                const double2 m = cmul(X[l * ldc + i0], a.vhat[(int64_t)i0 * F1 + c0 + l]);
+                X[l * ldc + i0] = make_double2(m.x, -m.y);
+            }
+            __syncthreads();
+            COOP_STAMP(10);
+            const double2* Z = line_fft(X, Y, F0, ldc, a.lpbc, tw0s);
+            COOP_STAMP(11);
+            for (int w = tid; w < (n0 << lgC); w += kLineThreads) {
+                const int j = w >> lgC, l = w & (a.lpbc - 1);
+                const double2 z = Z[l * ldc + (n0 - 1) + j];
+                store_agent2(b2 + (int64_t)j * F1 + c0 + l, make_double2(z.x, -z.y));
+            }
+        }
+        COOP_STAMP(2);
+        if (!coop_barrier(bar, epoch, G, a.status, &sflag)) return false;
+        COOP_STAMP(3);
+        // Ri
+        if (nl > 0) {
+            double2 tmp[kCoopLoads];
+#pragma unroll
+            for (int q = 0; q < kCoopLoads; ++q) {
+                const int w = tid + q * kLineThreads;
+                tmp[q] = w < (nl << lgF1) ? load_agent2(b2 + (int64_t)r0 * F1 + w) : make_double2(0.0, 0.0);   // the owned rows are contiguous
+            }
+#pragma unroll
+            for (int q = 0; q < kCoopLoads; ++q) {
+                const int w = tid + q * kLineThreads;
+                if (w < (nl << lgF1)) A[(w >> lgF1) * ldr + (w & (F1 - 1))] = make_double2(tmp[q].x, -tmp[q].y);
+            }
+            __syncthreads();
+            const double2* X = line_fft(A, B, F1, ldr, nl, tw1s);
+#pragma unroll
+            for (int s = 0; s < kCoopSlots; ++s) {
+                if (ok[s]) {
+                    const double2 z = X[lidx[s]];
+                    const double2 gq = cmul(wsv[s], make_double2(z.x, -z.y));
+                    if (a.variant == 0) Au[s] = make_double2(gq.x + a.sigmasq * u[s].x, gq.y + a.sigmasq * u[s].y);
+                    else Au[s] = make_double2(gq.x / a.sigmasq + u[s].x, gq.y / a.sigmasq + u[s].y);
+                } else {
+                    Au[s] = make_double2(0.0, 0.0);
+                }
+            }
+            __syncthreads();                                      // the next phase overwrites the buffers
+        } else {
+#pragma unroll
+            for (int s = 0; s < kCoopSlots; ++s) Au[s] = make_double2(0.0, 0.0);
+        }
+        COOP_STAMP(4);
+        return true;
+    };
+    // sum of K per-workgroup partials over the G workgroups: same order, same bits in every workgroup.  `slot0`: first of the
+    // three partial arrays used -- consecutive sums must use DIFFERENT arrays (a fast workgroup writes its next partial
+    // while a slow one still reads the previous sum's: there is no barrier between a sum's reads and the next sum's writes)
+    auto all_sum = [&](double (&v)[3], int K, int slot0) __attribute__((always_inline)) -> bool {
+        for (int k = 0; k < K; ++k) {
+            const double t = block_sum(v[k], red);
+            if (tid == 0) __hip_atomic_store(&part[(slot0 + k) * kCoopMaxG + wg], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!coop_barrier(bar, epoch, G, a.status, &sflag)) return false;
+        for (int w = tid; w < K * G; w += kLineThreads) {
+            const int k = w / G, i = w - k * G;
+            fin[k * kCoopMaxG + i] = __hip_atomic_load(&part[(slot0 + k) * kCoopMaxG + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        for (int k = 0; k < K; ++k) {
+            double t = 0.0;
+            for (int i = 0; i < G; ++i) t += fin[k * kCoopMaxG + i];
+            v[k] = t;
+        }
+        __syncthreads();                                          // fin is reused by the next sum
+        return true;
+    };
+    auto dead = [&]() {
+        if (wg == 0 && tid == 0) a.iters[sys] = -3;
+    };
+
+    double2 Ap[kCoopSlots];
+    if (!apply(xv, Ap)) return dead();
+    double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < kCoopSlots; ++s) {
+        if (ok[s]) {
+            const double2 bv = a.b[base + tid + s * kLineThreads];
+            rv[s] = make_double2(bv.x - Ap[s].x, bv.y - Ap[s].y);
+            pv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            acc[0] += rv[s].x * pv[s].x + rv[s].y * pv[s].y;
+            acc[1] += bv.x * bv.x + bv.y * bv.y;
+        }
+    }
+    if (!all_sum(acc, 2, 0)) return dead();
+    double rz = acc[0];
+    const double bn = sqrt(acc[1]);
+    const double den = bn > 0.0 ? bn : 1.0;
+    int it = 0;
+    for (; it < a.max_iter;) {
+        if (!apply(pv, Ap)) return dead();
+        acc[0] = 0.0;
+#pragma unroll
+        for (int s = 0; s < kCoopSlots; ++s) acc[0] += pv[s].x * Ap[s].x + pv[s].y * Ap[s].y;
+        if (!all_sum(acc, 1, 2)) return dead();
+        COOP_STAMP(5);
+        const double alpha = rz / (acc[0] + kDivEps);
+        acc[0] = acc[1] = 0.0;
+        double2 zv[kCoopSlots];
+#pragma unroll
+        for (int s = 0; s < kCoopSlots; ++s) {
+            xv[s].x += alpha * pv[s].x;
+            xv[s].y += alpha * pv[s].y;
+            rv[s].x -= alpha * Ap[s].x;
+            rv[s].y -= alpha * Ap[s].y;
+            zv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            acc[0] += rv[s].x * rv[s].x + rv[s].y * rv[s].y;
+            acc[1] += rv[s].x * zv[s].x + rv[s].y * zv[s].y;
+        }
+        COOP_STAMP(6);
+        if (!all_sum(acc, 2, 0)) return dead();
+        COOP_STAMP(7);
+        ++it;
+        const double rnorm = sqrt(acc[0]), rzn = acc[1];
+        if (a.hist && sys == 0 && wg == 0 && tid == 0 && it <= a.hist_cap) a.hist[it - 1] = rnorm / (den + kDivEps);
+        const bool conv = a.early_stop && ((rnorm / (den + kDivEps) < a.tol) || (a.batched && rnorm < 1e-12));
+        if (!a.batched && conv) break;                            // cg.py:132
+        const double beta = rzn / (rz + kDivEps);
+#pragma unroll
+        for (int s = 0; s < kCoopSlots; ++s) pv[s] = make_double2(zv[s].x + beta * pv[s].x, zv[s].y + beta * pv[s].y);
+        rz = rzn;
+        if (conv) break;                                          // cg.py:229-241
+    }
+#pragma unroll
+    for (int s = 0; s < kCoopSlots; ++s)
+        if (ok[s]) a.x[base + tid + s * kLineThreads] = xv[s];
+    if (wg == 0 && tid == 0) a.iters[sys] = it;
 }
 
 // ==========================================================================================================
@@ -1074,6 +1439,88 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         if (batched_semantics && mx < max_iter) total = mx + 1;      // the terminating pass, cg.py:193-199,243
         if (iters_out) *iters_out = total;
         return EFGP_OK;
+    }
+
+    // 2-D grids of 128..512 per dimension, few systems: the whole solve in ONE cooperative launch (cg_coop2d_kernel)
+    if (op->lines_ok && std::getenv("EFGP_NO_CG_COOP") == nullptr && std::getenv("EFGP_NO_CG_LINES") == nullptr) {
+        const int F0 = (int)g.F[0], F1 = (int)g.F[1], n0 = (int)g.n[0], n1 = (int)g.n[1];
+        const int lpbc = F1 >= 256 ? 8 : 4;
+        const int G = F1 / lpbc;
+        const int lines = (n0 + G - 1) / G;
+        const size_t bufsz = (size_t)std::max(lines * (F1 + 1), lpbc * (F0 + 1));
+        const size_t lds = (2 * bufsz + (size_t)F1 + (F0 == F1 ? 0 : (size_t)F0)) * sizeof(double2);
+        if (G <= kCoopMaxG && (int64_t)G * nbatch <= ctx->num_cu && lines * n1 <= kCoopSlots * kLineThreads &&
+            lpbc * F0 <= kCoopLoads * kLineThreads && lines * F1 <= kCoopLoads * kLineThreads &&
+            lds + 2048 <= (size_t)ctx->max_lds) {
+            const size_t grid_elems = (size_t)nbatch * (size_t)n0 * (size_t)F1;
+            double2* pad = (double2*)scratch(ctx, SLOT_TOEP_PAD, 2 * grid_elems * sizeof(double2));
+            // partial sums | arrival counters (64 B apart) | iteration counts | status
+            const size_t off_bar = (size_t)nbatch * 3 * kCoopMaxG * sizeof(double);
+            const size_t off_iters = off_bar + (size_t)nbatch * 64;
+            const size_t off_status = off_iters + (((size_t)nbatch * sizeof(int) + 63) & ~size_t(63));
+            char* scb = (char*)scratch(ctx, SLOT_CG_SCALARS, off_status + 64);
+            int* host = pinned_host(ctx, off_status - off_iters + 64);
+            if (!pad || !scb || !host) return EFGP_ENOMEM;
+            CoopArgs ca;
+            ca.g = g;
+            ca.ws = (const double2*)ws;
+            ca.diag = precond_diag;
+            ca.sigmasq = sigmasq;
+            ca.variant = variant;
+            ca.tol = tol;
+            ca.early_stop = early_stop;
+            ca.batched = batched_semantics;
+            ca.max_iter = max_iter;
+            ca.b = (const double2*)b;
+            ca.x = (double2*)x;
+            ca.vhat = op->vhat;
+            ca.tw0 = op->tw[0];
+            ca.tw1 = op->tw[1];
+            ca.b1 = pad;
+            ca.b2 = pad + grid_elems;
+            ca.partial = (double*)scb;
+            ca.bar = (unsigned*)(scb + off_bar);
+            ca.iters = (int*)(scb + off_iters);
+            ca.status = (int*)(scb + off_status);
+            ca.hist = cg_history().buf;
+            ca.hist_cap = cg_history().capacity;
+            ca.G = G;
+            ca.lines = lines;
+            ca.lpbc = lpbc;
+            ca.dbg = std::getenv("EFGP_COOP_DBG") ? std::atoi(std::getenv("EFGP_COOP_DBG")) : 0;
+            ca.stamps = (double*)scratch(ctx, SLOT_MISC, 128);
+            if (ca.dbg == 2) EFGP_HIP_CHECK(hipMemsetAsync(ca.stamps, 0, 128, stream));
+            EFGP_HIP_CHECK(hipMemsetAsync(scb + off_bar, 0, off_status + 64 - off_bar, stream));
+            EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg_coop2d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            {
+                KernelTimer timer("cg_coop", stream);
+                hipLaunchKernelGGL(cg_coop2d_kernel, dim3(G, nbatch), dim3(kLineThreads), lds, stream, ca);
+            }
+            EFGP_HIP_CHECK(hipGetLastError());
+            EFGP_HIP_CHECK(hipMemcpyAsync(host, ca.iters, off_status + sizeof(int) - off_iters, hipMemcpyDeviceToHost, stream));
+            EFGP_HIP_CHECK(stream_wait(stream));
+            const int dead = host[(off_status - off_iters) / sizeof(int)];
+            if (ca.dbg == 2) {
+                double hs[12];
+                EFGP_HIP_CHECK(hipMemcpy(hs, ca.stamps, sizeof(hs), hipMemcpyDeviceToHost));
+                const char* nm[12] = {"R compute+store", "barrier 1", "C store", "barrier 2", "Ri load+fft", "pAp sum (incl. barrier)", "update", "rr/rz sum (incl. barrier)",
+                                      "C load", "C fft 1", "C multiply", "C fft 2"};
+                double tot = 0;
+                for (int q = 0; q < 12; ++q) tot += hs[q];
+                for (int q = 0; q < 12; ++q) std::fprintf(stderr, "[coop] %-28s %9.0f cycles/iter %5.1f%%\n", nm[q], hs[q] / std::max(1, host[0]), 100.0 * hs[q] / tot);
+            }
+            if (!dead) {
+                int mx = 0;
+                for (int i = 0; i < nbatch; ++i) {
+                    mx = std::max(mx, host[i]);
+                    if (row_iters_out) row_iters_out[i] = host[i];
+                }
+                if (iters_out) *iters_out = (batched_semantics && mx < max_iter) ? mx + 1 : mx;
+                return EFGP_OK;
+            }
+            // a grid barrier ran out of polls (the workgroups were not co-resident): x still holds x0; take the multi-launch path
+            std::fprintf(stderr, "[efgp_hip] cooperative CG: grid barrier timed out, falling back to the multi-launch iteration\n");
+        }
     }
 
     // The iteration bursts below are replayed as hipGraphs, which cannot be captured on the legacy default stream:

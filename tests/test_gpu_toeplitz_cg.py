@@ -248,3 +248,40 @@ def test_one_launch_toeplitz_spectrum_matches_rocfft_path(mtot, monkeypatch):
     plain = ToeplitzOp(v.cuda()).apply(u.cuda())
     assert _rel(fused, plain) < 1e-14
     assert _rel(fused, T(u)) < 1e-13
+
+
+@pytest.mark.parametrize("mtot,nb", [(41, 8), (71, 8), (131, 4), (57, 1), (99, 3)])
+def test_cooperative_solve_equals_multi_launch_iteration(mtot, nb, monkeypatch):
+    """cg_coop2d_kernel (the whole CG loop of a 128^2..512^2 grid in ONE launch over G workgroups per system with grid
+    barriers) against the multi-launch line-FFT iteration: same per-row iteration counts, solutions equal to rounding, and
+    bit-identical results launch after launch with as many systems in flight as fit the chip (a partial-sum array reused
+    by two consecutive reductions -- a cross-workgroup race -- showed up only with several systems resident)."""
+    from efgp_hip import ToeplitzOp, cg_solve
+    g = torch.Generator().manual_seed(12)
+    L = 2 * mtot - 1
+    v = torch.complex(torch.randn(L, L, generator=g, dtype=torch.float64), torch.randn(L, L, generator=g, dtype=torch.float64))
+    v = (v + v.flip(0, 1).conj()) / 2
+    v[mtot - 1, mtot - 1] = 3.0 * L
+    M = mtot * mtot
+    ws = torch.exp(-2.0 * torch.rand(M, generator=g, dtype=torch.float64)).to(torch.complex128)
+    b = torch.complex(torch.randn(nb, M, generator=g, dtype=torch.float64), torch.randn(nb, M, generator=g, dtype=torch.float64))
+    b = b * torch.logspace(-2, 1, nb, dtype=torch.float64)[:, None]
+    x0 = 0.05 * torch.complex(torch.randn(nb, M, generator=g, dtype=torch.float64), torch.randn(nb, M, generator=g, dtype=torch.float64))
+    diag = 3.0 * L * ws.abs().pow(2).real + 0.5
+    op = ToeplitzOp(v.cuda())
+    args = (op, ws.cuda(), 0.5, 0, b.cuda(), x0.cuda(), 1e-9)
+    monkeypatch.setenv("EFGP_NO_CG_COOP", "1")
+    ref = cg_solve(*args, diag=diag.cuda(), batched=True)
+    ref1 = cg_solve(op, ws.cuda(), 0.5, 1, b[0].cuda(), x0[0].cuda(), 1e-9, batched=False)
+    monkeypatch.delenv("EFGP_NO_CG_COOP")
+    first = None
+    for rep in range(6):
+        out = cg_solve(*args, diag=diag.cuda(), batched=True)
+        assert out[1] == ref[1] and out[2] == ref[2], (rep, out[1:], ref[1:])
+        for r in range(nb):                      # same recurrences; the partial sums are grouped by workgroup, not by 64 blocks
+            assert _rel(out[0][r], ref[0][r]) < 1e-12, (rep, r, _rel(out[0][r], ref[0][r]))
+        if first is None:
+            first = out[0].clone()
+        assert torch.equal(out[0], first), rep   # bit-identical from launch to launch: fixed summation order, no race
+    out1 = cg_solve(op, ws.cuda(), 0.5, 1, b[0].cuda(), x0[0].cuda(), 1e-9, batched=False)       # A_var, single-system rule, no diagonal
+    assert out1[1] == ref1[1] and _rel(out1[0], ref1[0]) < 1e-12
