@@ -271,6 +271,30 @@ def main():
     barrier()
     grad_step_ms = 1e3 * sorted(gts)[len(gts) // 2]
 
+    # CG iteration time on the circulant grids beyond one CU (BASELINE configs[2], [3] solve on 128^2..512^2): one cooperative
+    # launch per solve (cg_coop2d_kernel); synthetic Hermitian Toeplitz vector, 160 forced iterations, rank 0's GPU only
+    cg_mid = None
+    if rank == 0 and not args.no_extras:
+        from efgp_hip import ToeplitzOp
+        cg_mid = {}
+        gm = torch.Generator().manual_seed(0)
+        for mt in (41, 71, 131):
+            L = 2 * mt - 1
+            vv = torch.complex(torch.randn(L, L, generator=gm, dtype=torch.float64), torch.randn(L, L, generator=gm, dtype=torch.float64))
+            vv = ((vv + vv.flip(0, 1).conj()) / 2).to(dev)
+            wsm = torch.rand(mt * mt, generator=gm, dtype=torch.float64).to(torch.complex128).to(dev)
+            bm = torch.randn(mt * mt, generator=gm, dtype=torch.float64).to(torch.complex128).to(dev)
+            dgm = (wsm.abs() ** 2 + 0.1).real
+            opm = ToeplitzOp(vv)
+            for _ in range(2):
+                torch.cuda.synchronize(dev)
+                tm = time.perf_counter()
+                _, itm, _ = cg_solve(opm, wsm, 0.1, 0, bm, torch.zeros_like(bm), 1e-300, max_iter=160, early_stop=False, diag=dgm, batched=False)
+                torch.cuda.synchronize(dev)
+                dtm = time.perf_counter() - tm
+            cg_mid[f"{opm.fft_shape[0]}x{opm.fft_shape[1]}"] = 1e6 * dtm / itm
+            del opm
+
     # extra legs (every rank takes part: they contain collectives)
     weak = None
     star = None
@@ -354,6 +378,8 @@ def main():
             rec["weak_scaling"] = weak
         if star is not None:
             rec["north_star_n1e7"] = star
+        if cg_mid is not None:
+            rec["cg_mid_us_per_iter"] = cg_mid
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(1000)
         print(json.dumps(rec))
