@@ -109,25 +109,45 @@ __device__ __forceinline__ void window_eval(const double* __restrict__ coef_gene
         if (f < 0) f += (int)nfs[d];
         fs[d] = f;
     }
+    // p_j(s) = E_j(s^2) + s O_j(s^2) and its mirror p_{W-1-j}(s) = p_j(-s) = E_j - s O_j: the even and the odd half of
+    // the polynomial are evaluated once for the pair (degree + 1 fused multiply-adds per pair instead of 2 degree)
     double vp[D][RH], vm[D][RH];
+    double t[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) t[d] = s[d] * s[d];
+    const int ke = degree & ~1, ko = (degree - 1) | 1;      // highest even / odd power (degree >= 1)
 #pragma unroll
     for (int j = 0; j < RH; ++j) {
-        const double c = coef[degree * RHP + j];
+        const double ce = coef[ke * RHP + j], co = coef[ko * RHP + j];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            vp[d][j] = c;
-            vm[d][j] = c;
+            vp[d][j] = ce;
+            vm[d][j] = co;
         }
     }
-    for (int k = degree - 1; k >= 0; --k) {
+    for (int k = ke - 2; k >= 0; k -= 2) {
 #pragma unroll
         for (int j = 0; j < RH; ++j) {
             const double c = coef[k * RHP + j];
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                vp[d][j] = fma(vp[d][j], s[d], c);
-                vm[d][j] = fma(vm[d][j], -s[d], c);
-            }
+            for (int d = 0; d < D; ++d) vp[d][j] = fma(vp[d][j], t[d], c);
+        }
+    }
+    for (int k = ko - 2; k >= 1; k -= 2) {
+#pragma unroll
+        for (int j = 0; j < RH; ++j) {
+            const double c = coef[k * RHP + j];
+#pragma unroll
+            for (int d = 0; d < D; ++d) vm[d][j] = fma(vm[d][j], t[d], c);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RH; ++j) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const double e = vp[d][j], o = vm[d][j];
+            vp[d][j] = fma(s[d], o, e);
+            vm[d][j] = fma(-s[d], o, e);
         }
     }
     f0 = fs[0];

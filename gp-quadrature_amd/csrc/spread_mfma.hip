@@ -83,56 +83,67 @@ struct WindowCoef {
 template <int W, int DEG>
 __device__ __forceinline__ void horner2(const WindowCoef<W, DEG>& wc, const double* __restrict__ coef_generic, int degree, double s0,
                                         double s1, double (&v0)[W], double (&v1)[W]) {
+    // even / odd split (see window_eval): p_j(+-s) = E_j(s^2) +- s O_j(s^2), degree + 1 fused multiply-adds per mirror pair
     constexpr int RH = (W + 1) / 2, RHP = sym_row(W);
-    double p0[RH], m0[RH], p1[RH], m1[RH];
+    double e0[RH], o0[RH], e1[RH], o1[RH];
+    const double t0 = s0 * s0, t1 = s1 * s1;
     if (DEG > 0) {
+        constexpr int KE = DEG & ~1, KO = (DEG - 1) | 1;
 #pragma unroll
         for (int j = 0; j < RH; ++j) {
-            const double top = wc.cf[DEG * RH + j];
-            p0[j] = top;
-            m0[j] = top;
-            p1[j] = top;
-            m1[j] = top;
+            e0[j] = e1[j] = wc.cf[KE * RH + j];
+            o0[j] = o1[j] = wc.cf[KO * RH + j];
         }
 #pragma unroll
-        for (int k = DEG - 1; k >= 0; --k) {
+        for (int k = KE - 2; k >= 0; k -= 2) {
 #pragma unroll
             for (int j = 0; j < RH; ++j) {
                 const double c = wc.cf[k * RH + j];
-                p0[j] = fma(p0[j], s0, c);
-                m0[j] = fma(m0[j], -s0, c);
-                p1[j] = fma(p1[j], s1, c);
-                m1[j] = fma(m1[j], -s1, c);
+                e0[j] = fma(e0[j], t0, c);
+                e1[j] = fma(e1[j], t1, c);
+            }
+        }
+#pragma unroll
+        for (int k = KO - 2; k >= 1; k -= 2) {
+#pragma unroll
+            for (int j = 0; j < RH; ++j) {
+                const double c = wc.cf[k * RH + j];
+                o0[j] = fma(o0[j], t0, c);
+                o1[j] = fma(o1[j], t1, c);
             }
         }
     } else {
         const_coef_ptr coef = (const_coef_ptr)(coef_generic + (kMaxDegree + 1) * W);
+        const int ke = degree & ~1, ko = (degree - 1) | 1;
 #pragma unroll
         for (int j = 0; j < RH; ++j) {
-            const double top = coef[degree * RHP + j];
-            p0[j] = top;
-            m0[j] = top;
-            p1[j] = top;
-            m1[j] = top;
+            e0[j] = e1[j] = coef[ke * RHP + j];
+            o0[j] = o1[j] = coef[ko * RHP + j];
         }
-        for (int k = degree - 1; k >= 0; --k) {
+        for (int k = ke - 2; k >= 0; k -= 2) {
 #pragma unroll
             for (int j = 0; j < RH; ++j) {
                 const double c = coef[k * RHP + j];
-                p0[j] = fma(p0[j], s0, c);
-                m0[j] = fma(m0[j], -s0, c);
-                p1[j] = fma(p1[j], s1, c);
-                m1[j] = fma(m1[j], -s1, c);
+                e0[j] = fma(e0[j], t0, c);
+                e1[j] = fma(e1[j], t1, c);
+            }
+        }
+        for (int k = ko - 2; k >= 1; k -= 2) {
+#pragma unroll
+            for (int j = 0; j < RH; ++j) {
+                const double c = coef[k * RHP + j];
+                o0[j] = fma(o0[j], t0, c);
+                o1[j] = fma(o1[j], t1, c);
             }
         }
     }
 #pragma unroll
     for (int j = 0; j < RH; ++j) {
-        v0[j] = p0[j];
-        v1[j] = p1[j];
+        v0[j] = fma(s0, o0[j], e0[j]);
+        v1[j] = fma(s1, o1[j], e1[j]);
         if (W - 1 - j != j) {
-            v0[W - 1 - j] = m0[j];
-            v1[W - 1 - j] = m1[j];
+            v0[W - 1 - j] = fma(-s0, o0[j], e0[j]);
+            v1[W - 1 - j] = fma(-s1, o1[j], e1[j]);
         }
     }
 }
