@@ -1229,7 +1229,27 @@ struct efgp_toeplitz_s {
     bool persistent_ok = false;
     bool lines_ok = false;       // 2-D, power-of-two F in [128, 512]: fused line-FFT CG iteration
     bool lines3_ok = false;      // 3-D, power-of-two F in [64, 256]: the same with five pruned line passes
+    // 2-D blocks of up to 16 x 16 modes (circulant grids 8^2 .. 32^2): the CG solves run on a 64 x 64 embedding instead, through
+    // the specialised 64 x 64 kernels (any F >= 2 n - 1 embeds the Toeplitz product exactly; measured 3.1 us per iteration
+    // against 9-11 us of the generic kernel on the 32 x 32 grid).  fft_shape / efgp_toeplitz_apply keep the reference's grid.
+    ToepGeom g_cg;
+    double2* vhat_cg = nullptr;
+    double2* tw_cg[3] = {nullptr, nullptr, nullptr};
+    bool cg64 = false;
 };
+
+// geometry, twiddles and spectrum the single-launch CG kernels use for this operator
+static void cg_operands(const efgp_toeplitz_s* op, const ToepGeom** g, const double2* const** tw, const double2** vhat) {
+    if (op->cg64) {
+        *g = &op->g_cg;
+        *tw = (const double2* const*)op->tw_cg;
+        *vhat = op->vhat_cg;
+    } else {
+        *g = &op->g;
+        *tw = (const double2* const*)op->tw;
+        *vhat = op->vhat;
+    }
+}
 
 namespace efgp {
 
@@ -1356,6 +1376,37 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
             op->tw[a] = dtw;
         }
     }
+    if (dim == 2 && op->persistent_ok && op->g.n[0] == op->g.n[1] && op->g.F[0] == op->g.F[1] && op->g.F[0] < 64 &&
+        op->Ls[0] <= 63 && std::getenv("EFGP_NO_CG64_EMBED") == nullptr && std::getenv("EFGP_NO_CG64") == nullptr) {
+        op->g_cg = op->g;
+        op->g_cg.F[0] = op->g_cg.F[1] = 64;
+        op->g_cg.Ftot = 64 * 64;
+        op->vhat_cg = (double2*)pool_alloc(ctx, (size_t)4096 * sizeof(double2));
+        bool ok = op->vhat_cg != nullptr;
+        if (ok) {
+            auto it = ctx->twiddles.find(64);
+            if (it == ctx->twiddles.end()) {
+                std::vector<double2> tw(64);
+                const long double two_pi = 2.0L * acosl(-1.0L);
+                for (int q = 0; q < 64; ++q) tw[(size_t)q] = make_double2((double)cosl(-two_pi * q / 64.0L), (double)sinl(-two_pi * q / 64.0L));
+                double2* dtw = nullptr;
+                ok = hipMalloc((void**)&dtw, 64 * sizeof(double2)) == hipSuccess &&
+                     hipMemcpyAsync(dtw, tw.data(), 64 * sizeof(double2), hipMemcpyHostToDevice, stream) == hipSuccess &&
+                     hipStreamSynchronize(stream) == hipSuccess;
+                if (ok) ctx->twiddles[64] = dtw;
+                else if (dtw) (void)hipFree(dtw);
+            }
+            if (ok) op->tw_cg[0] = op->tw_cg[1] = (double2*)ctx->twiddles[64];
+        }
+        if (ok) ok = toeplitz_vhat_fused_launch((const double2*)v, (int)op->Ls[0], (int)op->Ls[1], 1.0 / 4096.0, op->vhat_cg, stream) == EFGP_OK;
+        if (ok) {
+            op->cg64 = true;
+        } else {
+            (void)hipGetLastError();
+            if (op->vhat_cg) pool_free(ctx, op->vhat_cg, (size_t)4096 * sizeof(double2));
+            op->vhat_cg = nullptr;
+        }
+    }
     *op_out = op;
     return EFGP_OK;
 }
@@ -1366,6 +1417,7 @@ int efgp_toeplitz_destroy(efgp_toeplitz_t* op) {
     // the spectrum block goes back to the pool; work already enqueued on the caller's stream that reads it
     // finishes before any later enqueue on that stream can overwrite a recycled block (single stream)
     if (op->vhat) pool_free(op->ctx, op->vhat, (size_t)op->g.Ftot * sizeof(double2));
+    if (op->vhat_cg) pool_free(op->ctx, op->vhat_cg, (size_t)4096 * sizeof(double2));
     delete op;
     return EFGP_OK;
 }
@@ -1423,7 +1475,11 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         int rc;
         {
             KernelTimer timer("cg_persistent", stream);
-            rc = persistent_cg_launch(g, (const double2* const*)op->tw, op->vhat, (const double2*)ws, precond_diag, sigmasq,
+            const ToepGeom* gq;
+            const double2* const* twq;
+            const double2* vq;
+            cg_operands(op, &gq, &twq, &vq);
+            rc = persistent_cg_launch(*gq, twq, vq, (const double2*)ws, precond_diag, sigmasq,
                                       variant, tol, early_stop, batched_semantics, max_iter, (const double2*)b, (double2*)x,
                                       nbatch, d_iters, stream);
         }
@@ -1839,7 +1895,11 @@ static int cg_solve_async_impl(efgp_toeplitz_t* op, const void* ws, double sigma
     DeviceGuard guard(op->device);
     if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * op->g.M, 2000000000);
     KernelTimer timer("cg_persistent", stream);
-    return persistent_cg_launch(op->g, (const double2* const*)op->tw, op->vhat, (const double2*)ws, precond_diag, sigmasq,
+    const ToepGeom* gq;
+    const double2* const* twq;
+    const double2* vq;
+    cg_operands(op, &gq, &twq, &vq);
+    return persistent_cg_launch(*gq, twq, vq, (const double2*)ws, precond_diag, sigmasq,
                                 variant, tol, early_stop, batched_semantics, max_iter, (const double2*)b, (double2*)x, nbatch,
                                 row_iters_dev, stream, nullptr, 0, 0, nullptr, hermitian);
 }
@@ -1857,7 +1917,11 @@ int efgp_lanczos(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varian
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(op->device);
     const LanczosOut lz{steps, alpha_dev, beta_dev, norm2_dev};
-    return persistent_cg_launch(op->g, (const double2* const*)op->tw, op->vhat, (const double2*)ws, nullptr, sigmasq, variant, 0.0, 0,
+    const ToepGeom* gq;
+    const double2* const* twq;
+    const double2* vq;
+    cg_operands(op, &gq, &twq, &vq);
+    return persistent_cg_launch(*gq, twq, vq, (const double2*)ws, nullptr, sigmasq, variant, 0.0, 0,
                                 1, steps, (const double2*)z, nullptr, nprobes, steps_taken_dev, stream, nullptr, 0, 1, &lz);
 }
 
@@ -1872,7 +1936,11 @@ int efgp_cg_solve_mean_async(efgp_toeplitz_t* op, const void* ws, double sigmasq
     DeviceGuard guard(op->device);
     if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * op->g.M, 2000000000);
     KernelTimer timer("cg_persistent", stream);
-    return persistent_cg_launch(op->g, (const double2* const*)op->tw, op->vhat, (const double2*)ws, nullptr, sigmasq, 0, tol,
+    const ToepGeom* gq;
+    const double2* const* twq;
+    const double2* vq;
+    cg_operands(op, &gq, &twq, &vq);
+    return persistent_cg_launch(*gq, twq, vq, (const double2*)ws, nullptr, sigmasq, 0, tol,
                                 early_stop, 0, max_iter, (const double2*)fy, (double2*)x, 1, iters_dev, stream, diag_scale_dev,
                                 1, 1, nullptr, /*hermitian: F*y of a real y, Toeplitz vector of real weights*/ 1);
 }

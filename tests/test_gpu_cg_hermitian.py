@@ -36,7 +36,8 @@ def _system(mtot, seed, N=700, rows=None):
     return v, O.Toeplitz(v), ws, b
 
 
-@pytest.mark.parametrize("mtot,precond,tol", [(23, True, 1e-8), (23, False, 1e-6), (17, True, 1e-10), (31, True, 1e-6), (29, True, 1e-4)])
+@pytest.mark.parametrize("mtot,precond,tol", [(23, True, 1e-8), (23, False, 1e-6), (17, True, 1e-10), (31, True, 1e-6), (29, True, 1e-4),
+                                              (15, True, 1e-8), (7, True, 1e-8), (3, False, 1e-8)])   # small blocks: 64 x 64 embedding
 def test_mean_solve_matches_complex_kernel_and_oracle(mtot, precond, tol, monkeypatch):
     from efgp_hip import ToeplitzOp, cg_solve_mean_async
     from oracle import efgp_oracle as O
@@ -124,7 +125,7 @@ def test_contract_violations_are_refused():
 def test_other_grids_take_the_general_solver():
     """hermitian=True is a contract plus a hint: grids without the specialised kernel give the general solver's result."""
     from efgp_hip import ToeplitzOp, cg_solve
-    for mtot in (15, 41):
+    for mtot in (41, 71):
         v, T, ws, b = _system(mtot, 4)
         op = ToeplitzOp(v.cuda())
         xa, ia, _ = cg_solve(op, ws.cuda(), 0.25, 0, b.cuda(), torch.zeros_like(b).cuda(), 1e-8, batched=False, hermitian=True)
