@@ -697,18 +697,28 @@ struct CoopArgs {
     int* status;              // [0] != 0: a barrier timed out
     double* hist;
     int hist_cap;
-    int G;                    // workgroups per system == column blocks
-    int lines;                // rows owned per workgroup
-    int lpbc;                 // columns per workgroup
+    int G;                    // workgroups per system
+    int rows_wg;              // rows of the mode block owned per workgroup (ceil(n0 / G))
+    int cols_wg;              // columns owned per workgroup (F1 / G)
+    int lines;                // rows per LDS pass of the row phases
+    int lpbc;                 // columns per LDS pass of the column phase (a power of two)
     int dbg;                  // EFGP_COOP_DBG=2: cycle counters per phase (workgroup 0 of system 0)
     double* stamps;
 };
 
-__device__ __forceinline__ void store_agent2(double2* p, double2 v) {
-    __hip_atomic_store(&p->x, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// SOLO (G == 1): the intermediate grids are private to the workgroup -- ordinary cached accesses, no grid barrier
+template <bool SOLO>
+__device__ __forceinline__ void store_x2(double2* p, double2 v) {
+    if (SOLO) {
+        *p = v;
+    } else {
+        __hip_atomic_store(&p->x, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
-__device__ __forceinline__ double2 load_agent2(const double2* p) {
+template <bool SOLO>
+__device__ __forceinline__ double2 load_x2(const double2* p) {
+    if (SOLO) return *p;
     return make_double2(__hip_atomic_load(&p->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                         __hip_atomic_load(&p->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
@@ -720,8 +730,6 @@ __device__ __forceinline__ bool coop_barrier(unsigned* bar, unsigned& epoch, int
     __syncthreads();
     ++epoch;
     if (threadIdx.x == 0) {
-        // release: an acknowledged write-through store has left this XCD's L2 only once the L2 write-back the release
-        // performs has drained (a relaxed arrival let another XCD read B1 / B2 before the data: 1 wrong system in ~30)
         __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = epoch * (unsigned)G;
         int ok = 1;
@@ -742,6 +750,11 @@ __device__ __forceinline__ bool coop_barrier(unsigned* bar, unsigned& epoch, int
     return *sflag != 0;
 }
 
+// KS: vector elements per thread (owned rows x n1 <= KS x 256).  Two launch shapes (chosen by the host):
+//   latency  (few systems)  : G = F1 / lpbc workgroups per system, one row pass and one column pass per phase, KS = 4
+//   throughput (many systems): as few workgroups per system as the registers allow (G = 1: no grid barrier at all, the
+//                              intermediate grids stay in this CU's caches), several LDS passes per phase, KS = 8
+template <int KS, bool SOLO>
 __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
     extern __shared__ double2 lsm[];
     __shared__ double red[kLineThreads / 64];
@@ -760,11 +773,11 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
     if (F0 != F1) load_twiddles(tw0s, a.tw0, F0);
     __syncthreads();
     const int64_t M = a.g.M;
-    const int r0 = wg * a.lines;
-    const int nl = max(0, min(a.lines, n0 - r0));       // rows owned (0 for the trailing workgroups)
-    const int cnt = nl * n1;
+    const int r0 = wg * a.rows_wg;
+    const int nrows = max(0, min(a.rows_wg, n0 - r0));      // rows owned (0 for trailing workgroups)
+    const int cnt = nrows * n1;
     const int64_t base = (int64_t)sys * M + (int64_t)r0 * n1;    // the owned elements are contiguous in the flat vector
-    const int c0 = wg * a.lpbc;
+    const int c_lo = wg * a.cols_wg;
     double2* b1 = a.b1 + (int64_t)sys * n0 * F1;
     double2* b2 = a.b2 + (int64_t)sys * n0 * F1;
     double* part = a.partial + (int64_t)sys * 3 * kCoopMaxG;
@@ -775,22 +788,21 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
     do {                                                                                      \
         if (a.dbg == 2 && wg == 0 && sys == 0 && tid == 0) {                                  \
             const long long now_ = (long long)__builtin_readcyclecounter();                   \
-            a.stamps[slot_] += (double)(now_ - st_prev);       \
+            a.stamps[slot_] += (double)(now_ - st_prev);                                      \
             st_prev = now_;                                                                   \
         }                                                                                     \
     } while (0)
 
-    double2 xv[kCoopSlots], rv[kCoopSlots], pv[kCoopSlots], wsv[kCoopSlots];
-    double dg[kCoopSlots];
-    int lo_[kCoopSlots], lidx[kCoopSlots];              // LDS offsets: padded input position, cropped output position
-    bool ok[kCoopSlots];
+    double2 xv[KS], rv[KS], pv[KS], wsv[KS];
+    double dg[KS];
+    int lrow[KS], lcol[KS];                              // owned element s: row r0 + lrow[s], column lcol[s] of the mode block
+    bool ok[KS];
 #pragma unroll
-    for (int s = 0; s < kCoopSlots; ++s) {
+    for (int s = 0; s < KS; ++s) {
         const int e = tid + s * kLineThreads;
         ok[s] = e < cnt;
-        const int l = ok[s] ? e / n1 : 0, i1 = ok[s] ? e - l * n1 : 0;
-        lo_[s] = l * ldr + i1;
-        lidx[s] = l * ldr + (n1 - 1) + i1;
+        lrow[s] = ok[s] ? e / n1 : 0;
+        lcol[s] = ok[s] ? e - lrow[s] * n1 : 0;
         if (ok[s]) {
             const int t = r0 * n1 + e;
             xv[s] = a.x[base + e];
@@ -802,34 +814,43 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
         }
         rv[s] = pv[s] = make_double2(0.0, 0.0);
     }
+    auto sync_grid = [&]() __attribute__((always_inline)) -> bool {
+        if (SOLO) {
+            __syncthreads();
+            return true;
+        }
+        return coop_barrier(bar, epoch, G, a.status, &sflag);
+    };
 
     // Au = A u for the owned elements; false when a barrier died
-    auto apply = [&](const double2 (&u)[kCoopSlots], double2 (&Au)[kCoopSlots]) __attribute__((always_inline)) -> bool {
-        // R
-        if (nl > 0) {
+    auto apply = [&](const double2 (&u)[KS], double2 (&Au)[KS]) __attribute__((always_inline)) -> bool {
+        // R: owned rows in passes of a.lines
+        for (int p0 = 0; p0 < nrows; p0 += a.lines) {
+            const int nl = min(a.lines, nrows - p0);
             for (int l = 0; l < nl; ++l)                                      // zero padding behind the n1 inputs of each row
                 for (int i1 = n1 + tid; i1 < F1; i1 += kLineThreads) A[l * ldr + i1] = make_double2(0.0, 0.0);
 #pragma unroll
-            for (int s = 0; s < kCoopSlots; ++s)
-                if (ok[s]) A[lo_[s]] = cmul(u[s], wsv[s]);
+            for (int s = 0; s < KS; ++s)
+                if (ok[s] && lrow[s] >= p0 && lrow[s] < p0 + nl) A[(lrow[s] - p0) * ldr + lcol[s]] = cmul(u[s], wsv[s]);
             __syncthreads();
             const double2* X = line_fft(A, B, F1, ldr, nl, tw1s);
             for (int w = tid; w < (nl << lgF1); w += kLineThreads) {
                 const int l = w >> lgF1, i1 = w & (F1 - 1);
-                store_agent2(b1 + (int64_t)(r0 + l) * F1 + i1, X[l * ldr + i1]);
+                store_x2<SOLO>(b1 + (int64_t)(r0 + p0 + l) * F1 + i1, X[l * ldr + i1]);
             }
+            __syncthreads();                                                  // the next pass refills the buffers
         }
         COOP_STAMP(0);
-        if (!coop_barrier(bar, epoch, G, a.status, &sflag)) return false;
+        if (!sync_grid()) return false;
         COOP_STAMP(1);
-        // C
-        {
+        // C: owned columns in passes of a.lpbc
+        for (int c0 = c_lo; c0 < c_lo + a.cols_wg; c0 += a.lpbc) {
             // every thread's loads are issued before the first is consumed (one at a time costs a memory round trip each)
             double2 tmp[kCoopLoads];
 #pragma unroll
             for (int q = 0; q < kCoopLoads; ++q) {
                 const int w = tid + q * kLineThreads, i0 = w >> lgC;
-                tmp[q] = (w < (F0 << lgC) && i0 < n0) ? load_agent2(b1 + (int64_t)i0 * F1 + c0 + (w & (a.lpbc - 1))) : make_double2(0.0, 0.0);
+                tmp[q] = (w < (F0 << lgC) && i0 < n0) ? load_x2<SOLO>(b1 + (int64_t)i0 * F1 + c0 + (w & (a.lpbc - 1))) : make_double2(0.0, 0.0);
             }
 #pragma unroll
             for (int q = 0; q < kCoopLoads; ++q) {
@@ -837,9 +858,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
                 if (w < (F0 << lgC)) A[(w & (a.lpbc - 1)) * ldc + (w >> lgC)] = tmp[q];
             }
             __syncthreads();
-            COOP_STAMP(8);
             double2* X = line_fft(A, B, F0, ldc, a.lpbc, tw0s);
-            COOP_STAMP(9);
             double2* Y = X == A ? B : A;
             for (int w = tid; w < (F0 << lgC); w += kLineThreads) {
                 const int i0 = w >> lgC, l = w & (a.lpbc - 1);
@@ -847,25 +866,27 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
                 X[l * ldc + i0] = make_double2(m.x, -m.y);
             }
             __syncthreads();
-            COOP_STAMP(10);
             const double2* Z = line_fft(X, Y, F0, ldc, a.lpbc, tw0s);
-            COOP_STAMP(11);
             for (int w = tid; w < (n0 << lgC); w += kLineThreads) {
                 const int j = w >> lgC, l = w & (a.lpbc - 1);
                 const double2 z = Z[l * ldc + (n0 - 1) + j];
-                store_agent2(b2 + (int64_t)j * F1 + c0 + l, make_double2(z.x, -z.y));
+                store_x2<SOLO>(b2 + (int64_t)j * F1 + c0 + l, make_double2(z.x, -z.y));
             }
+            __syncthreads();
         }
         COOP_STAMP(2);
-        if (!coop_barrier(bar, epoch, G, a.status, &sflag)) return false;
+        if (!sync_grid()) return false;
         COOP_STAMP(3);
-        // Ri
-        if (nl > 0) {
+        // Ri: owned rows in passes
+#pragma unroll
+        for (int s = 0; s < KS; ++s) Au[s] = make_double2(0.0, 0.0);
+        for (int p0 = 0; p0 < nrows; p0 += a.lines) {
+            const int nl = min(a.lines, nrows - p0);
             double2 tmp[kCoopLoads];
 #pragma unroll
             for (int q = 0; q < kCoopLoads; ++q) {
                 const int w = tid + q * kLineThreads;
-                tmp[q] = w < (nl << lgF1) ? load_agent2(b2 + (int64_t)r0 * F1 + w) : make_double2(0.0, 0.0);   // the owned rows are contiguous
+                tmp[q] = w < (nl << lgF1) ? load_x2<SOLO>(b2 + (int64_t)(r0 + p0) * F1 + w) : make_double2(0.0, 0.0);   // rows are contiguous
             }
 #pragma unroll
             for (int q = 0; q < kCoopLoads; ++q) {
@@ -875,20 +896,15 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
             __syncthreads();
             const double2* X = line_fft(A, B, F1, ldr, nl, tw1s);
 #pragma unroll
-            for (int s = 0; s < kCoopSlots; ++s) {
-                if (ok[s]) {
-                    const double2 z = X[lidx[s]];
+            for (int s = 0; s < KS; ++s) {
+                if (ok[s] && lrow[s] >= p0 && lrow[s] < p0 + nl) {
+                    const double2 z = X[(lrow[s] - p0) * ldr + (n1 - 1) + lcol[s]];
                     const double2 gq = cmul(wsv[s], make_double2(z.x, -z.y));
                     if (a.variant == 0) Au[s] = make_double2(gq.x + a.sigmasq * u[s].x, gq.y + a.sigmasq * u[s].y);
                     else Au[s] = make_double2(gq.x / a.sigmasq + u[s].x, gq.y / a.sigmasq + u[s].y);
-                } else {
-                    Au[s] = make_double2(0.0, 0.0);
                 }
             }
-            __syncthreads();                                      // the next phase overwrites the buffers
-        } else {
-#pragma unroll
-            for (int s = 0; s < kCoopSlots; ++s) Au[s] = make_double2(0.0, 0.0);
+            __syncthreads();                                      // the next pass / phase overwrites the buffers
         }
         COOP_STAMP(4);
         return true;
@@ -897,6 +913,10 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
     // three partial arrays used -- consecutive sums must use DIFFERENT arrays (a fast workgroup writes its next partial
     // while a slow one still reads the previous sum's: there is no barrier between a sum's reads and the next sum's writes)
     auto all_sum = [&](double (&v)[3], int K, int slot0) __attribute__((always_inline)) -> bool {
+        if (SOLO) {
+            for (int k = 0; k < K; ++k) v[k] = block_sum(v[k], red);
+            return true;
+        }
         for (int k = 0; k < K; ++k) {
             const double t = block_sum(v[k], red);
             if (tid == 0) __hip_atomic_store(&part[(slot0 + k) * kCoopMaxG + wg], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -919,11 +939,11 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
         if (wg == 0 && tid == 0) a.iters[sys] = -3;
     };
 
-    double2 Ap[kCoopSlots];
+    double2 Ap[KS];
     if (!apply(xv, Ap)) return dead();
     double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int s = 0; s < kCoopSlots; ++s) {
+    for (int s = 0; s < KS; ++s) {
         if (ok[s]) {
             const double2 bv = a.b[base + tid + s * kLineThreads];
             rv[s] = make_double2(bv.x - Ap[s].x, bv.y - Ap[s].y);
@@ -941,14 +961,14 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
         if (!apply(pv, Ap)) return dead();
         acc[0] = 0.0;
 #pragma unroll
-        for (int s = 0; s < kCoopSlots; ++s) acc[0] += pv[s].x * Ap[s].x + pv[s].y * Ap[s].y;
+        for (int s = 0; s < KS; ++s) acc[0] += pv[s].x * Ap[s].x + pv[s].y * Ap[s].y;
         if (!all_sum(acc, 1, 2)) return dead();
         COOP_STAMP(5);
         const double alpha = rz / (acc[0] + kDivEps);
         acc[0] = acc[1] = 0.0;
-        double2 zv[kCoopSlots];
+        double2 zv[KS];
 #pragma unroll
-        for (int s = 0; s < kCoopSlots; ++s) {
+        for (int s = 0; s < KS; ++s) {
             xv[s].x += alpha * pv[s].x;
             xv[s].y += alpha * pv[s].y;
             rv[s].x -= alpha * Ap[s].x;
@@ -967,14 +987,15 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
         if (!a.batched && conv) break;                            // cg.py:132
         const double beta = rzn / (rz + kDivEps);
 #pragma unroll
-        for (int s = 0; s < kCoopSlots; ++s) pv[s] = make_double2(zv[s].x + beta * pv[s].x, zv[s].y + beta * pv[s].y);
+        for (int s = 0; s < KS; ++s) pv[s] = make_double2(zv[s].x + beta * pv[s].x, zv[s].y + beta * pv[s].y);
         rz = rzn;
         if (conv) break;                                          // cg.py:229-241
     }
 #pragma unroll
-    for (int s = 0; s < kCoopSlots; ++s)
+    for (int s = 0; s < KS; ++s)
         if (ok[s]) a.x[base + tid + s * kLineThreads] = xv[s];
     if (wg == 0 && tid == 0) a.iters[sys] = it;
+#undef COOP_STAMP
 }
 
 // ==========================================================================================================
@@ -1452,6 +1473,8 @@ int efgp_toeplitz_apply(efgp_toeplitz_t* op, const void* x, int nbatch, void* y,
     return EFGP_OK;
 }
 
+static thread_local bool t_no_coop = false;    // set while the cooperative solve hands systems to the multi-launch path
+
 int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
                   const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop,
                   int batched_semantics, int* iters_out, int* row_iters_out, void* stream_) {
@@ -1497,25 +1520,41 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         return EFGP_OK;
     }
 
-    // 2-D grids of 128..512 per dimension, few systems: the whole solve in ONE cooperative launch (cg_coop2d_kernel)
-    if (op->lines_ok && std::getenv("EFGP_NO_CG_COOP") == nullptr && std::getenv("EFGP_NO_CG_LINES") == nullptr) {
+    // 2-D grids of 128..512 per dimension: the whole solve in cooperative launches (cg_coop2d_kernel).  Few systems: G = 32-64
+    // workgroups per system (latency); many systems (variance / trace probes): as few workgroups per system as the
+    // registers allow, G = 1 when the mode block has <= 2048 entries -- no grid barrier, one system per CU (throughput)
+    if (op->lines_ok && !t_no_coop && std::getenv("EFGP_NO_CG_COOP") == nullptr && std::getenv("EFGP_NO_CG_LINES") == nullptr) {
         const int F0 = (int)g.F[0], F1 = (int)g.F[1], n0 = (int)g.n[0], n1 = (int)g.n[1];
-        const int lpbc = F1 >= 256 ? 8 : 4;
-        const int G = F1 / lpbc;
-        const int lines = (n0 + G - 1) / G;
-        const size_t bufsz = (size_t)std::max(lines * (F1 + 1), lpbc * (F0 + 1));
-        const size_t lds = (2 * bufsz + (size_t)F1 + (F0 == F1 ? 0 : (size_t)F0)) * sizeof(double2);
-        if (G <= kCoopMaxG && (int64_t)G * nbatch <= ctx->num_cu && lines * n1 <= kCoopSlots * kLineThreads &&
-            lpbc * F0 <= kCoopLoads * kLineThreads && lines * F1 <= kCoopLoads * kLineThreads &&
-            lds + 2048 <= (size_t)ctx->max_lds) {
-            const size_t grid_elems = (size_t)nbatch * (size_t)n0 * (size_t)F1;
+        // workgroups per system: as many as the latency shape uses (32 / 32 / 64) while the whole batch stays resident (one
+        // workgroup per CU), never fewer than the registers need (8 vector entries per thread)
+        const int G_lat = F1 / (F1 >= 256 ? 8 : 4);
+        int G_min = 1;
+        while (G_min < G_lat && ((n0 + G_min - 1) / G_min) * n1 > 8 * kLineThreads) G_min <<= 1;
+        int G = G_lat;
+        while (G > G_min && (int64_t)G * nbatch > ctx->num_cu) G >>= 1;
+        const int ks = ((n0 + G - 1) / G) * n1 <= 4 * kLineThreads ? 4 : 8;
+        const int lpbc = std::min(8, F1 / G);
+        bool shape_ok = G <= kCoopMaxG && ((n0 + G - 1) / G) * n1 <= ks * kLineThreads && F1 % (G * lpbc) == 0;
+        const int rows_wg = (n0 + G - 1) / G, cols_wg = F1 / G;
+        int lines = std::min(rows_wg, kCoopLoads * kLineThreads / F1);
+        auto lds_for = [&](int ln) {
+            const size_t bufsz = (size_t)std::max(ln * (F1 + 1), lpbc * (F0 + 1));
+            return (2 * bufsz + (size_t)F1 + (F0 == F1 ? 0 : (size_t)F0)) * sizeof(double2);
+        };
+        while (lines > 1 && lds_for(lines) + 2048 > (size_t)ctx->max_lds) --lines;
+        const size_t lds = lds_for(lines);
+        shape_ok = shape_ok && lpbc * F0 <= kCoopLoads * kLineThreads && lds + 2048 <= (size_t)ctx->max_lds && G <= ctx->num_cu;
+        if (shape_ok) {
+            const int cap = std::max(1, ctx->num_cu / G);                      // systems resident at once (one workgroup per CU)
+            const int per = std::min(cap, nbatch);
+            const size_t grid_elems = (size_t)per * (size_t)n0 * (size_t)F1;
             double2* pad = (double2*)scratch(ctx, SLOT_TOEP_PAD, 2 * grid_elems * sizeof(double2));
-            // partial sums | arrival counters (64 B apart) | iteration counts | status
-            const size_t off_bar = (size_t)nbatch * 3 * kCoopMaxG * sizeof(double);
-            const size_t off_iters = off_bar + (size_t)nbatch * 64;
-            const size_t off_status = off_iters + (((size_t)nbatch * sizeof(int) + 63) & ~size_t(63));
-            char* scb = (char*)scratch(ctx, SLOT_CG_SCALARS, off_status + 64);
-            int* host = pinned_host(ctx, off_status - off_iters + 64);
+            // partial sums | arrival counters (64 B apart) | status | iteration counts of ALL systems
+            const size_t off_bar = (size_t)per * 3 * kCoopMaxG * sizeof(double);
+            const size_t off_status = off_bar + (size_t)per * 64;
+            const size_t off_iters = off_status + 64;
+            char* scb = (char*)scratch(ctx, SLOT_CG_SCALARS, off_iters + (size_t)nbatch * sizeof(int) + 64);
+            int* host = pinned_host(ctx, (size_t)nbatch * sizeof(int) + 128);
             if (!pad || !scb || !host) return EFGP_ENOMEM;
             CoopArgs ca;
             ca.g = g;
@@ -1527,8 +1566,6 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
             ca.early_stop = early_stop;
             ca.batched = batched_semantics;
             ca.max_iter = max_iter;
-            ca.b = (const double2*)b;
-            ca.x = (double2*)x;
             ca.vhat = op->vhat;
             ca.tw0 = op->tw[0];
             ca.tw1 = op->tw[1];
@@ -1536,46 +1573,85 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
             ca.b2 = pad + grid_elems;
             ca.partial = (double*)scb;
             ca.bar = (unsigned*)(scb + off_bar);
-            ca.iters = (int*)(scb + off_iters);
             ca.status = (int*)(scb + off_status);
-            ca.hist = cg_history().buf;
             ca.hist_cap = cg_history().capacity;
             ca.G = G;
+            ca.rows_wg = rows_wg;
+            ca.cols_wg = cols_wg;
             ca.lines = lines;
             ca.lpbc = lpbc;
             ca.dbg = std::getenv("EFGP_COOP_DBG") ? std::atoi(std::getenv("EFGP_COOP_DBG")) : 0;
             ca.stamps = (double*)scratch(ctx, SLOT_MISC, 128);
             if (ca.dbg == 2) EFGP_HIP_CHECK(hipMemsetAsync(ca.stamps, 0, 128, stream));
-            EFGP_HIP_CHECK(hipMemsetAsync(scb + off_bar, 0, off_status + 64 - off_bar, stream));
-            EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg_coop2d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            EFGP_HIP_CHECK(hipMemsetAsync(scb + off_status, 0, 64, stream));
+            auto launch = [&](auto kern, int nsys) -> hipError_t {
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, dim3(G, nsys), dim3(kLineThreads), lds, stream, ca);
+                return hipGetLastError();
+            };
             {
                 KernelTimer timer("cg_coop", stream);
-                hipLaunchKernelGGL(cg_coop2d_kernel, dim3(G, nbatch), dim3(kLineThreads), lds, stream, ca);
+                for (int s0 = 0; s0 < nbatch; s0 += per) {
+                    const int nsys = std::min(per, nbatch - s0);
+                    ca.b = (const double2*)b + (int64_t)s0 * g.M;
+                    ca.x = (double2*)x + (int64_t)s0 * g.M;
+                    ca.iters = (int*)(scb + off_iters) + s0;
+                    ca.hist = s0 == 0 ? cg_history().buf : nullptr;
+                    EFGP_HIP_CHECK(hipMemsetAsync(scb + off_bar, 0, (size_t)per * 64, stream));
+                    hipError_t e;
+                    if (G == 1 && ks == 8) e = launch(cg_coop2d_kernel<8, true>, nsys);
+                    else if (G == 1) e = launch(cg_coop2d_kernel<4, true>, nsys);
+                    else if (ks == 8) e = launch(cg_coop2d_kernel<8, false>, nsys);
+                    else e = launch(cg_coop2d_kernel<4, false>, nsys);
+                    EFGP_HIP_CHECK(e);
+                }
             }
-            EFGP_HIP_CHECK(hipGetLastError());
-            EFGP_HIP_CHECK(hipMemcpyAsync(host, ca.iters, off_status + sizeof(int) - off_iters, hipMemcpyDeviceToHost, stream));
+            EFGP_HIP_CHECK(hipMemcpyAsync(host, scb + off_status, 64 + (size_t)nbatch * sizeof(int), hipMemcpyDeviceToHost, stream));
             EFGP_HIP_CHECK(stream_wait(stream));
-            const int dead = host[(off_status - off_iters) / sizeof(int)];
+            const int dead = host[0];
+            const int* hit = host + 16;
             if (ca.dbg == 2) {
-                double hs[12];
+                double hs[8];
                 EFGP_HIP_CHECK(hipMemcpy(hs, ca.stamps, sizeof(hs), hipMemcpyDeviceToHost));
-                const char* nm[12] = {"R compute+store", "barrier 1", "C store", "barrier 2", "Ri load+fft", "pAp sum (incl. barrier)", "update", "rr/rz sum (incl. barrier)",
-                                      "C load", "C fft 1", "C multiply", "C fft 2"};
+                const char* nm[8] = {"R compute+store", "barrier 1", "C load+fft+store", "barrier 2", "Ri load+fft", "pAp sum (incl. barrier)", "update", "rr/rz sum (incl. barrier)"};
                 double tot = 0;
-                for (int q = 0; q < 12; ++q) tot += hs[q];
-                for (int q = 0; q < 12; ++q) std::fprintf(stderr, "[coop] %-28s %9.0f cycles/iter %5.1f%%\n", nm[q], hs[q] / std::max(1, host[0]), 100.0 * hs[q] / tot);
+                for (int q = 0; q < 8; ++q) tot += hs[q];
+                std::fprintf(stderr, "[coop] G = %d, rows/wg %d, lines/pass %d, columns/wg %d, systems/launch %d\n", G, rows_wg, lines, cols_wg, per);
+                for (int q = 0; q < 8; ++q) std::fprintf(stderr, "[coop] %-28s %9.0f cycles/iter %5.1f%%\n", nm[q], hs[q] / std::max(1, hit[0]), 100.0 * hs[q] / tot);
             }
-            if (!dead) {
+            bool any_dead = dead != 0;
+            for (int i = 0; i < nbatch; ++i) any_dead = any_dead || hit[i] < 0;
+            if (!any_dead) {
                 int mx = 0;
                 for (int i = 0; i < nbatch; ++i) {
-                    mx = std::max(mx, host[i]);
-                    if (row_iters_out) row_iters_out[i] = host[i];
+                    mx = std::max(mx, hit[i]);
+                    if (row_iters_out) row_iters_out[i] = hit[i];
                 }
                 if (iters_out) *iters_out = (batched_semantics && mx < max_iter) ? mx + 1 : mx;
                 return EFGP_OK;
             }
-            // a grid barrier ran out of polls (the workgroups were not co-resident): x still holds x0; take the multi-launch path
+            // a grid barrier ran out of polls (the workgroups were not co-resident): the systems it hit still hold x0 in x (a
+            // solution is written only by a system that finished) and go through the multi-launch path one by one
             std::fprintf(stderr, "[efgp_hip] cooperative CG: grid barrier timed out, falling back to the multi-launch iteration\n");
+            int mx = 0;
+            std::vector<int> its(hit, hit + nbatch);
+            for (int i = 0; i < nbatch; ++i) {
+                if (its[i] < 0) {
+                    int one = 0;
+                    t_no_coop = true;
+                    const int rc1 = efgp_cg_solve(op, ws, sigmasq, variant, precond_diag, (const double2*)b + (int64_t)i * g.M,
+                                                  (double2*)x + (int64_t)i * g.M, 1, tol, max_iter, early_stop, batched_semantics, nullptr, &one,
+                                                  stream_);
+                    t_no_coop = false;
+                    if (rc1 != EFGP_OK) return rc1;
+                    its[i] = one;
+                }
+                mx = std::max(mx, its[i]);
+                if (row_iters_out) row_iters_out[i] = its[i];
+            }
+            if (iters_out) *iters_out = (batched_semantics && mx < max_iter) ? mx + 1 : mx;
+            return EFGP_OK;
         }
     }
 
