@@ -490,6 +490,135 @@ __device__ __forceinline__ double2* line_fft(double2* A, double2* B, int F, int 
     return x;
 }
 
+// ---- in-wave line transform (lengths 128, 256, 512) ---------------------------------------------------------------------
+// A line of F = 64 R points (R = 2, 4, 8) is transformed by 8 R lanes of ONE wave, 8 points per lane, as R interleaved
+// 64-point transforms (x[R m + r], r < R: radix 8 x 8 inside 8 adjacent lanes, as in cg_persistent.hip) followed by one
+// radix-R combine over r:   X[k1 + 64 k2] = sum_r w_F^(r k1) w_R^(r k2) Y_r[k1].
+// Three LDS exchanges, each written and read by the line's own lanes (wave fences, no workgroup barrier), all with
+// conflict-free patterns: exchange 1 (inside the 64-point transforms) XOR-swizzled in the destination line, exchange 2
+// in [r][k1] order in the source line (its contents are in registers by then), the result in natural order in the
+// destination line.  ~230 fp64 instructions and 48 LDS accesses per lane for 8 points, no index arithmetic in loops.
+// The generic Stockham stages above cost 1.5-2.5 k cycles per work item (measured in the cooperative solve).
+__device__ __forceinline__ void dft8_inplace(double2 (&v)[8]) {
+    const double2 e0 = make_double2(v[0].x + v[4].x, v[0].y + v[4].y), e1 = make_double2(v[0].x - v[4].x, v[0].y - v[4].y);
+    const double2 e2 = make_double2(v[2].x + v[6].x, v[2].y + v[6].y), e3 = make_double2(v[2].y - v[6].y, v[6].x - v[2].x);
+    const double2 E0 = make_double2(e0.x + e2.x, e0.y + e2.y), E1 = make_double2(e1.x + e3.x, e1.y + e3.y);
+    const double2 E2 = make_double2(e0.x - e2.x, e0.y - e2.y), E3 = make_double2(e1.x - e3.x, e1.y - e3.y);
+    const double2 o0 = make_double2(v[1].x + v[5].x, v[1].y + v[5].y), o1 = make_double2(v[1].x - v[5].x, v[1].y - v[5].y);
+    const double2 o2 = make_double2(v[3].x + v[7].x, v[3].y + v[7].y), o3 = make_double2(v[3].y - v[7].y, v[7].x - v[3].x);
+    const double2 O0 = make_double2(o0.x + o2.x, o0.y + o2.y), O1r = make_double2(o1.x + o3.x, o1.y + o3.y);
+    const double2 O2r = make_double2(o0.x - o2.x, o0.y - o2.y), O3r = make_double2(o1.x - o3.x, o1.y - o3.y);
+    const double hh = 0.70710678118654752440;
+    const double2 O1 = make_double2(hh * (O1r.x + O1r.y), hh * (O1r.y - O1r.x));
+    const double2 O2 = make_double2(O2r.y, -O2r.x);
+    const double2 O3 = make_double2(hh * (O3r.y - O3r.x), -hh * (O3r.x + O3r.y));
+    v[0] = make_double2(E0.x + O0.x, E0.y + O0.y);
+    v[1] = make_double2(E1.x + O1.x, E1.y + O1.y);
+    v[2] = make_double2(E2.x + O2.x, E2.y + O2.y);
+    v[3] = make_double2(E3.x + O3.x, E3.y + O3.y);
+    v[4] = make_double2(E0.x - O0.x, E0.y - O0.y);
+    v[5] = make_double2(E1.x - O1.x, E1.y - O1.y);
+    v[6] = make_double2(E2.x - O2.x, E2.y - O2.y);
+    v[7] = make_double2(E3.x - O3.x, E3.y - O3.y);
+}
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// forward transform of nl lines (line l at src + l * ld, natural order) into dst + l * ld (natural order); src is destroyed.
+// tw = exp(-2 pi i q / F), q < F, in LDS.  Ends with a workgroup barrier.
+template <int R>
+__device__ __forceinline__ void line_fft_inwave(double2* src, double2* dst, int ld, int nl, const double2* tw) {
+    constexpr int LPL = 8 * R, LINES = kLineThreads / LPL, U = R > 1 ? 8 / R : 1;
+    const int li = threadIdx.x & (LPL - 1), lsub = threadIdx.x / LPL;
+    const int r = li >> 3, j = li & 7;
+    for (int l0 = 0; l0 < nl; l0 += LINES) {
+        const bool act = l0 + lsub < nl;
+        double2* s = src + (act ? l0 + lsub : l0) * ld;
+        double2* d = dst + (act ? l0 + lsub : l0) * ld;
+        double2 v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = s[R * (j + 8 * t) + r];
+        dft8_inplace(v);
+        wave_sync_lds();
+        if (act) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) d[r * 64 + 8 * j + (m ^ j)] = v[m];
+        }
+        wave_sync_lds();
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = d[r * 64 + 8 * t + (j ^ t)];
+#pragma unroll
+        for (int t = 1; t < 8; ++t) v[t] = cmul(v[t], tw[R * j * t]);            // w_64^(j t)
+        dft8_inplace(v);                                                        // v[t] = Y_r[j + 8 t]
+        if (R == 1) {                                                           // a plain 64-point line: done
+            wave_sync_lds();
+            if (act) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) d[j + 8 * t] = v[t];
+            }
+            continue;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = cmul(v[t], tw[r * (j + 8 * t)]);      // w_F^(r k1)
+        wave_sync_lds();
+        if (act) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) s[r * 64 + j + 8 * t] = v[t];
+        }
+        wave_sync_lds();
+        // combine over r: lane li takes k1 = li + LPL u, u < 8 / R
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < R; ++q) v[u * R + q] = s[q * 64 + li + LPL * u];
+        if (R == 8) {
+            dft8_inplace(v);
+        } else if (R == 4) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const double2 a0 = v[4 * u], a1 = v[4 * u + 1], a2 = v[4 * u + 2], a3 = v[4 * u + 3];
+                const double2 t0 = make_double2(a0.x + a2.x, a0.y + a2.y), t1 = make_double2(a0.x - a2.x, a0.y - a2.y);
+                const double2 t2 = make_double2(a1.x + a3.x, a1.y + a3.y), t3 = make_double2(a1.y - a3.y, a3.x - a1.x);
+                v[4 * u] = make_double2(t0.x + t2.x, t0.y + t2.y);
+                v[4 * u + 1] = make_double2(t1.x + t3.x, t1.y + t3.y);
+                v[4 * u + 2] = make_double2(t0.x - t2.x, t0.y - t2.y);
+                v[4 * u + 3] = make_double2(t1.x - t3.x, t1.y - t3.y);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double2 a0 = v[2 * u], a1 = v[2 * u + 1];
+                v[2 * u] = make_double2(a0.x + a1.x, a0.y + a1.y);
+                v[2 * u + 1] = make_double2(a0.x - a1.x, a0.y - a1.y);
+            }
+        }
+        wave_sync_lds();
+        if (act) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int q = 0; q < R; ++q) d[li + LPL * u + 64 * q] = v[u * R + q];
+        }
+    }
+    __syncthreads();
+}
+
+// result buffer is always `dst`
+__device__ __forceinline__ double2* line_fft_fast(double2* src, double2* dst, int F, int ld, int nl, const double2* tw) {
+    if (F == 64) line_fft_inwave<1>(src, dst, ld, nl, tw);
+    else if (F == 128) line_fft_inwave<2>(src, dst, ld, nl, tw);
+    else if (F == 256) line_fft_inwave<4>(src, dst, ld, nl, tw);
+    else line_fft_inwave<8>(src, dst, ld, nl, tw);
+    return dst;
+}
+// in-wave transform for the lengths it covers, the generic Stockham stages otherwise; the result buffer is returned
+__device__ __forceinline__ double2* line_fft_any(double2* A, double2* B, int F, int ld, int nl, const double2* tw) {
+    if (F == 64 || F == 128 || F == 256 || F == 512) return line_fft_fast(A, B, F, ld, nl, tw);
+    return line_fft(A, B, F, ld, nl, tw);
+}
+
 // cooperative copy of a twiddle table into LDS (visible after the caller's next barrier)
 __device__ __forceinline__ void load_twiddles(double2* dst, const double2* __restrict__ src, int F) {
     for (int i = threadIdx.x; i < F; i += kLineThreads) dst[i] = src[i];
@@ -542,7 +671,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_rows_fwd_kernel(LineArgs a) {
         A[l * ld + i1] = v;
     }
     __syncthreads();
-    const double2* X = line_fft(A, B, F1, ld, nl, tws);
+    const double2* X = line_fft_any(A, B, F1, ld, nl, tws);
     double2* out = a.b1 + ((int64_t)slot * n0 + r0) * F1;
     for (int w = threadIdx.x; w < nl * F1; w += kLineThreads) {
         const int l = w / F1, i1 = w - l * F1;
@@ -570,7 +699,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_cols_mid_kernel(LineArgs a) {
         A[l * ld + i0] = i0 < n0 ? in[(int64_t)i0 * F1 + c0 + l] : make_double2(0.0, 0.0);
     }
     __syncthreads();
-    double2* X = line_fft(A, B, F0, ld, a.lpb, tws);
+    double2* X = line_fft_any(A, B, F0, ld, a.lpb, tws);
     double2* Y = X == A ? B : A;
     // .* vhat, conjugate: the inverse transform is conj(FFT(conj(.)))
     for (int w = threadIdx.x; w < a.lpb * F0; w += kLineThreads) {
@@ -579,7 +708,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_cols_mid_kernel(LineArgs a) {
         X[l * ld + i0] = make_double2(m.x, -m.y);
     }
     __syncthreads();
-    const double2* Z = line_fft(X, Y, F0, ld, a.lpb, tws);
+    const double2* Z = line_fft_any(X, Y, F0, ld, a.lpb, tws);
     double2* out = a.b2 + (int64_t)slot * n0 * F1;
     for (int w = threadIdx.x; w < a.lpb * n0; w += kLineThreads) {
         const int j = w / a.lpb, l = w - j * a.lpb;
@@ -611,7 +740,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_rows_inv_kernel(LineArgs a) {
         A[l * ld + i1] = make_double2(v.x, -v.y);
     }
     __syncthreads();
-    const double2* X = line_fft(A, B, F1, ld, nl, tws);
+    const double2* X = line_fft_any(A, B, F1, ld, nl, tws);
     const int64_t base = (int64_t)row * c.g.M;
     double pAp = 0.0;
     for (int w = threadIdx.x; w < nl * n1; w += kLineThreads) {
@@ -833,7 +962,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
             for (int s = 0; s < KS; ++s)
                 if (ok[s] && lrow[s] >= p0 && lrow[s] < p0 + nl) A[(lrow[s] - p0) * ldr + lcol[s]] = cmul(u[s], wsv[s]);
             __syncthreads();
-            const double2* X = line_fft(A, B, F1, ldr, nl, tw1s);
+            const double2* X = line_fft_fast(A, B, F1, ldr, nl, tw1s);
             for (int w = tid; w < (nl << lgF1); w += kLineThreads) {
                 const int l = w >> lgF1, i1 = w & (F1 - 1);
                 store_x2<SOLO>(b1 + (int64_t)(r0 + p0 + l) * F1 + i1, X[l * ldr + i1]);
@@ -858,7 +987,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
                 if (w < (F0 << lgC)) A[(w & (a.lpbc - 1)) * ldc + (w >> lgC)] = tmp[q];
             }
             __syncthreads();
-            double2* X = line_fft(A, B, F0, ldc, a.lpbc, tw0s);
+            double2* X = line_fft_fast(A, B, F0, ldc, a.lpbc, tw0s);
             double2* Y = X == A ? B : A;
             for (int w = tid; w < (F0 << lgC); w += kLineThreads) {
                 const int i0 = w >> lgC, l = w & (a.lpbc - 1);
@@ -866,7 +995,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
                 X[l * ldc + i0] = make_double2(m.x, -m.y);
             }
             __syncthreads();
-            const double2* Z = line_fft(X, Y, F0, ldc, a.lpbc, tw0s);
+            const double2* Z = line_fft_fast(X, Y, F0, ldc, a.lpbc, tw0s);
             for (int w = tid; w < (n0 << lgC); w += kLineThreads) {
                 const int j = w >> lgC, l = w & (a.lpbc - 1);
                 const double2 z = Z[l * ldc + (n0 - 1) + j];
@@ -894,7 +1023,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
                 if (w < (nl << lgF1)) A[(w >> lgF1) * ldr + (w & (F1 - 1))] = make_double2(tmp[q].x, -tmp[q].y);
             }
             __syncthreads();
-            const double2* X = line_fft(A, B, F1, ldr, nl, tw1s);
+            const double2* X = line_fft_fast(A, B, F1, ldr, nl, tw1s);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 if (ok[s] && lrow[s] >= p0 && lrow[s] < p0 + nl) {
@@ -1057,7 +1186,7 @@ __global__ __launch_bounds__(kLineThreads) void cg3_fwd2_kernel(Line3Args a) {
         A[l * ld + i2] = v;
     }
     __syncthreads();
-    const double2* X = line_fft(A, B, F2, ld, nl, tws);
+    const double2* X = line_fft_any(A, B, F2, ld, nl, tws);
     double2* out = a.b1 + ((int64_t)slot * nlines + l0) * F2;
     for (int w = threadIdx.x; w < nl * F2; w += kLineThreads) {
         const int l = w / F2, i2 = w - l * F2;
@@ -1097,7 +1226,7 @@ __global__ __launch_bounds__(kLineThreads) void cg3_dim1_kernel(Line3Args a) {
         }
     }
     __syncthreads();
-    const double2* X = line_fft(A, B, F1, ld, L, tws);
+    const double2* X = line_fft_any(A, B, F1, ld, L, tws);
     if (MODE == 0) {
         for (int w = threadIdx.x; w < L * F1; w += kLineThreads) {
             const int t1 = w / L, l = w - t1 * L;
@@ -1134,7 +1263,7 @@ __global__ __launch_bounds__(kLineThreads) void cg3_mid0_kernel(Line3Args a) {
         A[l * ld + i0] = i0 < n0 ? b2[((int64_t)i0 * F1 + t1) * F2 + c0 + l] : make_double2(0.0, 0.0);
     }
     __syncthreads();
-    double2* X = line_fft(A, B, F0, ld, L, tws);
+    double2* X = line_fft_any(A, B, F0, ld, L, tws);
     double2* Y = X == A ? B : A;
     for (int w = threadIdx.x; w < L * F0; w += kLineThreads) {
         const int t0 = w / L, l = w - t0 * L;
@@ -1142,7 +1271,7 @@ __global__ __launch_bounds__(kLineThreads) void cg3_mid0_kernel(Line3Args a) {
         X[l * ld + t0] = make_double2(m.x, -m.y);
     }
     __syncthreads();
-    const double2* Z = line_fft(X, Y, F0, ld, L, tws);
+    const double2* Z = line_fft_any(X, Y, F0, ld, L, tws);
     for (int w = threadIdx.x; w < L * n0; w += kLineThreads) {
         const int j0 = w / L, l = w - j0 * L;
         const double2 z = Z[l * ld + (n0 - 1) + j0];
@@ -1174,7 +1303,7 @@ __global__ __launch_bounds__(kLineThreads) void cg3_inv2_kernel(Line3Args a) {
         A[l * ld + i2] = make_double2(v.x, -v.y);
     }
     __syncthreads();
-    const double2* X = line_fft(A, B, F2, ld, nl, tws);
+    const double2* X = line_fft_any(A, B, F2, ld, nl, tws);
     const int64_t base = (int64_t)row * c.g.M;
     double pAp = 0.0;
     for (int w = threadIdx.x; w < nl * n2; w += kLineThreads) {
@@ -1533,7 +1662,11 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         int G = G_lat;
         while (G > G_min && (int64_t)G * nbatch > ctx->num_cu) G >>= 1;
         const int ks = ((n0 + G - 1) / G) * n1 <= 4 * kLineThreads ? 4 : 8;
-        const int lpbc = std::min(8, F1 / G);
+        // columns per LDS pass: as many as the workgroup owns, the per-thread load registers (16) and the LDS allow -- a pass of
+        // 8 columns leaves one work item per thread and stage (latency bound: 134 us per iteration of a 128^2 system on one CU
+        // with 8, 4 items with 32)
+        int lpbc = std::min(F1 / G, kCoopLoads * kLineThreads / F0);
+        while (lpbc > 4 && ((size_t)4 * lpbc * (F0 + 1) + (size_t)F0 + (size_t)F1) * sizeof(double2) + 2048 > (size_t)ctx->max_lds) lpbc >>= 1;
         bool shape_ok = G <= kCoopMaxG && ((n0 + G - 1) / G) * n1 <= ks * kLineThreads && F1 % (G * lpbc) == 0;
         const int rows_wg = (n0 + G - 1) / G, cols_wg = F1 / G;
         int lines = std::min(rows_wg, kCoopLoads * kLineThreads / F1);
