@@ -987,15 +987,22 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
                 if (w < (F0 << lgC)) A[(w & (a.lpbc - 1)) * ldc + (w >> lgC)] = tmp[q];
             }
             __syncthreads();
+            COOP_STAMP(8);
             double2* X = line_fft_fast(A, B, F0, ldc, a.lpbc, tw0s);
+            COOP_STAMP(9);
             double2* Y = X == A ? B : A;
+            // (requesting the pass's spectrum entries together instead of one load per iteration behind an LDS store removes 8 k of
+            // the 10.8 k cycles this loop costs per 32-column pass, but the extra live registers slow every other phase of the
+            // kernel by more: measured 85 -> 97 us per iteration of 200 systems, 24 -> 26 us for one; kept simple)
             for (int w = tid; w < (F0 << lgC); w += kLineThreads) {
                 const int i0 = w >> lgC, l = w & (a.lpbc - 1);
                 const double2 m = cmul(X[l * ldc + i0], a.vhat[(int64_t)i0 * F1 + c0 + l]);
                 X[l * ldc + i0] = make_double2(m.x, -m.y);
             }
             __syncthreads();
+            COOP_STAMP(10);
             const double2* Z = line_fft_fast(X, Y, F0, ldc, a.lpbc, tw0s);
+            COOP_STAMP(11);
             for (int w = tid; w < (n0 << lgC); w += kLineThreads) {
                 const int j = w >> lgC, l = w & (a.lpbc - 1);
                 const double2 z = Z[l * ldc + (n0 - 1) + j];
@@ -1745,13 +1752,14 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
             const int dead = host[0];
             const int* hit = host + 16;
             if (ca.dbg == 2) {
-                double hs[8];
+                double hs[12];
                 EFGP_HIP_CHECK(hipMemcpy(hs, ca.stamps, sizeof(hs), hipMemcpyDeviceToHost));
-                const char* nm[8] = {"R compute+store", "barrier 1", "C load+fft+store", "barrier 2", "Ri load+fft", "pAp sum (incl. barrier)", "update", "rr/rz sum (incl. barrier)"};
+                const char* nm[12] = {"R compute+store", "barrier 1", "C store", "barrier 2", "Ri load+fft", "pAp sum (incl. barrier)", "update", "rr/rz sum (incl. barrier)",
+                                      "C load", "C transform 1", "C multiply", "C transform 2"};
                 double tot = 0;
-                for (int q = 0; q < 8; ++q) tot += hs[q];
+                for (int q = 0; q < 12; ++q) tot += hs[q];
                 std::fprintf(stderr, "[coop] G = %d, rows/wg %d, lines/pass %d, columns/wg %d, systems/launch %d\n", G, rows_wg, lines, cols_wg, per);
-                for (int q = 0; q < 8; ++q) std::fprintf(stderr, "[coop] %-28s %9.0f cycles/iter %5.1f%%\n", nm[q], hs[q] / std::max(1, hit[0]), 100.0 * hs[q] / tot);
+                for (int q = 0; q < 12; ++q) std::fprintf(stderr, "[coop] %-28s %9.0f cycles/iter %5.1f%%\n", nm[q], hs[q] / std::max(1, hit[0]), 100.0 * hs[q] / tot);
             }
             bool any_dead = dead != 0;
             for (int i = 0; i < nbatch; ++i) any_dead = any_dead || hit[i] < 0;
