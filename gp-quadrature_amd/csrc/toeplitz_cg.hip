@@ -528,8 +528,11 @@ __device__ __forceinline__ void wave_sync_lds() {
 
 // forward transform of nl lines (line l at src + l * ld, natural order) into dst + l * ld (natural order); src is destroyed.
 // tw = exp(-2 pi i q / F), q < F, in LDS.  Ends with a workgroup barrier.
-template <int R>
-__device__ __forceinline__ void line_fft_inwave(double2* src, double2* dst, int ld, int nl, const double2* tw) {
+// MUL: the outputs are multiplied by mul[k * mul_stride + l] (entry k of line l) and conjugated on the way out -- the
+// spectrum multiply and the conjugation in front of the inverse transform, done on the registers that hold the result.
+template <int R, bool MUL = false>
+__device__ __forceinline__ void line_fft_inwave(double2* src, double2* dst, int ld, int nl, const double2* tw,
+                                                const double2* __restrict__ mul = nullptr, int64_t mul_stride = 0) {
     constexpr int LPL = 8 * R, LINES = kLineThreads / LPL, U = R > 1 ? 8 / R : 1;
     const int li = threadIdx.x & (LPL - 1), lsub = threadIdx.x / LPL;
     const int r = li >> 3, j = li & 7;
@@ -553,6 +556,17 @@ __device__ __forceinline__ void line_fft_inwave(double2* src, double2* dst, int 
         for (int t = 1; t < 8; ++t) v[t] = cmul(v[t], tw[R * j * t]);            // w_64^(j t)
         dft8_inplace(v);                                                        // v[t] = Y_r[j + 8 t]
         if (R == 1) {                                                           // a plain 64-point line: done
+            if (MUL) {
+                double2 mv[8];
+                const int lq = act ? l0 + lsub : l0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) mv[t] = mul[(int64_t)(j + 8 * t) * mul_stride + lq];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const double2 m = cmul(v[t], mv[t]);
+                    v[t] = make_double2(m.x, -m.y);
+                }
+            }
             wave_sync_lds();
             if (act) {
 #pragma unroll
@@ -569,6 +583,14 @@ __device__ __forceinline__ void line_fft_inwave(double2* src, double2* dst, int 
         }
         wave_sync_lds();
         // combine over r: lane li takes k1 = li + LPL u, u < 8 / R
+        double2 mv[MUL ? 8 : 1];
+        if (MUL) {                                                              // requested now, used after the butterflies
+            const int lq = act ? l0 + lsub : l0;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int q = 0; q < R; ++q) mv[u * R + q] = mul[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq];
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -594,6 +616,13 @@ __device__ __forceinline__ void line_fft_inwave(double2* src, double2* dst, int 
                 v[2 * u + 1] = make_double2(a0.x - a1.x, a0.y - a1.y);
             }
         }
+        if (MUL) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const double2 m = cmul(v[i], mv[i]);
+                v[i] = make_double2(m.x, -m.y);
+            }
+        }
         wave_sync_lds();
         if (act) {
 #pragma unroll
@@ -605,12 +634,32 @@ __device__ __forceinline__ void line_fft_inwave(double2* src, double2* dst, int 
     __syncthreads();
 }
 
+// One out-of-line copy per (R, MUL) shared by every call site of a kernel: inlined four times per operator application the
+// unrolled transforms put the cooperative kernel's loop body beyond the instruction cache (its speed then moved by 10-40 %
+// with every unrelated code change).  Operands are passed as offsets into the kernel's dynamic LDS so that the accesses
+// stay LDS instructions.
+extern __shared__ double2 efgp_line_lds[];
+template <int R, bool MUL>
+__device__ __noinline__ void line_fft_inwave_call(int src_off, int dst_off, int ld, int nl, int tw_off, const double2* mul,
+                                                  int64_t mul_stride) {
+    line_fft_inwave<R, MUL>(efgp_line_lds + src_off, efgp_line_lds + dst_off, ld, nl, efgp_line_lds + tw_off, mul, mul_stride);
+}
 // result buffer is always `dst`
 __device__ __forceinline__ double2* line_fft_fast(double2* src, double2* dst, int F, int ld, int nl, const double2* tw) {
-    if (F == 64) line_fft_inwave<1>(src, dst, ld, nl, tw);
-    else if (F == 128) line_fft_inwave<2>(src, dst, ld, nl, tw);
-    else if (F == 256) line_fft_inwave<4>(src, dst, ld, nl, tw);
-    else line_fft_inwave<8>(src, dst, ld, nl, tw);
+    const int so = (int)(src - efgp_line_lds), dn = (int)(dst - efgp_line_lds), to = (int)(tw - efgp_line_lds);
+    if (F == 64) line_fft_inwave_call<1, false>(so, dn, ld, nl, to, nullptr, 0);
+    else if (F == 128) line_fft_inwave_call<2, false>(so, dn, ld, nl, to, nullptr, 0);
+    else if (F == 256) line_fft_inwave_call<4, false>(so, dn, ld, nl, to, nullptr, 0);
+    else line_fft_inwave_call<8, false>(so, dn, ld, nl, to, nullptr, 0);
+    return dst;
+}
+// forward transform, spectrum multiply (mul[k * mul_stride + l]) and conjugation in one pass (F = 128, 256, 512)
+__device__ __forceinline__ double2* line_fft_fast_mul(double2* src, double2* dst, int F, int ld, int nl, const double2* tw,
+                                                      const double2* mul, int64_t mul_stride) {
+    const int so = (int)(src - efgp_line_lds), dn = (int)(dst - efgp_line_lds), to = (int)(tw - efgp_line_lds);
+    if (F == 128) line_fft_inwave_call<2, true>(so, dn, ld, nl, to, mul, mul_stride);
+    else if (F == 256) line_fft_inwave_call<4, true>(so, dn, ld, nl, to, mul, mul_stride);
+    else line_fft_inwave_call<8, true>(so, dn, ld, nl, to, mul, mul_stride);
     return dst;
 }
 // in-wave transform for the lengths it covers, the generic Stockham stages otherwise; the result buffer is returned
@@ -988,18 +1037,10 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
             }
             __syncthreads();
             COOP_STAMP(8);
-            double2* X = line_fft_fast(A, B, F0, ldc, a.lpbc, tw0s);
-            COOP_STAMP(9);
+            // forward transform, .* vhat and the conjugation in front of the inverse transform on the result registers
+            double2* X = line_fft_fast_mul(A, B, F0, ldc, a.lpbc, tw0s, a.vhat + c0, F1);
             double2* Y = X == A ? B : A;
-            // (requesting the pass's spectrum entries together instead of one load per iteration behind an LDS store removes 8 k of
-            // the 10.8 k cycles this loop costs per 32-column pass, but the extra live registers slow every other phase of the
-            // kernel by more: measured 85 -> 97 us per iteration of 200 systems, 24 -> 26 us for one; kept simple)
-            for (int w = tid; w < (F0 << lgC); w += kLineThreads) {
-                const int i0 = w >> lgC, l = w & (a.lpbc - 1);
-                const double2 m = cmul(X[l * ldc + i0], a.vhat[(int64_t)i0 * F1 + c0 + l]);
-                X[l * ldc + i0] = make_double2(m.x, -m.y);
-            }
-            __syncthreads();
+            COOP_STAMP(9);
             COOP_STAMP(10);
             const double2* Z = line_fft_fast(X, Y, F0, ldc, a.lpbc, tw0s);
             COOP_STAMP(11);
