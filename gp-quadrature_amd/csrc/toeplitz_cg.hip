@@ -1112,6 +1112,8 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
         __syncthreads();                                          // fin is reused by the next sum
         return true;
     };
+    // a dead grid barrier: the row reports -3 iterations.  The synchronous entry retries such rows through the multi-launch
+    // path (x still holds x0); an asynchronous caller must look at the counts (efgp_hip.LazyIterations raises)
     auto dead = [&]() {
         if (wg == 0 && tid == 0) a.iters[sys] = -3;
     };
@@ -1650,6 +1652,120 @@ int efgp_toeplitz_apply(efgp_toeplitz_t* op, const void* x, int nbatch, void* y,
     return EFGP_OK;
 }
 
+// Enqueues the cooperative solve of `nbatch` systems on a 2-D 128^2..512^2 grid (cg_coop2d_kernel).  Few systems: G = 32-64
+// workgroups per system (latency); many systems (variance / trace probes): as few workgroups per system as the registers
+// allow, G = 1 when the mode block has <= 2048 entries -- no grid barrier, one system per CU (throughput).  Iteration counts
+// go to d_iters (device, nbatch ints; -3 where a grid barrier died), *d_status (device int) is non-zero when one did.
+// EFGP_EUNSUPPORTED when no launch shape fits.
+struct CoopInfo {
+    int* d_status = nullptr;
+    int G = 0, rows_wg = 0, lines = 0, cols_wg = 0, per = 0;
+    double* stamps = nullptr;
+    int dbg = 0;
+};
+static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int variant, const double* precond_diag, const void* b,
+                        void* x, int nbatch, double tol, int max_iter, int early_stop, int batched_semantics, int* d_iters,
+                        hipStream_t stream, CoopInfo* info) {
+    DeviceCtx* ctx = op->ctx;
+    const ToepGeom g = op->g;
+    const int F0 = (int)g.F[0], F1 = (int)g.F[1], n0 = (int)g.n[0], n1 = (int)g.n[1];
+    // workgroups per system: as many as the latency shape uses (32 / 32 / 64) while the whole batch stays resident (one
+    // workgroup per CU), never fewer than the registers need (8 vector entries per thread)
+    const int G_lat = F1 / (F1 >= 256 ? 8 : 4);
+    int G_min = 1;
+    while (G_min < G_lat && ((n0 + G_min - 1) / G_min) * n1 > 8 * kLineThreads) G_min <<= 1;
+    int G = G_lat;
+    while (G > G_min && (int64_t)G * nbatch > ctx->num_cu) G >>= 1;
+    const int ks = ((n0 + G - 1) / G) * n1 <= 4 * kLineThreads ? 4 : 8;
+    // columns per LDS pass: as many as the workgroup owns, the per-thread load registers (16) and the LDS allow -- a pass of
+    // 8 columns leaves one work item per thread and stage (latency bound: 134 us per iteration of a 128^2 system on one CU
+    // with 8, 4 items with 32)
+    int lpbc = std::min(F1 / G, kCoopLoads * kLineThreads / F0);
+    while (lpbc > 4 && ((size_t)4 * lpbc * (F0 + 1) + (size_t)F0 + (size_t)F1) * sizeof(double2) + 2048 > (size_t)ctx->max_lds) lpbc >>= 1;
+    bool shape_ok = G <= kCoopMaxG && ((n0 + G - 1) / G) * n1 <= ks * kLineThreads && F1 % (G * lpbc) == 0;
+    const int rows_wg = (n0 + G - 1) / G, cols_wg = F1 / G;
+    int lines = std::min(rows_wg, kCoopLoads * kLineThreads / F1);
+    auto lds_for = [&](int ln) {
+        const size_t bufsz = (size_t)std::max(ln * (F1 + 1), lpbc * (F0 + 1));
+        return (2 * bufsz + (size_t)F1 + (F0 == F1 ? 0 : (size_t)F0)) * sizeof(double2);
+    };
+    while (lines > 1 && lds_for(lines) + 2048 > (size_t)ctx->max_lds) --lines;
+    const size_t lds = lds_for(lines);
+    shape_ok = shape_ok && lpbc * F0 <= kCoopLoads * kLineThreads && lds + 2048 <= (size_t)ctx->max_lds && G <= ctx->num_cu;
+    if (!shape_ok) return EFGP_EUNSUPPORTED;
+    const int cap = std::max(1, ctx->num_cu / G);                      // systems resident at once (one workgroup per CU)
+    const int per = std::min(cap, nbatch);
+    const size_t grid_elems = (size_t)per * (size_t)n0 * (size_t)F1;
+    double2* pad = (double2*)scratch(ctx, SLOT_TOEP_PAD, 2 * grid_elems * sizeof(double2));
+    // partial sums | arrival counters (64 B apart) | status
+    const size_t off_bar = (size_t)per * 3 * kCoopMaxG * sizeof(double);
+    const size_t off_status = off_bar + (size_t)per * 64;
+    char* scb = (char*)scratch(ctx, SLOT_MISC, off_status + 64 + 128);
+    if (!pad || !scb) return EFGP_ENOMEM;
+    CoopArgs ca;
+    ca.g = g;
+    ca.ws = (const double2*)ws;
+    ca.diag = precond_diag;
+    ca.sigmasq = sigmasq;
+    ca.variant = variant;
+    ca.tol = tol;
+    ca.early_stop = early_stop;
+    ca.batched = batched_semantics;
+    ca.max_iter = max_iter;
+    ca.vhat = op->vhat;
+    ca.tw0 = op->tw[0];
+    ca.tw1 = op->tw[1];
+    ca.b1 = pad;
+    ca.b2 = pad + grid_elems;
+    ca.partial = (double*)scb;
+    ca.bar = (unsigned*)(scb + off_bar);
+    ca.status = (int*)(scb + off_status);
+    ca.hist_cap = cg_history().capacity;
+    ca.G = G;
+    ca.rows_wg = rows_wg;
+    ca.cols_wg = cols_wg;
+    ca.lines = lines;
+    ca.lpbc = lpbc;
+    ca.dbg = std::getenv("EFGP_COOP_DBG") ? std::atoi(std::getenv("EFGP_COOP_DBG")) : 0;
+    ca.stamps = (double*)(scb + off_status + 64);
+    if (ca.dbg == 2) EFGP_HIP_CHECK(hipMemsetAsync(ca.stamps, 0, 128, stream));
+    EFGP_HIP_CHECK(hipMemsetAsync(scb + off_status, 0, 64, stream));
+    auto launch = [&](auto kern, int nsys) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(G, nsys), dim3(kLineThreads), lds, stream, ca);
+        return hipGetLastError();
+    };
+    {
+        KernelTimer timer("cg_coop", stream);
+        for (int s0 = 0; s0 < nbatch; s0 += per) {
+            const int nsys = std::min(per, nbatch - s0);
+            ca.b = (const double2*)b + (int64_t)s0 * g.M;
+            ca.x = (double2*)x + (int64_t)s0 * g.M;
+            ca.iters = d_iters + s0;
+            ca.hist = s0 == 0 ? cg_history().buf : nullptr;
+            EFGP_HIP_CHECK(hipMemsetAsync(scb + off_bar, 0, (size_t)per * 64, stream));
+            hipError_t e;
+            if (G == 1 && ks == 8) e = launch(cg_coop2d_kernel<8, true>, nsys);
+            else if (G == 1) e = launch(cg_coop2d_kernel<4, true>, nsys);
+            else if (ks == 8) e = launch(cg_coop2d_kernel<8, false>, nsys);
+            else e = launch(cg_coop2d_kernel<4, false>, nsys);
+            EFGP_HIP_CHECK(e);
+        }
+    }
+    if (info) {
+        info->d_status = ca.status;
+        info->G = G;
+        info->rows_wg = rows_wg;
+        info->lines = lines;
+        info->cols_wg = cols_wg;
+        info->per = per;
+        info->stamps = ca.stamps;
+        info->dbg = ca.dbg;
+    }
+    return EFGP_OK;
+}
+
 static thread_local bool t_no_coop = false;    // set while the cooperative solve hands systems to the multi-launch path
 
 int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
@@ -1697,109 +1813,29 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         return EFGP_OK;
     }
 
-    // 2-D grids of 128..512 per dimension: the whole solve in cooperative launches (cg_coop2d_kernel).  Few systems: G = 32-64
-    // workgroups per system (latency); many systems (variance / trace probes): as few workgroups per system as the
-    // registers allow, G = 1 when the mode block has <= 2048 entries -- no grid barrier, one system per CU (throughput)
+    // 2-D grids of 128..512 per dimension: the whole solve in cooperative launches (coop_enqueue)
     if (op->lines_ok && !t_no_coop && std::getenv("EFGP_NO_CG_COOP") == nullptr && std::getenv("EFGP_NO_CG_LINES") == nullptr) {
-        const int F0 = (int)g.F[0], F1 = (int)g.F[1], n0 = (int)g.n[0], n1 = (int)g.n[1];
-        // workgroups per system: as many as the latency shape uses (32 / 32 / 64) while the whole batch stays resident (one
-        // workgroup per CU), never fewer than the registers need (8 vector entries per thread)
-        const int G_lat = F1 / (F1 >= 256 ? 8 : 4);
-        int G_min = 1;
-        while (G_min < G_lat && ((n0 + G_min - 1) / G_min) * n1 > 8 * kLineThreads) G_min <<= 1;
-        int G = G_lat;
-        while (G > G_min && (int64_t)G * nbatch > ctx->num_cu) G >>= 1;
-        const int ks = ((n0 + G - 1) / G) * n1 <= 4 * kLineThreads ? 4 : 8;
-        // columns per LDS pass: as many as the workgroup owns, the per-thread load registers (16) and the LDS allow -- a pass of
-        // 8 columns leaves one work item per thread and stage (latency bound: 134 us per iteration of a 128^2 system on one CU
-        // with 8, 4 items with 32)
-        int lpbc = std::min(F1 / G, kCoopLoads * kLineThreads / F0);
-        while (lpbc > 4 && ((size_t)4 * lpbc * (F0 + 1) + (size_t)F0 + (size_t)F1) * sizeof(double2) + 2048 > (size_t)ctx->max_lds) lpbc >>= 1;
-        bool shape_ok = G <= kCoopMaxG && ((n0 + G - 1) / G) * n1 <= ks * kLineThreads && F1 % (G * lpbc) == 0;
-        const int rows_wg = (n0 + G - 1) / G, cols_wg = F1 / G;
-        int lines = std::min(rows_wg, kCoopLoads * kLineThreads / F1);
-        auto lds_for = [&](int ln) {
-            const size_t bufsz = (size_t)std::max(ln * (F1 + 1), lpbc * (F0 + 1));
-            return (2 * bufsz + (size_t)F1 + (F0 == F1 ? 0 : (size_t)F0)) * sizeof(double2);
-        };
-        while (lines > 1 && lds_for(lines) + 2048 > (size_t)ctx->max_lds) --lines;
-        const size_t lds = lds_for(lines);
-        shape_ok = shape_ok && lpbc * F0 <= kCoopLoads * kLineThreads && lds + 2048 <= (size_t)ctx->max_lds && G <= ctx->num_cu;
-        if (shape_ok) {
-            const int cap = std::max(1, ctx->num_cu / G);                      // systems resident at once (one workgroup per CU)
-            const int per = std::min(cap, nbatch);
-            const size_t grid_elems = (size_t)per * (size_t)n0 * (size_t)F1;
-            double2* pad = (double2*)scratch(ctx, SLOT_TOEP_PAD, 2 * grid_elems * sizeof(double2));
-            // partial sums | arrival counters (64 B apart) | status | iteration counts of ALL systems
-            const size_t off_bar = (size_t)per * 3 * kCoopMaxG * sizeof(double);
-            const size_t off_status = off_bar + (size_t)per * 64;
-            const size_t off_iters = off_status + 64;
-            char* scb = (char*)scratch(ctx, SLOT_CG_SCALARS, off_iters + (size_t)nbatch * sizeof(int) + 64);
-            int* host = pinned_host(ctx, (size_t)nbatch * sizeof(int) + 128);
-            if (!pad || !scb || !host) return EFGP_ENOMEM;
-            CoopArgs ca;
-            ca.g = g;
-            ca.ws = (const double2*)ws;
-            ca.diag = precond_diag;
-            ca.sigmasq = sigmasq;
-            ca.variant = variant;
-            ca.tol = tol;
-            ca.early_stop = early_stop;
-            ca.batched = batched_semantics;
-            ca.max_iter = max_iter;
-            ca.vhat = op->vhat;
-            ca.tw0 = op->tw[0];
-            ca.tw1 = op->tw[1];
-            ca.b1 = pad;
-            ca.b2 = pad + grid_elems;
-            ca.partial = (double*)scb;
-            ca.bar = (unsigned*)(scb + off_bar);
-            ca.status = (int*)(scb + off_status);
-            ca.hist_cap = cg_history().capacity;
-            ca.G = G;
-            ca.rows_wg = rows_wg;
-            ca.cols_wg = cols_wg;
-            ca.lines = lines;
-            ca.lpbc = lpbc;
-            ca.dbg = std::getenv("EFGP_COOP_DBG") ? std::atoi(std::getenv("EFGP_COOP_DBG")) : 0;
-            ca.stamps = (double*)scratch(ctx, SLOT_MISC, 128);
-            if (ca.dbg == 2) EFGP_HIP_CHECK(hipMemsetAsync(ca.stamps, 0, 128, stream));
-            EFGP_HIP_CHECK(hipMemsetAsync(scb + off_status, 0, 64, stream));
-            auto launch = [&](auto kern, int nsys) -> hipError_t {
-                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(kern, dim3(G, nsys), dim3(kLineThreads), lds, stream, ca);
-                return hipGetLastError();
-            };
-            {
-                KernelTimer timer("cg_coop", stream);
-                for (int s0 = 0; s0 < nbatch; s0 += per) {
-                    const int nsys = std::min(per, nbatch - s0);
-                    ca.b = (const double2*)b + (int64_t)s0 * g.M;
-                    ca.x = (double2*)x + (int64_t)s0 * g.M;
-                    ca.iters = (int*)(scb + off_iters) + s0;
-                    ca.hist = s0 == 0 ? cg_history().buf : nullptr;
-                    EFGP_HIP_CHECK(hipMemsetAsync(scb + off_bar, 0, (size_t)per * 64, stream));
-                    hipError_t e;
-                    if (G == 1 && ks == 8) e = launch(cg_coop2d_kernel<8, true>, nsys);
-                    else if (G == 1) e = launch(cg_coop2d_kernel<4, true>, nsys);
-                    else if (ks == 8) e = launch(cg_coop2d_kernel<8, false>, nsys);
-                    else e = launch(cg_coop2d_kernel<4, false>, nsys);
-                    EFGP_HIP_CHECK(e);
-                }
-            }
-            EFGP_HIP_CHECK(hipMemcpyAsync(host, scb + off_status, 64 + (size_t)nbatch * sizeof(int), hipMemcpyDeviceToHost, stream));
+        int* d_iters = (int*)scratch(ctx, SLOT_CG_SCALARS, (size_t)nbatch * sizeof(int) + 64);
+        int* host = pinned_host(ctx, (size_t)nbatch * sizeof(int) + 128);
+        if (!d_iters || !host) return EFGP_ENOMEM;
+        CoopInfo ci;
+        const int rcq = coop_enqueue(op, ws, sigmasq, variant, precond_diag, b, x, nbatch, tol, max_iter, early_stop, batched_semantics,
+                                     d_iters, stream, &ci);
+        if (rcq != EFGP_OK && rcq != EFGP_EUNSUPPORTED) return rcq;
+        if (rcq == EFGP_OK) {
+            EFGP_HIP_CHECK(hipMemcpyAsync(host, ci.d_status, sizeof(int), hipMemcpyDeviceToHost, stream));
+            EFGP_HIP_CHECK(hipMemcpyAsync(host + 16, d_iters, (size_t)nbatch * sizeof(int), hipMemcpyDeviceToHost, stream));
             EFGP_HIP_CHECK(stream_wait(stream));
             const int dead = host[0];
             const int* hit = host + 16;
-            if (ca.dbg == 2) {
+            if (ci.dbg == 2) {
                 double hs[12];
-                EFGP_HIP_CHECK(hipMemcpy(hs, ca.stamps, sizeof(hs), hipMemcpyDeviceToHost));
+                EFGP_HIP_CHECK(hipMemcpy(hs, ci.stamps, sizeof(hs), hipMemcpyDeviceToHost));
                 const char* nm[12] = {"R compute+store", "barrier 1", "C store", "barrier 2", "Ri load+fft", "pAp sum (incl. barrier)", "update", "rr/rz sum (incl. barrier)",
-                                      "C load", "C transform 1", "C multiply", "C transform 2"};
+                                      "C load", "C transform 1 (+ multiply)", "-", "C transform 2"};
                 double tot = 0;
                 for (int q = 0; q < 12; ++q) tot += hs[q];
-                std::fprintf(stderr, "[coop] G = %d, rows/wg %d, lines/pass %d, columns/wg %d, systems/launch %d\n", G, rows_wg, lines, cols_wg, per);
+                std::fprintf(stderr, "[coop] G = %d, rows/wg %d, lines/pass %d, columns/wg %d, systems/launch %d\n", ci.G, ci.rows_wg, ci.lines, ci.cols_wg, ci.per);
                 for (int q = 0; q < 12; ++q) std::fprintf(stderr, "[coop] %-28s %9.0f cycles/iter %5.1f%%\n", nm[q], hs[q] / std::max(1, hit[0]), 100.0 * hs[q] / tot);
             }
             bool any_dead = dead != 0;
@@ -2146,6 +2182,15 @@ static int cg_solve_async_impl(efgp_toeplitz_t* op, const void* ws, double sigma
     EFGP_REQUIRE(batched_semantics || nbatch == 1, "efgp_cg_solve_async: single-system semantics need nbatch == 1");
     EFGP_REQUIRE(sigmasq > 0.0 || variant == 0, "efgp_cg_solve_async: sigmasq must be positive for A_var");
     if (!op->persistent_ok || std::getenv("EFGP_NO_PERSISTENT_CG") != nullptr) {
+        // 2-D 128^2..512^2: the cooperative launches need no host either (a row whose grid barrier died -- workgroups not
+        // co-resident -- reports -3 iterations and keeps x0; the synchronous entry retries those through the multi-launch path)
+        if (op->lines_ok && std::getenv("EFGP_NO_CG_COOP") == nullptr && std::getenv("EFGP_NO_CG_LINES") == nullptr) {
+            hipStream_t stream_c = (hipStream_t)stream_;
+            DeviceGuard guard_c(op->device);
+            if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * op->g.M, 2000000000);
+            return coop_enqueue(op, ws, sigmasq, variant, precond_diag, b, x, nbatch, tol, max_iter, early_stop, batched_semantics,
+                                row_iters_dev, stream_c, nullptr);
+        }
         set_error("efgp_cg_solve_async: grid does not fit the persistent kernel");
         return EFGP_EUNSUPPORTED;
     }

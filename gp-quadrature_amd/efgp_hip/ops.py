@@ -276,6 +276,10 @@ class LazyIterations:
     def rows(self):
         if self._rows is None:
             self._rows = [int(v) for v in self._rows_dev.tolist()]
+            if any(v == -3 for v in self._rows):
+                raise RuntimeError("efgp_hip: a cooperative CG launch could not get its workgroups resident together (another "
+                                   "kernel held the CUs); the affected systems were not solved -- call cg_solve (it retries "
+                                   "them through the multi-launch iteration) or set EFGP_NO_CG_COOP=1")
             if any(v == -2 for v in self._rows):
                 raise RuntimeError("efgp_hip: a system given to the Hermitian CG kernel is not the transform of real data "
                                    "(right-hand side not conjugate-even, or ws not real and even); its solution is NaN")

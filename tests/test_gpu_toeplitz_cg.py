@@ -286,3 +286,28 @@ def test_cooperative_solve_equals_multi_launch_iteration(mtot, nb, monkeypatch):
         assert torch.equal(out[0], first), rep   # bit-identical from launch to launch: fixed summation order, no race
     out1 = cg_solve(op, ws.cuda(), 0.5, 1, b[0].cuda(), x0[0].cuda(), 1e-9, batched=False)       # A_var, single-system rule, no diagonal
     assert out1[1] == ref1[1] and _rel(out1[0], ref1[0]) < 1e-12
+
+
+def test_async_solve_on_mid_size_grids():
+    """efgp_cg_solve_async on 128^2..512^2 grids enqueues the cooperative launches without any host synchronisation: same
+    solution and counts as the synchronous entry."""
+    from efgp_hip import ToeplitzOp, cg_solve, cg_solve_async
+    mtot = 57
+    g = torch.Generator().manual_seed(5)
+    L = 2 * mtot - 1
+    v = torch.complex(torch.randn(L, L, generator=g, dtype=torch.float64), torch.randn(L, L, generator=g, dtype=torch.float64))
+    v = (v + v.flip(0, 1).conj()) / 2
+    v[mtot - 1, mtot - 1] = 3.0 * L
+    M = mtot * mtot
+    ws = torch.exp(-2.0 * torch.rand(M, generator=g, dtype=torch.float64)).to(torch.complex128)
+    b = torch.complex(torch.randn(5, M, generator=g, dtype=torch.float64), torch.randn(5, M, generator=g, dtype=torch.float64))
+    diag = 3.0 * L * ws.abs().pow(2).real + 0.5
+    op = ToeplitzOp(v.cuda())
+    res = cg_solve_async(op, ws.cuda(), 0.5, 0, b.cuda(), torch.zeros_like(b).cuda(), 1e-9, diag=diag.cuda(), batched=True)
+    assert res is not None
+    xa, lazy = res
+    xs, its, rows = cg_solve(op, ws.cuda(), 0.5, 0, b.cuda(), torch.zeros_like(b).cuda(), 1e-9, diag=diag.cuda(), batched=True)
+    assert int(lazy) == its and list(lazy.rows) == rows
+    assert torch.equal(xa, xs)
+    one = cg_solve_async(op, ws.cuda(), 0.5, 0, b[1].cuda(), torch.zeros_like(b[1]).cuda(), 1e-9, diag=diag.cuda(), batched=False, hermitian=True)
+    assert one is not None and _rel(one[0], xs[1]) < 1e-8           # hermitian is only a hint on these grids
