@@ -172,9 +172,11 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
 
 /* Same solve without any host synchronisation: the per-row iteration counts are left in the DEVICE array
  * row_iters_dev (nbatch ints) and the call returns as soon as the work is enqueued, so the host can prepare
- * the next fit while this one runs.  Only available when the circulant grid fits the single-launch persistent
- * kernel (power-of-two FFT sizes, <= 4608 padded elements); otherwise returns EFGP_EUNSUPPORTED and the
- * caller uses efgp_cg_solve. */
+ * the next fit while this one runs.  Available when the circulant grid fits the single-launch persistent
+ * kernel (power-of-two FFT sizes, <= 4608 padded elements) and on 2-D grids of 128^2..512^2 (cooperative
+ * launches: G workgroups per system with grid barriers, all resident at once; a row whose barrier could not
+ * complete because other work held the CUs reports -3 iterations and keeps x0 -- efgp_cg_solve retries such
+ * rows itself); otherwise returns EFGP_EUNSUPPORTED and the caller uses efgp_cg_solve. */
 int efgp_cg_solve_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant,
                         const double* precond_diag, const void* b, void* x, int nbatch, double tol,
                         int max_iter, int early_stop, int batched_semantics, int* row_iters_dev, void* stream);
