@@ -1669,9 +1669,10 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     DeviceCtx* ctx = op->ctx;
     const ToepGeom g = op->g;
     const int F0 = (int)g.F[0], F1 = (int)g.F[1], n0 = (int)g.n[0], n1 = (int)g.n[1];
-    // workgroups per system: as many as the latency shape uses (32 / 32 / 64) while the whole batch stays resident (one
+    // workgroups per system: as many as the latency shape uses (16 / 32 / 64) while the whole batch stays resident (one
     // workgroup per CU), never fewer than the registers need (8 vector entries per thread)
-    const int G_lat = F1 / (F1 >= 256 ? 8 : 4);
+    int G_lat = F1 / 8;      // 16 / 32 / 64 (measured at 128^2: 19.9 us per iteration with 16 workgroups, 22.7 with 32, 20.6 with 8)
+    if (const char* eg = std::getenv("EFGP_COOP_G")) G_lat = std::max(1, std::min(G_lat, std::atoi(eg)));   // experiments
     int G_min = 1;
     while (G_min < G_lat && ((n0 + G_min - 1) / G_min) * n1 > 8 * kLineThreads) G_min <<= 1;
     int G = G_lat;
