@@ -209,8 +209,19 @@ struct TimingRec {
     hipEvent_t start, stop;
 };
 static bool g_timing = false;
+static std::string g_timing_only;            // non-empty: only timers of this name record (efgp_kernel_timing_only)
 static std::vector<TimingRec> g_recs;
+static std::vector<hipEvent_t> g_free_events;   // recycled: hipEventCreate per launch cost the host ~10 us per timed kernel
 constexpr size_t kMaxTimingRecs = 1 << 16;
+
+static bool take_event(hipEvent_t* e) {
+    if (!g_free_events.empty()) {
+        *e = g_free_events.back();
+        g_free_events.pop_back();
+        return true;
+    }
+    return hipEventCreate(e) == hipSuccess;
+}
 
 bool timing_enabled() { return g_timing; }
 
@@ -229,11 +240,12 @@ hipError_t stream_wait(hipStream_t stream) {
 
 KernelTimer::KernelTimer(const char* name, hipStream_t s) : stream(s) {
     if (!g_timing || g_recs.size() >= kMaxTimingRecs) return;
+    if (!g_timing_only.empty() && g_timing_only != name) return;
     TimingRec r;
     r.name = name;
-    if (hipEventCreate(&r.start) != hipSuccess) return;
-    if (hipEventCreate(&r.stop) != hipSuccess) {
-        (void)hipEventDestroy(r.start);
+    if (!take_event(&r.start)) return;
+    if (!take_event(&r.stop)) {
+        g_free_events.push_back(r.start);
         return;
     }
     (void)hipEventRecord(r.start, s);
@@ -247,8 +259,8 @@ KernelTimer::~KernelTimer() {
 
 static void clear_timing() {
     for (auto& r : g_recs) {
-        (void)hipEventDestroy(r.start);
-        (void)hipEventDestroy(r.stop);
+        g_free_events.push_back(r.start);
+        g_free_events.push_back(r.stop);
     }
     g_recs.clear();
 }
@@ -272,6 +284,11 @@ int efgp_kernel_timing(int enable) {
     (void)hipDeviceSynchronize();
     clear_timing();
     g_timing = enable != 0;
+    return EFGP_OK;
+}
+
+int efgp_kernel_timing_only(const char* name) {
+    g_timing_only = name ? name : "";
     return EFGP_OK;
 }
 

@@ -107,6 +107,40 @@ __global__ __launch_bounds__(256) void variance_contract_kernel(int d, int mtot,
     }
 }
 
+// ws[k] = sqrt(S(|xi_k|) h^d) (complex, imaginary part 0) and optionally h^d (dS/dl, dS/dvariance) on the tensor grid
+// xi = h (-m..m)^d for the built-in kernels (efgpnd.py:766-780, kernels/*.py): one launch instead of computing the M
+// weights on the host and staging them through a pinned buffer (host-side cost of every fit: the step was waiting for it).
+__global__ __launch_bounds__(256) void spectral_weights_kernel(int kind, int dim, double nu, double ell, double var, double c0, double h,
+                                                               int mtot, int64_t M, double2* __restrict__ ws, double2* __restrict__ dprime) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M) return;
+    const int m = (mtot - 1) / 2;
+    int64_t rem = t;
+    double q = 0.0;
+    for (int a = dim - 1; a >= 0; --a) {
+        const double xa = (double)((int)(rem % mtot) - m) * h;
+        rem /= mtot;
+        q += xa * xa;
+    }
+    const double two_pi = 6.283185307179586476925286766559, pi = 3.14159265358979323846264338327950288;
+    double hd = h;
+    for (int a = 1; a < dim; ++a) hd *= h;
+    double S, d_ell;
+    if (kind == 0) {
+        S = c0 * exp(-(two_pi * two_pi) * (ell * ell) * q / 2);
+        d_ell = S * (dim / ell - (two_pi * two_pi) * ell * q);
+    } else {
+        const double den = 2 * nu / (ell * ell) + (4 * pi * pi) * q;
+        S = c0 * pow(den, -(nu + dim / 2.0));
+        d_ell = S * (-2 * nu / ell + (-(nu + dim / 2.0)) * (-4 * nu / (ell * ell * ell)) / den);
+    }
+    ws[t] = make_double2(sqrt(S * hd), 0.0);
+    if (dprime) {
+        dprime[2 * t] = make_double2(hd * d_ell, 0.0);
+        dprime[2 * t + 1] = make_double2(hd * (S / var), 0.0);
+    }
+}
+
 }  // namespace efgp
 
 using namespace efgp;
@@ -192,6 +226,22 @@ int efgp_variance_contract(int device, int dim, int64_t mtot, double h, const do
     for (int a = 0; a < dim; ++a) M *= mtot;
     hipLaunchKernelGGL(variance_contract_kernel, dim3((unsigned)npts), dim3(256), 0, (hipStream_t)stream_, dim, (int)mtot, M, h, x_new,
                        (const double2*)ws, (const double2*)gamma, out);
+    EFGP_HIP_CHECK(hipGetLastError());
+    return EFGP_OK;
+}
+
+
+int efgp_spectral_weights(int device, int kind, int dim, double nu, double lengthscale, double variance, double c0, double h, int mtot,
+                          void* ws, void* dprime, void* stream_) {
+    EFGP_REQUIRE(ws, "efgp_spectral_weights: null output");
+    EFGP_REQUIRE(kind == 0 || kind == 1, "efgp_spectral_weights: kernel kind %d not built in", kind);
+    EFGP_REQUIRE(dim >= 1 && dim <= 3 && mtot >= 1 && (mtot & 1), "efgp_spectral_weights: bad grid");
+    if (!device_ctx(device)) return EFGP_EHIP;
+    DeviceGuard guard(device);
+    int64_t M = 1;
+    for (int a = 0; a < dim; ++a) M *= mtot;
+    hipLaunchKernelGGL(spectral_weights_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, kind, dim, nu, lengthscale,
+                       variance, c0, h, mtot, M, (double2*)ws, (double2*)dprime);
     EFGP_HIP_CHECK(hipGetLastError());
     return EFGP_OK;
 }

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "efgp_last_error": (C.c_char_p, []),
     "efgp_release_workspaces": (_I, [_I]),
     "efgp_kernel_timing": (_I, [_I]),
+    "efgp_kernel_timing_only": (_I, [C.c_char_p]),
     "efgp_kernel_timing_read": (_I, [C.c_char_p, C.POINTER(_D), _PI64]),
     "efgp_window_width": (_I, [_D, _D]),
     "efgp_window_eval": (_I, [_D, _D, _D, _PI64, C.POINTER(_D), C.POINTER(_I), C.POINTER(_D)]),
@@ -61,6 +62,9 @@ _SIGNATURES = {
     "efgp_toeplitz_fft_shape": (_I, [_VP, _PI64]),
     "efgp_cg_solve": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _VP]),
     "efgp_cg_solve_async": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, _VP, _VP]),
+    "efgp_grid_bounds": (_I, [_I, _I, _D, _D, _D, _D, _D, _D, _D, _VP, _VP]),
+    "efgp_spectral_weights_host": (_I, [_I, _I, _D, _D, _D, _D, _D, _I, _VP, _VP]),
+    "efgp_spectral_weights": (_I, [_I, _I, _I, _D, _D, _D, _D, _D, _I, _VP, _VP, _VP]),
     "efgp_cg_solve_hermitian_async": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, _VP, _VP]),
     "efgp_cg_solve_mean_async": (_I, [_VP, _VP, _D, _VP, _VP, _VP, _D, _I, _I, _VP, _VP]),
     "efgp_cg_record_history": (_I, [_VP, _I]),

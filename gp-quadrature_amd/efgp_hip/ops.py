@@ -486,7 +486,10 @@ def rademacher_fill(dev, seed, nbatch, npts, index_offset=0):
     return out
 
 
-def kernel_timing(enable):
+def kernel_timing(enable, only=None):
+    """HIP-event timers around the library's main launches; `only`: record the launches of this name alone (every timed
+    launch puts two event records into the stream)."""
+    check(lib().efgp_kernel_timing_only(only.encode() if only else None), "efgp_kernel_timing_only")
     check(lib().efgp_kernel_timing(int(bool(enable))), "efgp_kernel_timing")
 
 

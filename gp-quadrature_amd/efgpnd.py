@@ -305,14 +305,7 @@ class _Grid:
         self.shape = (self.mtot,) * d
         self.M = self.mtot ** d
         self.xis_1d = xis_1d
-        mesh = torch.meshgrid(*(xis_1d for _ in range(d)), indexing="ij")
-        self.xis = torch.stack(mesh, dim=-1).view(-1, d)                         # (M,d) host float64
-        # Small grids: evaluate the spectral density on the host (one upload instead of several launches).  Large
-        # grids (3-D): on the device -- torch's CPU reductions switch to their threaded path above 32768 elements,
-        # which costs tens of milliseconds per call on a many-core host (measured: 89 ms for M = 12167, d = 3).
-        # The same host pathology hits torch.pow with a real exponent even on a few hundred elements (12 ms per call
-        # measured on the 256-thread host): Matern densities always go to the device.
-        host_ok = self.M * d <= 16384 and type(kernel).__name__ != "Matern"
+        self._xis = None                                                         # (M,d) host float64, built on first use
         # Non-blocking uploads where the whole solve is one launch (circulant grid small enough for the persistent kernel:
         # F^d <= 4096 with F = next_pow2(2 mtot - 1)) -- that is where the host running ahead pays (launch gaps of the
         # N = 1e6 step).  The multi-kernel solves synchronise with the device per burst anyway and keep the plain copy
@@ -322,12 +315,57 @@ class _Grid:
         F = 1 << (2 * self.mtot - 2).bit_length()
         async_ok = F ** d <= 4096 or bool(os.environ.get("EFGP_ASYNC_UPLOAD_ALL"))
         up = _upload if async_ok else (lambda t, dv: t.to(dv))
+        self.dprime = None
+        # Built-in kernels: ws (and the hyper-derivatives) in ONE C call on the host (efgp_spectral_weights_host) instead of
+        # meshgrid + stack + spectral_density + sqrt + casts, ~10 torch CPU ops whose dispatch (60-150 us per fit) the 0.3-ms
+        # step had started to wait for; 3-D grids too (torch's own CPU ops go multi-threaded and slow above 32768 elements)
+        native = self._native_weights(kernel, want_grad, dev)
+        if native is not None:
+            self.ws, self.dprime = native
+            return
+        # Small grids: evaluate the spectral density on the host (one upload instead of several launches).  Large
+        # grids (3-D): on the device -- torch's CPU reductions switch to their threaded path above 32768 elements,
+        # which costs tens of milliseconds per call on a many-core host (measured: 89 ms for M = 12167, d = 3).
+        # The same host pathology hits torch.pow with a real exponent even on a few hundred elements (12 ms per call
+        # measured on the 256-thread host): Matern densities always go to the device.
+        host_ok = self.M * d <= 16384 and type(kernel).__name__ != "Matern"
         where = self.xis if host_ok else up(self.xis, dev)
         S = kernel.spectral_density(where).to(torch.float64)
         self.ws = up(torch.sqrt(S.to(torch.complex128) * self.h ** d), dev)       # (M,) complex, imag 0
-        self.dprime = None
         if want_grad:
             self.dprime = up((self.h ** d * kernel.spectral_grad(where)).to(torch.complex128), dev)   # (M,H)
+
+    @property
+    def xis(self):
+        if self._xis is None:
+            mesh = torch.meshgrid(*(self.xis_1d for _ in range(self.d)), indexing="ij")
+            self._xis = torch.stack(mesh, dim=-1).view(-1, self.d)
+        return self._xis
+
+    def _native_weights(self, kernel, want_grad, dev):
+        """(ws, dprime) as device tensors from ONE launch (efgp_spectral_weights) for the built-in kernels, else None."""
+        if os.environ.get("EFGP_NO_NATIVE_GRID") or self.M > (1 << 24) or torch.device(dev).type != "cuda":
+            return None
+        from utils.kernels import kernel_constants
+        if tuple(getattr(kernel, "hypers", ())) != ("lengthscale", "variance") or not hasattr(kernel, "get_hypers"):
+            return None
+        try:
+            ell, var = kernel.get_hypers()
+            kc = kernel_constants(kernel, ell, var)
+        except Exception:
+            return None
+        if kc is None:
+            return None
+        from efgp_hip.lib import lib
+        dev = torch.device(dev)
+        ws_d = torch.empty(self.M, dtype=torch.complex128, device=dev)
+        dp_d = torch.empty((self.M, 2), dtype=torch.complex128, device=dev) if want_grad else None
+        with torch.cuda.device(dev):
+            rc = lib().efgp_spectral_weights(dev.index if dev.index is not None else torch.cuda.current_device(), kc[0], int(self.d),
+                                             float(kc[1]), float(ell), float(var), float(kc[2]), float(self.h), int(self.mtot),
+                                             ws_d.data_ptr(), dp_d.data_ptr() if want_grad else None,
+                                             torch.cuda.current_stream(dev).cuda_stream)
+        return (ws_d, dp_d) if rc == 0 else None
 
 
 def _domain_length(xd: torch.Tensor, shards: PointShards) -> float:
@@ -980,10 +1018,8 @@ class EFGPND(nn.Module):
                 res = cg_solve(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False)[:2]
         beta, iters = res
 
-        xis = grid.xis.to(dtype=rdtype)
-        xis.h_float = grid.h
         self._beta = beta.to(cdtype) if cdtype != torch.complex128 else beta
-        self._xis = xis
+        self._xis = (grid, rdtype)                 # the (M, d) node tensor is built when somebody asks for it (property below)
         self._ws = grid.ws.to(cdtype) if cdtype != torch.complex128 else grid.ws
         self._toeplitz = toeplitz
         self._fit_state = dict(h=grid.h, mtot=grid.mtot, d=d, sig=sig, ws=grid.ws, beta=beta,
@@ -991,6 +1027,23 @@ class EFGPND(nn.Module):
         self._last_fit_stats = dict(mean_cg_iters=iters, mtot=grid.mtot, feature_count=grid.M, h=grid.h)
         self._fitted = True
         self._update_param_cache()
+
+    @property
+    def _xis(self):
+        """(M, d) frequency nodes of the last fit (reference attribute `_xis`, efgpnd.py:816), materialised on first access."""
+        src = self.__dict__.get("_xis_src")
+        if src is None:
+            return None
+        if not torch.is_tensor(src):
+            grid, rdtype = src
+            xis = grid.xis.to(dtype=rdtype)
+            xis.h_float = grid.h
+            self.__dict__["_xis_src"] = src = xis
+        return src
+
+    @_xis.setter
+    def _xis(self, value):
+        self.__dict__["_xis_src"] = value
 
     def fit(self, force_recompute: bool = True):
         """Convenience: run the fit now (the reference fits lazily inside predict)."""

@@ -62,6 +62,38 @@ class GetTruncationBound:
         return mid
 
 
+def kernel_constants(kernel_obj, ell, var):
+    """(kind, nu, c0) of a built-in kernel for the library's host-side grid functions, or None: kind 0 squared exponential
+    with c0 = (2 pi l^2)^(d/2) * variance, kind 1 Matern (nu in {1/2, 3/2, 5/2}) with c0 = variance * scaling(l) -- the
+    leading factors exactly as the Python expressions of kernels/*.py form them."""
+    if type(kernel_obj) is SquaredExponential:
+        return 0, 0.0, (2.0 * math.pi * ell ** 2) ** (kernel_obj.dimension / 2) * var
+    if type(kernel_obj) is Matern and kernel_obj.nu in (0.5, 1.5, 2.5):
+        return 1, kernel_obj.nu, var * kernel_obj._scaling(ell)
+    return None
+
+
+def _native_bounds(kernel_obj, ell, var, S0, eps, trunc_eps):
+    """The two bisections in C (efgp_grid_bounds: same operations in the same order, bit-identical bounds) when the library is
+    built and the kernel is one of the built-in ones; None otherwise (the Python loops below then run)."""
+    import os
+    if os.environ.get("EFGP_NO_NATIVE_GRID"):
+        return None
+    kc = kernel_constants(kernel_obj, ell, var)
+    if kc is None or not (1 <= kernel_obj.dimension <= 3):
+        return None
+    try:
+        import ctypes as C
+        from efgp_hip.lib import lib
+        L = lib()
+    except Exception:
+        return None
+    a, b = C.c_double(0.0), C.c_double(0.0)
+    rc = L.efgp_grid_bounds(kc[0], int(kernel_obj.dimension), float(kc[1]), float(ell), float(var), float(kc[2]), float(S0), float(eps),
+                            float(trunc_eps), C.byref(a), C.byref(b))
+    return (a.value, b.value) if rc == 0 else None
+
+
 def get_xis(kernel_obj, eps: float, L, use_integral: bool = False, l2scaled: bool = False,
             dtype: torch.dtype = torch.float64, trunc_eps: Optional[float] = None) -> Tuple[torch.Tensor, float, int]:
     dim = kernel_obj.dimension
@@ -73,7 +105,10 @@ def get_xis(kernel_obj, eps: float, L, use_integral: bool = False, l2scaled: boo
     if use_integral:
         fast = hasattr(kernel_obj, "_k_scalar") and hasattr(kernel_obj, "_S_scalar") and dtype == torch.float64
         if fast:
-            ell, var = kernel_obj.get_hyper("lengthscale"), kernel_obj.get_hyper("variance")
+            if hasattr(kernel_obj, "get_hypers") and tuple(kernel_obj.hypers) == ("lengthscale", "variance"):
+                ell, var = kernel_obj.get_hypers()
+            else:
+                ell, var = kernel_obj.get_hyper("lengthscale"), kernel_obj.get_hyper("variance")
             k_of = lambda r: kernel_obj._k_scalar(r, ell, var)
             S0 = kernel_obj._S_scalar(0.0, ell, var)
             khat = lambda r: abs(r ** (dim - 1)) * kernel_obj._S_scalar(r, ell, var) / S0
@@ -81,9 +116,13 @@ def get_xis(kernel_obj, eps: float, L, use_integral: bool = False, l2scaled: boo
             k_of = kernel_obj.kernel
             khat = lambda r: abs(r ** (dim - 1)) * kernel_obj.spectral_density(r) / kernel_obj.spectral_density(
                 torch.tensor(0, device="cpu", dtype=dtype))
-        Ltime = GetTruncationBound(eps, k_of, dtype=dtype, _scalar=fast).find_truncation_bound()
+        native = _native_bounds(kernel_obj, ell, var, S0, eps, trunc_eps) if fast else None
+        if native is not None:
+            Ltime, Lfreq = native
+        else:
+            Ltime = GetTruncationBound(eps, k_of, dtype=dtype, _scalar=fast).find_truncation_bound()
+            Lfreq = GetTruncationBound(trunc_eps, khat, dtype=dtype, _scalar=fast).find_truncation_bound()
         h_spacing = 1 / (L + Ltime)
-        Lfreq = GetTruncationBound(trunc_eps, khat, dtype=dtype, _scalar=fast).find_truncation_bound()
         hm = math.ceil(Lfreq / h_spacing)
     elif isinstance(kernel_obj, Matern):
         ell, nu = kernel_obj.get_hyper("lengthscale"), kernel_obj.nu

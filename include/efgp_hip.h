@@ -49,6 +49,9 @@ int efgp_release_workspaces(int device);
  * "cg_iteration" (one pad+FFT+multiply+FFT+update group).  efgp_kernel_timing_read synchronises the
  * device and returns the summed duration (ms) and launch count of `name` since enabling. */
 int efgp_kernel_timing(int enable);
+/* Restrict the timers to the launches of one name (NULL or "": all names): two event records per timed launch sit in the
+ * stream, so a benchmark that wants one kernel's duration inside its timed region should not pay for the others. */
+int efgp_kernel_timing_only(const char* name);
 int efgp_kernel_timing_read(const char* name, double* total_ms_out, int64_t* launches_out);
 
 /* ---- spreading-window parameters (host only; no GPU needed) ------------------------------
@@ -180,6 +183,22 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
 int efgp_cg_solve_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant,
                         const double* precond_diag, const void* b, void* x, int nbatch, double tol,
                         int max_iter, int early_stop, int batched_semantics, int* row_iters_dev, void* stream);
+
+/* Host-side scalar work of the quadrature grid for the built-in kernels (kind 0 squared exponential, 1 Matern with nu in
+ * {1/2, 3/2, 5/2}); no device involved.  efgp_grid_bounds: the two bisections of get_xis(use_integral=True)
+ * (utils/kernels.py:28-69, 94-105): *ltime_out with k(L) = eps, *lfreq_out with r^(d-1) S(r) / S(0) = trunc_eps, found with
+ * the operations of the reference's Python expressions in the same order (bit-identical bounds, hence identical h and
+ * mtot).  c0 = (2 pi l^2)^(d/2) * variance (SE) or variance * scaling(l) (Matern), s0 = S(0): formed by the caller.
+ * efgp_spectral_weights_host: ws = sqrt(S(xi) h^d) on the (mtot)^d tensor grid xi = h * (-m..m)^d as complex numbers
+ * (efgpnd.py:766-780) and, when dprime_out is not NULL, h^d * (dS/dlengthscale, dS/dvariance) (complex, (M, 2)). */
+int efgp_grid_bounds(int kind, int dim, double nu, double lengthscale, double variance, double c0, double s0, double eps,
+                     double trunc_eps, double* ltime_out, double* lfreq_out);
+int efgp_spectral_weights_host(int kind, int dim, double nu, double lengthscale, double variance, double c0, double h, int mtot,
+                               double* ws_out, double* dprime_out);
+/* The same weights computed ON the device into ws (M complex128) and, when not NULL, dprime ((M, 2) complex128): one small launch
+ * on `stream` instead of a host computation plus a staged upload. */
+int efgp_spectral_weights(int device, int kind, int dim, double nu, double lengthscale, double variance, double c0, double h, int mtot,
+                          void* ws, void* dprime, void* stream);
 
 /* efgp_cg_solve_async for systems whose vectors are Fourier coefficients of REAL functions on the symmetric mode grid:
  * every right-hand side and start vector satisfies u[-k] = conj u[k], ws is real and even, the Toeplitz vector comes

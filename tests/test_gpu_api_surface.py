@@ -338,3 +338,23 @@ def test_pointwise_alpha_matches_adjoint_and_nan_targets_poison_the_fit():
     mb = model(ybad)
     mean, _ = mb.predict(x[:100].cuda(), return_variance=False)
     assert torch.isnan(mean).all()
+
+
+def test_device_spectral_weights_match_the_kernel_classes():
+    """efgp_spectral_weights (ws and hyper-derivatives on the tensor grid in one launch) against kernel.spectral_density /
+    spectral_grad (efgpnd.py:766-780, kernels/*.py): equal to rounding; and the model's grid uses it."""
+    import torch
+    import efgpnd as E
+    from kernels.squared_exponential import SquaredExponential
+    from kernels.matern import Matern
+    dev = torch.device("cuda", 0)
+    for k, eps, L in ((SquaredExponential(dimension=2, init_lengthscale=0.2, init_variance=2.0), 1e-4, 2.0),
+                      (Matern(dimension=3, nu=1.5, init_lengthscale=0.5, init_variance=1.3), 1e-2, 2.0),
+                      (Matern(dimension=1, nu=2.5, init_lengthscale=0.1, init_variance=0.7), 1e-5, 1.5)):
+        g = E._Grid(k, eps, L, k.dimension, dev, want_grad=True)
+        ws_ref = torch.sqrt(k.spectral_density(g.xis).to(torch.complex128) * g.h ** k.dimension)
+        dp_ref = (g.h ** k.dimension * k.spectral_grad(g.xis)).to(torch.complex128)
+        assert g.ws.is_cuda and g.ws.shape == ws_ref.shape and g.dprime.shape == dp_ref.shape
+        assert float((g.ws.cpu() - ws_ref).abs().max() / ws_ref.abs().max()) < 1e-13
+        assert float((g.dprime.cpu() - dp_ref).abs().max() / dp_ref.abs().max()) < 1e-12
+        assert float(g.ws.imag.abs().max()) == 0.0

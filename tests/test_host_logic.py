@@ -192,3 +192,54 @@ def test_cpu_quota_parsing(tmp_path):
     (v1 / "cpu" / "cpu.cfs_quota_us").write_text("250000\n")
     (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
     assert cpu_quota.cpu_quota_cores(str(v1)) == 2.5
+
+
+def test_native_grid_bounds_are_bit_identical(monkeypatch):
+    """efgp_grid_bounds runs the two bisections of get_xis (utils/kernels.py:28-69, 94-105) in C with the operations of the
+    Python expressions in the same order: h, mtot and the nodes must be IDENTICAL over kernels, dimensions, tolerances."""
+    import random
+    from utils.kernels import get_xis
+    from kernels.squared_exponential import SquaredExponential
+    from kernels.matern import Matern
+    rnd = random.Random(11)
+    for trial in range(400):
+        d = rnd.choice([1, 2, 3])
+        ell, var = 10 ** rnd.uniform(-1.5, 0.5), 10 ** rnd.uniform(-2, 2)
+        eps, L = 10 ** rnd.uniform(-9, -1), rnd.uniform(0.3, 6)
+        if trial % 2:
+            k = SquaredExponential(dimension=d, init_lengthscale=ell, init_variance=var)
+        else:
+            k = Matern(dimension=d, nu=rnd.choice([0.5, 1.5, 2.5]), init_lengthscale=ell, init_variance=var)
+        monkeypatch.setenv("EFGP_NO_NATIVE_GRID", "1")
+        ref = get_xis(kernel_obj=k, eps=eps, L=L, use_integral=True)
+        monkeypatch.delenv("EFGP_NO_NATIVE_GRID")
+        got = get_xis(kernel_obj=k, eps=eps, L=L, use_integral=True)
+        assert got[1] == ref[1] and got[2] == ref[2] and torch.equal(got[0], ref[0]), (trial, d, ell, var, eps, L)
+
+
+def test_native_spectral_weights_match_the_kernel_classes():
+    """efgp_spectral_weights_host against kernel.spectral_density / spectral_grad on the tensor grid (efgpnd.py:766-780):
+    equal to rounding (libm vs torch's vectorised exp / pow)."""
+    import ctypes as C
+    from efgp_hip.lib import lib
+    from utils.kernels import kernel_constants
+    from kernels.squared_exponential import SquaredExponential
+    from kernels.matern import Matern
+    for k, h, mtot in ((SquaredExponential(dimension=2, init_lengthscale=0.2, init_variance=2.0), 0.346, 23),
+                       (Matern(dimension=3, nu=1.5, init_lengthscale=0.5, init_variance=1.3), 0.21, 9),
+                       (Matern(dimension=1, nu=2.5, init_lengthscale=0.1, init_variance=0.7), 0.4, 41),
+                       (SquaredExponential(dimension=3, init_lengthscale=0.4, init_variance=0.5), 0.3, 7)):
+        d = k.dimension
+        ell, var = k.get_hyper("lengthscale"), k.get_hyper("variance")
+        kind, nu, c0 = kernel_constants(k, ell, var)
+        M = mtot ** d
+        ws = torch.empty(M, dtype=torch.complex128)
+        dp = torch.empty((M, 2), dtype=torch.complex128)
+        assert lib().efgp_spectral_weights_host(kind, d, nu, ell, var, c0, h, mtot, ws.data_ptr(), dp.data_ptr()) == 0
+        x1 = torch.arange(-(mtot // 2), mtot // 2 + 1, dtype=torch.float64) * h
+        xis = torch.stack(torch.meshgrid(*(x1 for _ in range(d)), indexing="ij"), dim=-1).view(-1, d)
+        ws_ref = torch.sqrt(k.spectral_density(xis).to(torch.complex128) * h ** d)
+        dp_ref = (h ** d * k.spectral_grad(xis)).to(torch.complex128)
+        assert float((ws - ws_ref).abs().max() / ws_ref.abs().max()) < 1e-14
+        assert float((dp - dp_ref).abs().max() / dp_ref.abs().max()) < 1e-13
+        assert float(ws.imag.abs().max()) == 0.0
