@@ -358,3 +358,26 @@ def test_device_spectral_weights_match_the_kernel_classes():
         assert float((g.ws.cpu() - ws_ref).abs().max() / ws_ref.abs().max()) < 1e-13
         assert float((g.dprime.cpu() - dp_ref).abs().max() / dp_ref.abs().max()) < 1e-12
         assert float(g.ws.imag.abs().max()) == 0.0
+
+
+def test_kernel_timing_name_filter():
+    """efgp_kernel_timing_only: with a name set only that kernel's launches carry HIP events (bench.py keeps the timed region
+    free of the other timers)."""
+    import torch
+    from efgp_hip import NufftPlan, PointSet, kernel_timing, kernel_timing_read
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(50000, 2, generator=g, dtype=torch.float64) * 2 - 1).cuda()
+    y = torch.randn(50000, generator=g, dtype=torch.float64).cuda()
+    plan = NufftPlan(x, 0.31, 1e-7, points=PointSet(x, values=y))
+    beta = torch.complex(torch.randn(23, 23, generator=g, dtype=torch.float64), torch.randn(23, 23, generator=g, dtype=torch.float64)).cuda()
+    try:
+        kernel_timing(True, only="spread")
+        plan.type1_pair(y, (23, 23), (45, 45))
+        plan.type2(beta, (23, 23), real_only=True)
+        assert kernel_timing_read("spread")[1] == 1 and kernel_timing_read("interp")[1] == 0
+        kernel_timing(True)
+        plan.type1_pair(y, (23, 23), (45, 45))
+        plan.type2(beta, (23, 23), real_only=True)
+        assert kernel_timing_read("spread")[1] == 1 and kernel_timing_read("interp")[1] == 1
+    finally:
+        kernel_timing(False)
