@@ -1086,34 +1086,48 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
         COOP_STAMP(4);
         return true;
     };
-    // sum of K per-workgroup partials over the G workgroups: same order, same bits in every workgroup.  `slot0`: first of the
-    // three partial arrays used -- consecutive sums must use DIFFERENT arrays (a fast workgroup writes its next partial
-    // while a slow one still reads the previous sum's: there is no barrier between a sum's reads and the next sum's writes)
+    // sum of K (<= 2) per-workgroup partials over the G (<= 64) workgroups, the same bits in every workgroup: both values go
+    // through ONE workgroup reduction (fixed shuffle tree, then the four wave sums in order), and every wave then loads the G
+    // partials into its lanes and reduces them with the same fixed butterfly -- no LDS staging, no serial chain of G adds.
+    // `slot0`: first of the three partial arrays used -- consecutive sums must use DIFFERENT arrays (a fast workgroup writes
+    // its next partial while a slow one still reads the previous sum's: no barrier sits between a sum's reads and the next
+    // sum's writes)
     auto all_sum = [&](double (&v)[3], int K, int slot0) __attribute__((always_inline)) -> bool {
-        if (SOLO) {
-            for (int k = 0; k < K; ++k) v[k] = block_sum(v[k], red);
-            return true;
+        double a0 = v[0], a1 = K > 1 ? v[1] : 0.0;
+        for (int off = 32; off > 0; off >>= 1) {
+            a0 += __shfl_down(a0, off, 64);
+            a1 += __shfl_down(a1, off, 64);
         }
-        for (int k = 0; k < K; ++k) {
-            const double t = block_sum(v[k], red);
-            if (tid == 0) __hip_atomic_store(&part[(slot0 + k) * kCoopMaxG + wg], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (!coop_barrier(bar, epoch, G, a.status, &sflag)) return false;
-        for (int w = tid; w < K * G; w += kLineThreads) {
-            const int k = w / G, i = w - k * G;
-            fin[k * kCoopMaxG + i] = __hip_atomic_load(&part[(slot0 + k) * kCoopMaxG + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int lane = tid & 63, wid = tid >> 6;
+        __syncthreads();
+        if (lane == 0) {
+            red[wid] = a0;
+            fin[wid] = a1;
         }
         __syncthreads();
-        for (int k = 0; k < K; ++k) {
-            double t = 0.0;
-            for (int i = 0; i < G; ++i) t += fin[k * kCoopMaxG + i];
-            v[k] = t;
+        a0 = ((red[0] + red[1]) + red[2]) + red[3];
+        a1 = ((fin[0] + fin[1]) + fin[2]) + fin[3];
+        if (SOLO) {
+            v[0] = a0;
+            v[1] = a1;
+            __syncthreads();
+            return true;
         }
-        __syncthreads();                                          // fin is reused by the next sum
+        if (tid == 0) {
+            __hip_atomic_store(&part[slot0 * kCoopMaxG + wg], a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (K > 1) __hip_atomic_store(&part[(slot0 + 1) * kCoopMaxG + wg], a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!coop_barrier(bar, epoch, G, a.status, &sflag)) return false;
+        double b0 = lane < G ? __hip_atomic_load(&part[slot0 * kCoopMaxG + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        double b1 = (K > 1 && lane < G) ? __hip_atomic_load(&part[(slot0 + 1) * kCoopMaxG + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        for (int off = 32; off > 0; off >>= 1) {
+            b0 += __shfl_xor(b0, off, 64);
+            b1 += __shfl_xor(b1, off, 64);
+        }
+        v[0] = b0;
+        v[1] = b1;
         return true;
     };
-    // a dead grid barrier: the row reports -3 iterations.  The synchronous entry retries such rows through the multi-launch
-    // path (x still holds x0); an asynchronous caller must look at the counts (efgp_hip.LazyIterations raises)
     auto dead = [&]() {
         if (wg == 0 && tid == 0) a.iters[sys] = -3;
     };
