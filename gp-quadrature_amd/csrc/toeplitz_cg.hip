@@ -529,11 +529,13 @@ __device__ __forceinline__ void wave_sync_lds() {
 // forward transform of nl lines (line l at src + l * ld, natural order) into dst + l * ld (natural order); src is destroyed.
 // tw = exp(-2 pi i q / F), q < F, in LDS.  Ends with a workgroup barrier.
 // MUL: the outputs are multiplied by mul[k * mul_stride + l] (entry k of line l) and conjugated on the way out -- the
-// spectrum multiply and the conjugation in front of the inverse transform, done on the registers that hold the result.
+// spectrum multiply and the conjugation in front of the inverse transform, done on the registers that hold the result;
+// the return value is the thread's share of sum Re(mul) |X|^2 (with the centred spectrum: <w, T w> by Parseval).
 template <int R, bool MUL = false>
-__device__ __forceinline__ void line_fft_inwave(double2* src, double2* dst, int ld, int nl, const double2* tw,
-                                                const double2* __restrict__ mul = nullptr, int64_t mul_stride = 0) {
+__device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, int ld, int nl, const double2* tw,
+                                                  const double2* __restrict__ mul = nullptr, int64_t mul_stride = 0) {
     constexpr int LPL = 8 * R, LINES = kLineThreads / LPL, U = R > 1 ? 8 / R : 1;
+    double psum = 0.0;          // MUL: this thread's share of sum_k Re(mul_k) |X_k|^2 over its lines (Parseval: <w, T w>)
     const int li = threadIdx.x & (LPL - 1), lsub = threadIdx.x / LPL;
     const int r = li >> 3, j = li & 7;
     for (int l0 = 0; l0 < nl; l0 += LINES) {
@@ -563,6 +565,7 @@ __device__ __forceinline__ void line_fft_inwave(double2* src, double2* dst, int 
                 for (int t = 0; t < 8; ++t) mv[t] = mul[(int64_t)(j + 8 * t) * mul_stride + lq];
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
+                    if (act) psum += mv[t].x * (v[t].x * v[t].x + v[t].y * v[t].y);
                     const double2 m = cmul(v[t], mv[t]);
                     v[t] = make_double2(m.x, -m.y);
                 }
@@ -619,6 +622,7 @@ __device__ __forceinline__ void line_fft_inwave(double2* src, double2* dst, int 
         if (MUL) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
+                if (act) psum += mv[i].x * (v[i].x * v[i].x + v[i].y * v[i].y);
                 const double2 m = cmul(v[i], mv[i]);
                 v[i] = make_double2(m.x, -m.y);
             }
@@ -632,6 +636,7 @@ __device__ __forceinline__ void line_fft_inwave(double2* src, double2* dst, int 
         }
     }
     __syncthreads();
+    return psum;
 }
 
 // One out-of-line copy per (R, MUL) shared by every call site of a kernel: inlined four times per operator application the
@@ -640,9 +645,9 @@ __device__ __forceinline__ void line_fft_inwave(double2* src, double2* dst, int 
 // stay LDS instructions.
 extern __shared__ double2 efgp_line_lds[];
 template <int R, bool MUL>
-__device__ __noinline__ void line_fft_inwave_call(int src_off, int dst_off, int ld, int nl, int tw_off, const double2* mul,
-                                                  int64_t mul_stride) {
-    line_fft_inwave<R, MUL>(efgp_line_lds + src_off, efgp_line_lds + dst_off, ld, nl, efgp_line_lds + tw_off, mul, mul_stride);
+__device__ __noinline__ double line_fft_inwave_call(int src_off, int dst_off, int ld, int nl, int tw_off, const double2* mul,
+                                                    int64_t mul_stride) {
+    return line_fft_inwave<R, MUL>(efgp_line_lds + src_off, efgp_line_lds + dst_off, ld, nl, efgp_line_lds + tw_off, mul, mul_stride);
 }
 // result buffer is always `dst`
 __device__ __forceinline__ double2* line_fft_fast(double2* src, double2* dst, int F, int ld, int nl, const double2* tw) {
@@ -655,11 +660,11 @@ __device__ __forceinline__ double2* line_fft_fast(double2* src, double2* dst, in
 }
 // forward transform, spectrum multiply (mul[k * mul_stride + l]) and conjugation in one pass (F = 128, 256, 512)
 __device__ __forceinline__ double2* line_fft_fast_mul(double2* src, double2* dst, int F, int ld, int nl, const double2* tw,
-                                                      const double2* mul, int64_t mul_stride) {
+                                                      const double2* mul, int64_t mul_stride, double& psum) {
     const int so = (int)(src - efgp_line_lds), dn = (int)(dst - efgp_line_lds), to = (int)(tw - efgp_line_lds);
-    if (F == 128) line_fft_inwave_call<2, true>(so, dn, ld, nl, to, mul, mul_stride);
-    else if (F == 256) line_fft_inwave_call<4, true>(so, dn, ld, nl, to, mul, mul_stride);
-    else line_fft_inwave_call<8, true>(so, dn, ld, nl, to, mul, mul_stride);
+    if (F == 128) psum += line_fft_inwave_call<2, true>(so, dn, ld, nl, to, mul, mul_stride);
+    else if (F == 256) psum += line_fft_inwave_call<4, true>(so, dn, ld, nl, to, mul, mul_stride);
+    else psum += line_fft_inwave_call<8, true>(so, dn, ld, nl, to, mul, mul_stride);
     return dst;
 }
 // in-wave transform for the lengths it covers, the generic Stockham stages otherwise; the result buffer is returned
@@ -1001,91 +1006,6 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
     };
 
     // Au = A u for the owned elements; false when a barrier died
-    auto apply = [&](const double2 (&u)[KS], double2 (&Au)[KS]) __attribute__((always_inline)) -> bool {
-        // R: owned rows in passes of a.lines
-        for (int p0 = 0; p0 < nrows; p0 += a.lines) {
-            const int nl = min(a.lines, nrows - p0);
-            for (int l = 0; l < nl; ++l)                                      // zero padding behind the n1 inputs of each row
-                for (int i1 = n1 + tid; i1 < F1; i1 += kLineThreads) A[l * ldr + i1] = make_double2(0.0, 0.0);
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-                if (ok[s] && lrow[s] >= p0 && lrow[s] < p0 + nl) A[(lrow[s] - p0) * ldr + lcol[s]] = cmul(u[s], wsv[s]);
-            __syncthreads();
-            const double2* X = line_fft_fast(A, B, F1, ldr, nl, tw1s);
-            for (int w = tid; w < (nl << lgF1); w += kLineThreads) {
-                const int l = w >> lgF1, i1 = w & (F1 - 1);
-                store_x2<SOLO>(b1 + (int64_t)(r0 + p0 + l) * F1 + i1, X[l * ldr + i1]);
-            }
-            __syncthreads();                                                  // the next pass refills the buffers
-        }
-        COOP_STAMP(0);
-        if (!sync_grid()) return false;
-        COOP_STAMP(1);
-        // C: owned columns in passes of a.lpbc
-        for (int c0 = c_lo; c0 < c_lo + a.cols_wg; c0 += a.lpbc) {
-            // every thread's loads are issued before the first is consumed (one at a time costs a memory round trip each)
-            double2 tmp[kCoopLoads];
-#pragma unroll
-            for (int q = 0; q < kCoopLoads; ++q) {
-                const int w = tid + q * kLineThreads, i0 = w >> lgC;
-                tmp[q] = (w < (F0 << lgC) && i0 < n0) ? load_x2<SOLO>(b1 + (int64_t)i0 * F1 + c0 + (w & (a.lpbc - 1))) : make_double2(0.0, 0.0);
-            }
-#pragma unroll
-            for (int q = 0; q < kCoopLoads; ++q) {
-                const int w = tid + q * kLineThreads;
-                if (w < (F0 << lgC)) A[(w & (a.lpbc - 1)) * ldc + (w >> lgC)] = tmp[q];
-            }
-            __syncthreads();
-            COOP_STAMP(8);
-            // forward transform, .* vhat and the conjugation in front of the inverse transform on the result registers
-            double2* X = line_fft_fast_mul(A, B, F0, ldc, a.lpbc, tw0s, a.vhat + c0, F1);
-            double2* Y = X == A ? B : A;
-            COOP_STAMP(9);
-            COOP_STAMP(10);
-            const double2* Z = line_fft_fast(X, Y, F0, ldc, a.lpbc, tw0s);
-            COOP_STAMP(11);
-            for (int w = tid; w < (n0 << lgC); w += kLineThreads) {
-                const int j = w >> lgC, l = w & (a.lpbc - 1);
-                const double2 z = Z[l * ldc + (n0 - 1) + j];
-                store_x2<SOLO>(b2 + (int64_t)j * F1 + c0 + l, make_double2(z.x, -z.y));
-            }
-            __syncthreads();
-        }
-        COOP_STAMP(2);
-        if (!sync_grid()) return false;
-        COOP_STAMP(3);
-        // Ri: owned rows in passes
-#pragma unroll
-        for (int s = 0; s < KS; ++s) Au[s] = make_double2(0.0, 0.0);
-        for (int p0 = 0; p0 < nrows; p0 += a.lines) {
-            const int nl = min(a.lines, nrows - p0);
-            double2 tmp[kCoopLoads];
-#pragma unroll
-            for (int q = 0; q < kCoopLoads; ++q) {
-                const int w = tid + q * kLineThreads;
-                tmp[q] = w < (nl << lgF1) ? load_x2<SOLO>(b2 + (int64_t)(r0 + p0) * F1 + w) : make_double2(0.0, 0.0);   // rows are contiguous
-            }
-#pragma unroll
-            for (int q = 0; q < kCoopLoads; ++q) {
-                const int w = tid + q * kLineThreads;
-                if (w < (nl << lgF1)) A[(w >> lgF1) * ldr + (w & (F1 - 1))] = make_double2(tmp[q].x, -tmp[q].y);
-            }
-            __syncthreads();
-            const double2* X = line_fft_fast(A, B, F1, ldr, nl, tw1s);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                if (ok[s] && lrow[s] >= p0 && lrow[s] < p0 + nl) {
-                    const double2 z = X[(lrow[s] - p0) * ldr + (n1 - 1) + lcol[s]];
-                    const double2 gq = cmul(wsv[s], make_double2(z.x, -z.y));
-                    if (a.variant == 0) Au[s] = make_double2(gq.x + a.sigmasq * u[s].x, gq.y + a.sigmasq * u[s].y);
-                    else Au[s] = make_double2(gq.x / a.sigmasq + u[s].x, gq.y / a.sigmasq + u[s].y);
-                }
-            }
-            __syncthreads();                                      // the next pass / phase overwrites the buffers
-        }
-        COOP_STAMP(4);
-        return true;
-    };
     // sum of K (<= 2) per-workgroup partials over the G (<= 64) workgroups, the same bits in every workgroup: both values go
     // through ONE workgroup reduction (fixed shuffle tree, then the four wave sums in order), and every wave then loads the G
     // partials into its lanes and reduces them with the same fixed butterfly -- no LDS staging, no serial chain of G adds.
@@ -1128,12 +1048,109 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
         v[1] = b1;
         return true;
     };
+    // <u, A u> comes out of the operator application itself: sigma^2 |u|^2 (own rows, phase R) + sum_f Re(vhat_c) |FFT(ws u)|^2 (own
+    // columns, phase C; Parseval with the CENTRED spectrum vhat_c = vhat . e^(2 pi i f (n-1)/F), whose circular convolution has its
+    // crop window at [0, n)), reduced over the workgroups ON the barrier between phases C and Ri -- the separate <p, A p> barrier
+    // and all-reduce of an iteration are gone (3 grid barriers instead of 4)
+    auto apply = [&](const double2 (&u)[KS], double2 (&Au)[KS], double& uAu) __attribute__((always_inline)) -> bool {
+        double pp = 0.0, cs = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pp += u[s].x * u[s].x + u[s].y * u[s].y;
+        // R: owned rows in passes of a.lines
+        for (int p0 = 0; p0 < nrows; p0 += a.lines) {
+            const int nl = min(a.lines, nrows - p0);
+            for (int l = 0; l < nl; ++l)                                      // zero padding behind the n1 inputs of each row
+                for (int i1 = n1 + tid; i1 < F1; i1 += kLineThreads) A[l * ldr + i1] = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                if (ok[s] && lrow[s] >= p0 && lrow[s] < p0 + nl) A[(lrow[s] - p0) * ldr + lcol[s]] = cmul(u[s], wsv[s]);
+            __syncthreads();
+            const double2* X = line_fft_fast(A, B, F1, ldr, nl, tw1s);
+            for (int w = tid; w < (nl << lgF1); w += kLineThreads) {
+                const int l = w >> lgF1, i1 = w & (F1 - 1);
+                store_x2<SOLO>(b1 + (int64_t)(r0 + p0 + l) * F1 + i1, X[l * ldr + i1]);
+            }
+            __syncthreads();                                                  // the next pass refills the buffers
+        }
+        COOP_STAMP(0);
+        if (!sync_grid()) return false;
+        COOP_STAMP(1);
+        // C: owned columns in passes of a.lpbc
+        for (int c0 = c_lo; c0 < c_lo + a.cols_wg; c0 += a.lpbc) {
+            // every thread's loads are issued before the first is consumed (one at a time costs a memory round trip each)
+            double2 tmp[kCoopLoads];
+#pragma unroll
+            for (int q = 0; q < kCoopLoads; ++q) {
+                const int w = tid + q * kLineThreads, i0 = w >> lgC;
+                tmp[q] = (w < (F0 << lgC) && i0 < n0) ? load_x2<SOLO>(b1 + (int64_t)i0 * F1 + c0 + (w & (a.lpbc - 1))) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int q = 0; q < kCoopLoads; ++q) {
+                const int w = tid + q * kLineThreads;
+                if (w < (F0 << lgC)) A[(w & (a.lpbc - 1)) * ldc + (w >> lgC)] = tmp[q];
+            }
+            __syncthreads();
+            COOP_STAMP(8);
+            // forward transform, .* vhat and the conjugation in front of the inverse transform on the result registers
+            double2* X = line_fft_fast_mul(A, B, F0, ldc, a.lpbc, tw0s, a.vhat + c0, F1, cs);
+            double2* Y = X == A ? B : A;
+            COOP_STAMP(9);
+            COOP_STAMP(10);
+            const double2* Z = line_fft_fast(X, Y, F0, ldc, a.lpbc, tw0s);
+            COOP_STAMP(11);
+            for (int w = tid; w < (n0 << lgC); w += kLineThreads) {
+                const int j = w >> lgC, l = w & (a.lpbc - 1);
+                const double2 z = Z[l * ldc + j];
+                store_x2<SOLO>(b2 + (int64_t)j * F1 + c0 + l, make_double2(z.x, -z.y));
+            }
+            __syncthreads();
+        }
+        COOP_STAMP(2);
+        {
+            double t3[3] = {a.variant == 0 ? a.sigmasq * pp + cs : pp + cs / a.sigmasq, 0.0, 0.0};
+            if (!all_sum(t3, 1, 2)) return false;
+            uAu = t3[0];
+        }
+        COOP_STAMP(3);
+        // Ri: owned rows in passes
+#pragma unroll
+        for (int s = 0; s < KS; ++s) Au[s] = make_double2(0.0, 0.0);
+        for (int p0 = 0; p0 < nrows; p0 += a.lines) {
+            const int nl = min(a.lines, nrows - p0);
+            double2 tmp[kCoopLoads];
+#pragma unroll
+            for (int q = 0; q < kCoopLoads; ++q) {
+                const int w = tid + q * kLineThreads;
+                tmp[q] = w < (nl << lgF1) ? load_x2<SOLO>(b2 + (int64_t)(r0 + p0) * F1 + w) : make_double2(0.0, 0.0);   // rows are contiguous
+            }
+#pragma unroll
+            for (int q = 0; q < kCoopLoads; ++q) {
+                const int w = tid + q * kLineThreads;
+                if (w < (nl << lgF1)) A[(w >> lgF1) * ldr + (w & (F1 - 1))] = make_double2(tmp[q].x, -tmp[q].y);
+            }
+            __syncthreads();
+            const double2* X = line_fft_fast(A, B, F1, ldr, nl, tw1s);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (ok[s] && lrow[s] >= p0 && lrow[s] < p0 + nl) {
+                    const double2 z = X[(lrow[s] - p0) * ldr + lcol[s]];
+                    const double2 gq = cmul(wsv[s], make_double2(z.x, -z.y));
+                    if (a.variant == 0) Au[s] = make_double2(gq.x + a.sigmasq * u[s].x, gq.y + a.sigmasq * u[s].y);
+                    else Au[s] = make_double2(gq.x / a.sigmasq + u[s].x, gq.y / a.sigmasq + u[s].y);
+                }
+            }
+            __syncthreads();                                      // the next pass / phase overwrites the buffers
+        }
+        COOP_STAMP(4);
+        return true;
+    };
     auto dead = [&]() {
         if (wg == 0 && tid == 0) a.iters[sys] = -3;
     };
 
     double2 Ap[KS];
-    if (!apply(xv, Ap)) return dead();
+    double uAu = 0.0;
+    if (!apply(xv, Ap, uAu)) return dead();
     double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -1151,13 +1168,9 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
     const double den = bn > 0.0 ? bn : 1.0;
     int it = 0;
     for (; it < a.max_iter;) {
-        if (!apply(pv, Ap)) return dead();
-        acc[0] = 0.0;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) acc[0] += pv[s].x * Ap[s].x + pv[s].y * Ap[s].y;
-        if (!all_sum(acc, 1, 2)) return dead();
+        if (!apply(pv, Ap, uAu)) return dead();
         COOP_STAMP(5);
-        const double alpha = rz / (acc[0] + kDivEps);
+        const double alpha = rz / (uAu + kDivEps);
         acc[0] = acc[1] = 0.0;
         double2 zv[KS];
 #pragma unroll
@@ -1402,6 +1415,20 @@ __global__ __launch_bounds__(kLineThreads) void cg3_inv2_kernel(Line3Args a) {
     }
 }
 
+// vhat_c[f] = vhat[f] e^(2 pi i (f0 (n0-1)/F0 + f1 (n1-1)/F1)): the spectrum of the Toeplitz vector circularly shifted so that the
+// crop window of the product sits at [0, n) -- real for the Hermitian vectors of EFGP; the cooperative solve multiplies by it
+// and reads <w, T w> = sum_f Re(vhat_c) |w^|^2 off the forward transform (Parseval)
+__global__ __launch_bounds__(256) void center_spectrum_kernel(const double2* __restrict__ vhat, const double2* __restrict__ tw0,
+                                                              const double2* __restrict__ tw1, int n0, int n1, int F0, int F1,
+                                                              double2* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)F0 * F1) return;
+    const int f0 = (int)(t / F1), f1 = (int)(t - (int64_t)f0 * F1);
+    const double2 a = tw0[((int64_t)(n0 - 1) * f0) & (F0 - 1)], b = tw1[((int64_t)(n1 - 1) * f1) & (F1 - 1)];
+    const double2 ph = make_double2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));      // conj(a b)
+    out[t] = cmul(vhat[t], ph);
+}
+
 template <bool AC, bool BC>
 __global__ void vdot_real_kernel(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
                                  double* __restrict__ partial) {
@@ -1446,6 +1473,7 @@ struct efgp_toeplitz_s {
     // 2-D blocks of up to 16 x 16 modes (circulant grids 8^2 .. 32^2): the CG solves run on a 64 x 64 embedding instead, through
     // the specialised 64 x 64 kernels (any F >= 2 n - 1 embeds the Toeplitz product exactly; measured 3.1 us per iteration
     // against 9-11 us of the generic kernel on the 32 x 32 grid).  fft_shape / efgp_toeplitz_apply keep the reference's grid.
+    double2* vhat_c = nullptr;   // lines_ok grids: centred spectrum for the cooperative solve (center_spectrum_kernel)
     ToepGeom g_cg;
     double2* vhat_cg = nullptr;
     double2* tw_cg[3] = {nullptr, nullptr, nullptr};
@@ -1590,6 +1618,17 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
             op->tw[a] = dtw;
         }
     }
+    if (op->lines_ok) {
+        op->vhat_c = (double2*)pool_alloc(ctx, (size_t)op->g.Ftot * sizeof(double2));
+        if (op->vhat_c) {
+            hipLaunchKernelGGL(center_spectrum_kernel, dim3((unsigned)((op->g.Ftot + 255) / 256)), dim3(256), 0, stream, op->vhat, op->tw[0],
+                               op->tw[1], (int)op->g.n[0], (int)op->g.n[1], (int)op->g.F[0], (int)op->g.F[1], op->vhat_c);
+            if (hipGetLastError() != hipSuccess) {
+                pool_free(ctx, op->vhat_c, (size_t)op->g.Ftot * sizeof(double2));
+                op->vhat_c = nullptr;
+            }
+        }
+    }
     if (dim == 2 && op->persistent_ok && op->g.n[0] == op->g.n[1] && op->g.F[0] == op->g.F[1] && op->g.F[0] < 64 &&
         op->Ls[0] <= 63 && std::getenv("EFGP_NO_CG64_EMBED") == nullptr && std::getenv("EFGP_NO_CG64") == nullptr) {
         op->g_cg = op->g;
@@ -1632,6 +1671,7 @@ int efgp_toeplitz_destroy(efgp_toeplitz_t* op) {
     // finishes before any later enqueue on that stream can overwrite a recycled block (single stream)
     if (op->vhat) pool_free(op->ctx, op->vhat, (size_t)op->g.Ftot * sizeof(double2));
     if (op->vhat_cg) pool_free(op->ctx, op->vhat_cg, (size_t)4096 * sizeof(double2));
+    if (op->vhat_c) pool_free(op->ctx, op->vhat_c, (size_t)op->g.Ftot * sizeof(double2));
     delete op;
     return EFGP_OK;
 }
@@ -1727,7 +1767,8 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     ca.early_stop = early_stop;
     ca.batched = batched_semantics;
     ca.max_iter = max_iter;
-    ca.vhat = op->vhat;
+    if (!op->vhat_c) return EFGP_EUNSUPPORTED;
+    ca.vhat = op->vhat_c;
     ca.tw0 = op->tw[0];
     ca.tw1 = op->tw[1];
     ca.b1 = pad;
