@@ -1311,6 +1311,173 @@ int toeplitz_vhat_fused_launch(const double2* v, int L0, int L1, double factor, 
 
 namespace pcg {
 
+// y[row] = post .* T(pre .* x[row]) on the 64 x 64 circulant grid in ONE launch, one workgroup per row: the operator part of
+// cg_persistent_2d64_kernel's iteration (same lane maps, same pruned passes, same arithmetic) without the recurrences.
+// The hyper-gradient applies T three times per step outside a solve (T g, T D'F*Z, T D V: efgpnd.py:150-153, :186-189, :203);
+// through pad / two rocFFT plans / multiply / two rocFFT plans / crop that is 7 dependent launches each.
+// pre / post: M-length complex diagonals or null; x may be real (x_is_real: M doubles per row).
+struct ApplyArgs {
+    int n, M;
+    const double2* tw;       // exp(-2 pi i q / 64)
+    const double2* vhat;     // [64][64], already divided by 4096
+    const double2* pre;
+    const double2* post;
+    const void* x;
+    int x_is_real;
+    double2* y;
+};
+
+__global__ __launch_bounds__(kThreads) void toeplitz_apply_2d64_kernel(ApplyArgs a) {
+    using namespace s64;
+    constexpr int LD = 72, BUF = F * LD;    // row pitch as in cg_persistent_2d64_kernel (8 mod 16)
+    constexpr int KS = 2;
+    extern __shared__ double2 lds2[];
+    double2* const bufA = lds2;
+    double2* const bufB = lds2 + BUF;
+    const int n = a.n, M = a.M;
+    const int64_t base = (int64_t)blockIdx.x * M;
+    const int tid = threadIdx.x;
+    const int j_row = tid & 7, r_row = tid >> 3;
+    const bool row_act = r_row < n;
+    const int c_col = tid & 63, j_col = tid >> 6;
+    const int nv_row = j_row < n ? (n - 1 - j_row) / 8 + 1 : 0;
+    const int nv_col = j_col < n ? (n - 1 - j_col) / 8 + 1 : 0;
+    unsigned keep_col = 0, keep_row = 0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int pc = j_col + 8 * t, pr = j_row + 8 * t;
+        if (pc >= n - 1 && pc < 2 * n - 1) keep_col |= 1u << t;
+        if (pr >= n - 1 && pr < 2 * n - 1) keep_row |= 1u << t;
+    }
+    double2 twr[7], twc[7];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) {
+        twr[t - 1] = a.tw[j_row * t];
+        twc[t - 1] = a.tw[j_col * t];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int t = tid + s * kThreads;
+        if (t < M) {
+            double2 u = a.x_is_real ? make_double2(((const double*)a.x)[base + t], 0.0) : ((const double2*)a.x)[base + t];
+            if (a.pre) u = cmulp(a.pre[t], u);
+            const int i0 = t / n, i1 = t - i0 * n;
+            bufA[i0 * LD + i1] = u;
+        }
+    }
+    __syncthreads();
+    double2 v[8];
+    // forward along dim 1 of the n non-zero rows (A -> B -> A), a row lives in one wave
+    if (row_act) {
+        load8<8>(bufA + r_row * LD + j_row, nv_row, v);
+        dft_fwd<8>(v);
+        store8_all<1>(bufB + r_row * LD + j_row * 9, v);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (row_act) {
+        load8_all<9>(bufB + r_row * LD + j_row, v);
+        twiddle8(v, twr);
+        dft_fwd<8>(v);
+        store8_all<8>(bufA + r_row * LD + j_row, v);
+    }
+    __syncthreads();
+    // forward along dim 0 (rows >= n are zero), spectrum, inverse along dim 0 keeping the crop window's rows
+    load8<8 * LD>(bufA + j_col * LD + c_col, nv_col, v);
+    dft_fwd<8>(v);
+    store8_all<LD>(bufB + j_col * 8 * LD + c_col, v);
+    __syncthreads();
+    load8_all<8 * LD>(bufB + j_col * LD + c_col, v);
+    twiddle8(v, twc);
+    dft_fwd<8>(v);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = conjd(cmulp(v[t], a.vhat[(j_col + 8 * t) * F + c_col]));
+    dft_fwd<8>(v);
+    conj8(v);
+    store8_all<LD>(bufA + j_col * 8 * LD + c_col, v);
+    __syncthreads();
+    load8_all<8 * LD>(bufA + j_col * LD + c_col, v);
+    conj8(v);
+    twiddle8(v, twc);
+    dft_fwd<8>(v);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (keep_col & (1u << t)) bufB[(j_col + 8 * t) * LD + c_col] = conjd(v[t]);
+    __syncthreads();
+    // inverse along dim 1 of the n window rows (B -> A -> B), cropped columns
+    const int wrow = n - 1 + r_row;
+    if (row_act) {
+        load8_all<8>(bufB + wrow * LD + j_row, v);
+        conj8(v);
+        dft_fwd<8>(v);
+        conj8(v);
+        store8_all<1>(bufA + wrow * LD + j_row * 9, v);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (row_act) {
+        load8_all<9>(bufA + wrow * LD + j_row, v);
+        conj8(v);
+        twiddle8(v, twr);
+        dft_fwd<8>(v);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (keep_row & (1u << t)) bufB[wrow * LD + j_row + 8 * t] = conjd(v[t]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int t = tid + s * kThreads;
+        if (t < M) {
+            const int i0 = t / n, i1 = t - i0 * n;
+            double2 g = bufB[(i0 + n - 1) * LD + (i1 + n - 1)];
+            if (a.post) g = cmulp(a.post[t], g);
+            a.y[base + t] = g;
+        }
+    }
+}
+
+}  // namespace pcg
+
+bool toeplitz_apply_fused_eligible(const ToepGeom& g) {
+    return g.d == 2 && g.F[0] == 64 && g.F[1] == 64 && g.n[0] == g.n[1] && g.n[0] <= 32 && g.M <= 2 * pcg::kThreads &&
+           std::getenv("EFGP_NO_APPLY64") == nullptr;
+}
+
+int toeplitz_apply_fused_launch(const ToepGeom& g, const double2* tw64, const double2* vhat, const double2* pre, const double2* post,
+                                const void* x, int x_is_real, double2* y, int rows, hipStream_t stream) {
+    using namespace pcg;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)toeplitz_apply_2d64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 256);
+        if (e != hipSuccess) {
+            set_error("Toeplitz apply (64x64): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return EFGP_EHIP;
+        }
+        attr = true;
+    }
+    ApplyArgs a;
+    a.n = (int)g.n[0];
+    a.M = (int)g.M;
+    a.tw = tw64;
+    a.vhat = vhat;
+    a.pre = pre;
+    a.post = post;
+    a.x = x;
+    a.x_is_real = x_is_real;
+    a.y = y;
+    hipLaunchKernelGGL(toeplitz_apply_2d64_kernel, dim3(rows), dim3(kThreads), (size_t)2 * 64 * 72 * sizeof(double2), stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("Toeplitz apply (64x64) launch failed: %s", hipGetErrorString(e));
+        return EFGP_EHIP;
+    }
+    return EFGP_OK;
+}
+
+namespace pcg {
+
 #ifdef EFGP_CG_STAMPS
 static long long* g_last_stamps = nullptr;
 #endif

@@ -122,6 +122,41 @@ __global__ void crop_kernel(ToepGeom g, const double2* __restrict__ pad, double2
         y[(int64_t)row * g.M + t] = P[pad_index(g, t, 1)];
 }
 
+// efgp_toeplitz_apply_scaled on grids without the single-launch kernel: the diagonals ride in the pad and crop passes
+// pad[row] = 0 except the leading n-box = pre .* x[row] (x real or complex)
+template <bool REAL>
+__global__ void pad_pre_kernel(ToepGeom g, const void* __restrict__ src, const double2* __restrict__ pre, double2* __restrict__ pad) {
+    const int row = blockIdx.y;
+    double2* P = pad + (int64_t)row * g.Ftot;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < g.Ftot; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t rem = t, flat = 0, coords[3];
+        bool inside = true;
+        for (int a = g.d - 1; a >= 0; --a) {
+            coords[a] = rem % g.F[a];
+            rem /= g.F[a];
+            inside = inside && coords[a] < g.n[a];
+        }
+        double2 v = make_double2(0.0, 0.0);
+        if (inside) {
+            for (int a = 0; a < g.d; ++a) flat = flat * g.n[a] + coords[a];
+            if (REAL) v = make_double2(((const double*)src)[(int64_t)row * g.M + flat], 0.0);
+            else v = ((const double2*)src)[(int64_t)row * g.M + flat];
+            if (pre) v = cmul(v, pre[flat]);
+        }
+        P[t] = v;
+    }
+}
+// y[row] = post .* window of pad[row]
+__global__ void crop_post_kernel(ToepGeom g, const double2* __restrict__ pad, const double2* __restrict__ post, double2* __restrict__ y) {
+    const int row = blockIdx.y;
+    const double2* P = pad + (int64_t)row * g.Ftot;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < g.M; t += (int64_t)gridDim.x * blockDim.x) {
+        double2 v = P[pad_index(g, t, 1)];
+        if (post) v = cmul(v, post[t]);
+        y[(int64_t)row * g.M + t] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // CG state
 // ------------------------------------------------------------------------------------------
@@ -1701,6 +1736,41 @@ int efgp_toeplitz_apply(efgp_toeplitz_t* op, const void* x, int nbatch, void* y,
         if (rc != EFGP_OK) return rc;
         hipLaunchKernelGGL(crop_kernel, grid_for(op->g.M, rows, kVecThreads), dim3(kVecThreads), 0, stream, op->g,
                            (const double2*)pad, (double2*)y + r0 * op->g.M);
+        EFGP_HIP_CHECK(hipGetLastError());
+    }
+    return EFGP_OK;
+}
+
+int efgp_toeplitz_apply_scaled(efgp_toeplitz_t* op, const void* x, int x_is_real, int nbatch, const void* pre, const void* post,
+                               void* y, void* stream_) {
+    EFGP_REQUIRE(op && x && y, "efgp_toeplitz_apply_scaled: null argument");
+    EFGP_REQUIRE(nbatch >= 1, "efgp_toeplitz_apply_scaled: nbatch must be >= 1");
+    EFGP_REQUIRE(x != y, "efgp_toeplitz_apply_scaled: x and y must not alias");
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(op->device);
+    const ToepGeom* gq;
+    const double2* const* twq;
+    const double2* vq;
+    cg_operands(op, &gq, &twq, &vq);
+    if (toeplitz_apply_fused_eligible(*gq))
+        return toeplitz_apply_fused_launch(*gq, twq[0], vq, (const double2*)pre, (const double2*)post, x, x_is_real, (double2*)y, nbatch,
+                                           stream);
+    const int64_t max_rows = std::max<int64_t>(1, (int64_t)(256ll << 20) / (op->g.Ftot * (int64_t)sizeof(double2)));
+    for (int64_t r0 = 0; r0 < nbatch; r0 += max_rows) {
+        const int rows = (int)std::min<int64_t>(max_rows, nbatch - r0);
+        double2* pad = (double2*)scratch(op->ctx, SLOT_TOEP_PAD, (size_t)rows * (size_t)op->g.Ftot * sizeof(double2));
+        if (!pad) return EFGP_ENOMEM;
+        if (x_is_real)
+            hipLaunchKernelGGL(pad_pre_kernel<true>, grid_for(op->g.Ftot, rows, kVecThreads), dim3(kVecThreads), 0, stream, op->g,
+                               (const void*)((const double*)x + r0 * op->g.M), (const double2*)pre, pad);
+        else
+            hipLaunchKernelGGL(pad_pre_kernel<false>, grid_for(op->g.Ftot, rows, kVecThreads), dim3(kVecThreads), 0, stream, op->g,
+                               (const void*)((const double2*)x + r0 * op->g.M), (const double2*)pre, pad);
+        EFGP_HIP_CHECK(hipGetLastError());
+        int rc = circulant(op, pad, rows, stream);
+        if (rc != EFGP_OK) return rc;
+        hipLaunchKernelGGL(crop_post_kernel, grid_for(op->g.M, rows, kVecThreads), dim3(kVecThreads), 0, stream, op->g,
+                           (const double2*)pad, (const double2*)post, (double2*)y + r0 * op->g.M);
         EFGP_HIP_CHECK(hipGetLastError());
     }
     return EFGP_OK;

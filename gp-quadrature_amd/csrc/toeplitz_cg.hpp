@@ -34,4 +34,9 @@ int persistent_cg_launch(const ToepGeom& g, const double2* const* twiddles, cons
 bool toeplitz_vhat_fused_eligible(const ToepGeom& g);
 int toeplitz_vhat_fused_launch(const double2* v, int L0, int L1, double factor, double2* vhat, hipStream_t stream);
 
+// y[row] = post .* T(pre .* x[row]) on the 64 x 64 circulant grid in one launch (cg_persistent.hip)
+bool toeplitz_apply_fused_eligible(const ToepGeom& g);
+int toeplitz_apply_fused_launch(const ToepGeom& g, const double2* tw64, const double2* vhat, const double2* pre, const double2* post,
+                                const void* x, int x_is_real, double2* y, int rows, hipStream_t stream);
+
 }  // namespace efgp

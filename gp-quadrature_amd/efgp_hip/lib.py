@@ -59,12 +59,15 @@ _SIGNATURES = {
     "efgp_toeplitz_create": (_I, [C.POINTER(_VP), _I, _I, _PI64, _VP, _I, _VP]),
     "efgp_toeplitz_destroy": (_I, [_VP]),
     "efgp_toeplitz_apply": (_I, [_VP, _VP, _I, _VP, _VP]),
+    "efgp_toeplitz_apply_scaled": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP]),
     "efgp_toeplitz_fft_shape": (_I, [_VP, _PI64]),
     "efgp_cg_solve": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _VP]),
     "efgp_cg_solve_async": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, _VP, _VP]),
     "efgp_grid_bounds": (_I, [_I, _I, _D, _D, _D, _D, _D, _D, _D, _VP, _VP]),
     "efgp_spectral_weights_host": (_I, [_I, _I, _D, _D, _D, _D, _D, _I, _VP, _VP]),
     "efgp_spectral_weights": (_I, [_I, _I, _I, _D, _D, _D, _D, _D, _I, _VP, _VP, _VP]),
+    "efgp_gradient_prepare": (_I, [_I, _I64, _VP, _VP, _VP, _D, _VP, _VP, _VP]),
+    "efgp_gradient_assemble": (_I, [_I, _I64, _I, _I, _I, _I, C.POINTER(_I), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _D, _D, _D, _D, _VP, _VP]),
     "efgp_cg_solve_hermitian_async": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, _VP, _VP]),
     "efgp_cg_solve_mean_async": (_I, [_VP, _VP, _D, _VP, _VP, _VP, _D, _I, _I, _VP, _VP]),
     "efgp_cg_record_history": (_I, [_VP, _I]),

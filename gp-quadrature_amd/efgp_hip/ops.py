@@ -235,6 +235,67 @@ class ToeplitzOp:
                   "efgp_toeplitz_apply")
         return out.reshape(u.shape)
 
+    def apply_scaled(self, u, pre=None, post=None, out=None):
+        """post .* T(pre .* u) for u (..., size) complex or real float64 on the device (efgp_toeplitz_apply_scaled); pre / post:
+        (size,) complex128 device tensors or None.  `out`: a contiguous complex128 (rows, size) device tensor to write into."""
+        real = not u.is_complex()
+        uu = u.reshape(-1, self.size).to(device=self.dev, dtype=_RD if real else _CD).contiguous()
+        res = out if out is not None else torch.empty(uu.shape, dtype=_CD, device=self.dev)
+        assert res.is_contiguous() and res.dtype == _CD and res.numel() == uu.numel()
+        for dgl in (pre, post):
+            assert dgl is None or (dgl.is_cuda and dgl.dtype == _CD and dgl.is_contiguous() and dgl.numel() == self.size)
+        with torch.cuda.device(self.dev):
+            check(lib().efgp_toeplitz_apply_scaled(self._h, _ptr(uu), int(real), uu.shape[0], _ptr(pre) if pre is not None else None,
+                                                   _ptr(post) if post is not None else None, _ptr(res), _stream(self.dev)),
+                  "efgp_toeplitz_apply_scaled")
+        return res if out is not None else res.reshape(u.shape)
+
+
+def gradient_prepare(ws, fy, v_center, sigmasq, want_diag=True, want_rhs=True):
+    """(diag, rhs) = (Re v_center |ws|^2 + sigmasq, ws .* fy) in one launch (efgp_gradient_prepare); v_center: a one-element
+    complex128 device view of the Toeplitz vector's centre."""
+    dev = ws.device
+    M = ws.numel()
+    assert ws.dtype == _CD and ws.is_contiguous()
+    diag = torch.empty(M, dtype=_RD, device=dev) if want_diag else None
+    rhs = torch.empty(M, dtype=_CD, device=dev) if want_rhs else None
+    ff = fy.reshape(-1).to(dtype=_CD).contiguous() if want_rhs else None
+    if want_diag:
+        assert v_center.is_cuda and v_center.dtype == _CD and v_center.numel() == 1
+    with torch.cuda.device(dev):
+        check(lib().efgp_gradient_prepare(dev.index, M, _ptr(ws), _ptr(ff) if ff is not None else None,
+                                          _ptr(v_center) if want_diag else None, float(sigmasq), _ptr(diag) if want_diag else None,
+                                          _ptr(rhs) if want_rhs else None, _stream(dev)), "efgp_gradient_prepare")
+    return diag, rhs
+
+
+def gradient_assemble(fy, tg, ws, beta, dprime, fz, v, beta_all, *, variance_idx, trace_idx, sigmasq, n_obs, yy, variance):
+    """grad | term1 | term2 | y.alpha as ONE device vector of 3 (H + 1) + 1 doubles (efgp_gradient_assemble)."""
+    dev = ws.device
+    M = ws.numel()
+    H = dprime.shape[1] if dprime is not None and dprime.ndim == 2 else 0
+    T = v.shape[0]
+    K = len(trace_idx)
+    for t_ in (fy, tg, ws, beta, beta_all) + ((dprime,) if H else ()) + ((fz,) if K else ()):
+        assert t_.is_cuda and t_.dtype == _CD and t_.is_contiguous()
+    assert v.dtype == _RD and v.is_contiguous() and v.shape == (T, M)
+    assert beta_all.numel() == (K + 1) * T * M and (K == 0 or fz.numel() == T * M)
+    out = torch.empty(3 * (H + 1) + 1, dtype=_RD, device=dev)
+    tix = (C.c_int * max(1, K))(*[int(i) for i in trace_idx])
+    with torch.cuda.device(dev):
+        check(lib().efgp_gradient_assemble(dev.index, M, T, H, -1 if variance_idx is None else int(variance_idx), K, tix,
+                                           _ptr(fy), _ptr(tg), _ptr(ws), _ptr(beta), _ptr(dprime) if H else None,
+                                           _ptr(fz) if K else None, _ptr(v), _ptr(beta_all), float(sigmasq), float(n_obs), float(yy),
+                                           float(variance), _ptr(out), _stream(dev)), "efgp_gradient_assemble")
+    return out
+
+
+def _start_vector(x0, bb, op, dev):
+    """The solver's in/out buffer: a copy of x0, or zeros when x0 is None (one fill instead of a fill and a copy)."""
+    if x0 is None:
+        return torch.zeros(bb.shape, dtype=_CD, device=dev)
+    return x0.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous().clone()
+
 
 def cg_solve(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=True, diag=None, batched=None, hermitian=False):
     """Fused device CG on ws*T(ws*.) (+sigma^2 | /sigma^2 + 1).  Returns (x, iters, row_iters).
@@ -249,7 +310,7 @@ def cg_solve(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=Tru
         if res is not None:
             return res[0], int(res[1]), list(res[1].rows)
     bb = b.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous()
-    x = x0.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous().clone()
+    x = _start_vector(x0, bb, op, dev)
     wsd = ws.to(device=dev, dtype=_CD).contiguous()
     dg = diag.to(device=dev, dtype=_RD).contiguous() if diag is not None else None
     B = bb.shape[0]
@@ -307,7 +368,7 @@ def cg_solve_async(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_st
     if batched is None:
         batched = b.ndim > 1
     bb = b.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous()
-    x = x0.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous().clone()
+    x = _start_vector(x0, bb, op, dev)
     wsd = ws.to(device=dev, dtype=_CD).contiguous()
     dg = diag.to(device=dev, dtype=_RD).contiguous() if diag is not None else None
     B = bb.shape[0]

@@ -31,7 +31,7 @@ from cg import ConjugateGradients
 from kernels.kernel_params import GPParams
 from utils.kernels import get_xis
 
-from efgp_hip import NufftPlan, PointSet, ToeplitzOp, lanczos, lag_sums, variance_rhs, variance_contract, cg_solve, cg_solve_async, cg_solve_mean_async, vdot_real, compute_device, rademacher_fill
+from efgp_hip import NufftPlan, PointSet, ToeplitzOp, lanczos, lag_sums, variance_rhs, variance_contract, cg_solve, cg_solve_async, cg_solve_mean_async, vdot_real, compute_device, rademacher_fill, gradient_prepare, gradient_assemble
 from efgp_hip.dist import PointShards
 
 TWO_PI = 2.0 * math.pi
@@ -486,142 +486,165 @@ def efgpnd_gradient_batched(
     # 3) Toeplitz operator, Jacobi diagonal (F*y rides in the same pass over the points) --------
     Fy, v = _normal_equations(plan, yd, grid, shards)
     top = ToeplitzOp(v)
-    diag = (_center_value(v) * ws.abs().pow(2).real + sig)
-    lap("3_toeplitz_setup")
-
-    # 4) mean solve ---------------------------------------------------------------------------
-    rhs = ws * Fy
-    warm = mean_cg_init is not None and tuple(mean_cg_init.shape) == tuple(rhs.shape)
-    b0 = mean_cg_init.detach().to(device=dev, dtype=torch.complex128) if warm else torch.zeros_like(rhs)
-    # rhs = D F*y of the real y (and a warm start from an earlier solve of the same kind): coefficients of real functions
-    res_m = cg_solve_async(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping,
-                           diag=diag if use_mean_cg_preconditioner else None, batched=False, hermitian=True)
-    if res_m is None:
-        res_m = cg_solve(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping,
-                         diag=diag if use_mean_cg_preconditioner else None, batched=False)[:2]
-    beta, mean_iters = res_m
-    beta_raw = beta.clone()
-    beta_s = ws * beta                                        # g = D beta
-    Tg = top.apply(beta_s)
-    if not adjoint:
-        z = plan_p.type2(beta_s, grid.shape)                 # F g, complex (N,)
-        alpha = (yd - z) / sig
-    lap("4_solve_cg")
-
-    # 5) term 2 -------------------------------------------------------------------------------
-    fadj_alpha = (Fy - Tg) / sig                               # = F* alpha without another pass over N
-    term2_kernel = torch.stack([vdot_m(fadj_alpha, Dp[:, i] * fadj_alpha) for i in range(kernel_hyper_count)]) \
-        if kernel_hyper_count else torch.zeros(0, dtype=torch.float64, device=dev)
-    if adjoint:
-        yy = float(y_norm_sq) if y_norm_sq is not None else shards.sum_scalars([vdot_real(yd, yd)], dev)[0]
-        y_z = vdot_m(Fy, beta_s)                               # Re sum_n y_n z_n          (0-dim device tensors:
-        z_z = vdot_m(beta_s, Tg)                               # |F g|^2 = <g, T g>         no host round trip)
-        if pointwise_alpha:
-            zr = plan_p.type2(beta_s, grid.shape, real_only=True)          # Re F g at the N points: one real gather
-            alpha_r = (yd - zr) / sig
-            a_norm, y_alpha = shards.sum_scalars([vdot_real(alpha_r, alpha_r), vdot_real(yd, alpha_r)], dev)
-        else:
-            a_norm = (yy - 2.0 * y_z + z_z) / (sig * sig)
-            y_alpha = (yy - y_z) / sig
+    # The M-scale tail in native launches when the estimator is the adjoint one: prepare | solve | T g | probes, two scaled
+    # Toeplitz products | batched solve | assemble -- about 35 launches per step instead of 118 (the step was bound by the host
+    # enqueueing 3 us torch kernels on 529-element vectors).  The literal / pointwise modes keep the torch sequence below.
+    fused = (adjoint and not pointwise_alpha and kernel_hyper_count <= 4 and Dp is not None and Dp.ndim == 2
+             and Dp.shape[1] == kernel_hyper_count and os.environ.get("EFGP_NO_FUSED_GRADIENT") is None)
+    if fused:
+        lap("3_toeplitz_setup")
+        (out_vec, grad, term1, term2, y_alpha, beta_raw, mean_iters, trace_iters, n_rhs, warm) = _gradient_tail_native(
+            kernel, grid, top, Fy, v, sig, N, N_local, cg_tol, early_stopping, mean_cg_init, use_mean_cg_preconditioner,
+            use_trace_cg_preconditioner, plan_p, shards, dev, int(trace_samples), trace_idx, variance_idx, probes_Z, probes_V,
+            probe_seed, y_norm_sq, yd, lap)
     else:
-        a_norm, y_alpha = shards.sum_scalars([vdot_real(alpha, alpha), vdot_real(yd, alpha)], dev)
-    if variance_idx is not None:
-        variance_scalar = float(kernel.get_hyper("variance"))
-        term2_kernel[variance_idx] = (y_alpha - sig * a_norm) / variance_scalar
-    term2 = torch.cat((term2_kernel, torch.as_tensor(a_norm, dtype=torch.float64, device=dev).reshape(1)))
-    lap("5_compute_term2")
+        diag = (_center_value(v) * ws.abs().pow(2).real + sig)
+        lap("3_toeplitz_setup")
 
-    # 6) Monte-Carlo trace probes ---------------------------------------------------------------
-    T = int(trace_samples)
-    K = len(trace_idx)
-    Z = None
-    rhs_k = None
-    if K > 0:
-        if probes_Z is not None:
-            Z = probes_Z.detach().to(device=dev, dtype=torch.float64).contiguous()
-            FZ = plan_p.type1(Z, grid.shape).reshape(T, M)                            # real rows, two per pass
-        elif adjoint:
-            if probe_seed is None:
-                probe_seed = shards.shared_seed(dev)              # one draw on rank 0: all shards use one Z stream
-            offset = shards.exclusive_offset(N_local, dev)
-            FZ = plan_p.type1_rademacher(probe_seed, T, grid.shape, index_offset=offset).reshape(T, M)
-        elif shards.active:
-            # sharded literal mode: Z[t, n] from (seed, t, GLOBAL index n) so the shards hold slices of one global
-            # probe matrix (per-rank torch generators would repeat or decorrelate blocks depending on their seeds)
-            if probe_seed is None:
-                probe_seed = shards.shared_seed(dev)
-            Z = rademacher_fill(dev, probe_seed, T, N_local, index_offset=shards.exclusive_offset(N_local, dev))
-            FZ = plan_p.type1(Z, grid.shape).reshape(T, M)
-        else:
-            Z = torch.empty((T, N_local), device=dev, dtype=torch.float64).bernoulli_(0.5).mul_(2).sub_(1)
-            FZ = plan_p.type1(Z, grid.shape).reshape(T, M)
-        shards.sum_(FZ)
-        DFZ = torch.stack([Dp[:, i] * FZ for i in trace_idx], dim=0).reshape(K * T, M)
+        # 4) mean solve ---------------------------------------------------------------------------
+        rhs = ws * Fy
+        warm = mean_cg_init is not None and tuple(mean_cg_init.shape) == tuple(rhs.shape)
+        b0 = mean_cg_init.detach().to(device=dev, dtype=torch.complex128) if warm else torch.zeros_like(rhs)
+        # rhs = D F*y of the real y (and a warm start from an earlier solve of the same kind): coefficients of real functions
+        res_m = cg_solve_async(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping,
+                               diag=diag if use_mean_cg_preconditioner else None, batched=False, hermitian=True)
+        if res_m is None:
+            res_m = cg_solve(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping,
+                             diag=diag if use_mean_cg_preconditioner else None, batched=False)[:2]
+        beta, mean_iters = res_m
+        beta_raw = beta.clone()
+        beta_s = ws * beta                                        # g = D beta
+        Tg = top.apply(beta_s)
         if not adjoint:
-            rhs_k = plan_p.type2(DFZ, grid.shape, batched=True)                       # (K*T, N) complex
-        B_k = ws * top.apply(DFZ)
-    else:
-        DFZ = torch.empty((0, M), dtype=torch.complex128, device=dev)
-        B_k = torch.empty((0, M), dtype=torch.complex128, device=dev)
-    if probes_V is not None:
-        V = probes_V.detach().to(device=dev, dtype=torch.float64).contiguous()
-    else:
-        V = torch.empty((T, M), device=dev, dtype=torch.float64).bernoulli_(0.5).mul_(2).sub_(1)
-        shards.broadcast_(V)                                      # replicated solves need ONE draw (rank 0's)
-    Vc = V.to(torch.complex128)
-    B_n = ws * top.apply(ws * Vc)
-    B_all = torch.cat((B_k, B_n), dim=0)
-    lap("6_monte_carlo_trace")
+            z = plan_p.type2(beta_s, grid.shape)                 # F g, complex (N,)
+            alpha = (yd - z) / sig
+        lap("4_solve_cg")
 
-    # 7) batched CG -----------------------------------------------------------------------------
-    res_t = cg_solve_async(top, ws, sig, 0, B_all, torch.zeros_like(B_all), cg_tol, early_stop=early_stopping,
-                           diag=diag if use_trace_cg_preconditioner else None, batched=True)
-    if res_t is None:
-        res_t = cg_solve(top, ws, sig, 0, B_all, torch.zeros_like(B_all), cg_tol, early_stop=early_stopping,
-                         diag=diag if use_trace_cg_preconditioner else None, batched=True)[:2]
-    Beta_all, trace_iters = res_t
-    lap("7_batch_cg_solve")
-
-    # 7.5) term 1 -------------------------------------------------------------------------------
-    term1 = torch.empty(num_hypers, dtype=torch.float64, device=dev)
-    Beta_k, Beta_n = Beta_all[:K * T], Beta_all[K * T:]
-    if K > 0:
+        # 5) term 2 -------------------------------------------------------------------------------
+        fadj_alpha = (Fy - Tg) / sig                               # = F* alpha without another pass over N
+        term2_kernel = torch.stack([vdot_m(fadj_alpha, Dp[:, i] * fadj_alpha) for i in range(kernel_hyper_count)]) \
+            if kernel_hyper_count else torch.zeros(0, dtype=torch.float64, device=dev)
         if adjoint:
-            # sum_n Z (F(D'F*Z) - F(ws beta))/sigma^2 = Re <F*Z, D'F*Z - ws beta> / sigma^2   (F*Z is already global)
-            diff = (DFZ - ws * Beta_k).reshape(K, T, M)
-            sums = [(FZ.conj() * diff[slot]).sum().real / sig for slot in range(K)]
+            yy = float(y_norm_sq) if y_norm_sq is not None else shards.sum_scalars([vdot_real(yd, yd)], dev)[0]
+            y_z = vdot_m(Fy, beta_s)                               # Re sum_n y_n z_n          (0-dim device tensors:
+            z_z = vdot_m(beta_s, Tg)                               # |F g|^2 = <g, T g>         no host round trip)
+            if pointwise_alpha:
+                zr = plan_p.type2(beta_s, grid.shape, real_only=True)          # Re F g at the N points: one real gather
+                alpha_r = (yd - zr) / sig
+                a_norm, y_alpha = shards.sum_scalars([vdot_real(alpha_r, alpha_r), vdot_real(yd, alpha_r)], dev)
+            else:
+                a_norm = (yy - 2.0 * y_z + z_z) / (sig * sig)
+                y_alpha = (yy - y_z) / sig
         else:
-            fwdB = plan_p.type2(ws * Beta_k, grid.shape, batched=True)
-            Alpha = (rhs_k - fwdB) / sig                                            # (K*T, N)
-            sums = [vdot_real(Z, Alpha[s_ * T:(s_ + 1) * T]) for s_ in range(K)]    # sum_t sum_n Z*Alpha
-            sums = shards.sum_scalars(sums, dev)
-        for slot, ki in enumerate(trace_idx):
-            term1[ki] = sums[slot] / T
-    t1_noise = N / sig - ((Vc.conj() * Beta_n).sum(dim=1).real / sig).mean()
-    if variance_idx is not None:
-        term1[variance_idx] = (N - sig * t1_noise) / float(kernel.get_hyper("variance"))
-    term1[-1] = t1_noise
-    lap("7.5_compute_alpha")
+            a_norm, y_alpha = shards.sum_scalars([vdot_real(alpha, alpha), vdot_real(yd, alpha)], dev)
+        if variance_idx is not None:
+            variance_scalar = float(kernel.get_hyper("variance"))
+            term2_kernel[variance_idx] = (y_alpha - sig * a_norm) / variance_scalar
+        term2 = torch.cat((term2_kernel, torch.as_tensor(a_norm, dtype=torch.float64, device=dev).reshape(1)))
+        lap("5_compute_term2")
 
-    grad = 0.5 * (term1 - term2)
-    lap("8_gradient_calculation")
+        # 6) Monte-Carlo trace probes ---------------------------------------------------------------
+        T = int(trace_samples)
+        K = len(trace_idx)
+        Z = None
+        rhs_k = None
+        if K > 0:
+            if probes_Z is not None:
+                Z = probes_Z.detach().to(device=dev, dtype=torch.float64).contiguous()
+                FZ = plan_p.type1(Z, grid.shape).reshape(T, M)                            # real rows, two per pass
+            elif adjoint:
+                if probe_seed is None:
+                    probe_seed = shards.shared_seed(dev)              # one draw on rank 0: all shards use one Z stream
+                offset = shards.exclusive_offset(N_local, dev)
+                FZ = plan_p.type1_rademacher(probe_seed, T, grid.shape, index_offset=offset).reshape(T, M)
+            elif shards.active:
+                # sharded literal mode: Z[t, n] from (seed, t, GLOBAL index n) so the shards hold slices of one global
+                # probe matrix (per-rank torch generators would repeat or decorrelate blocks depending on their seeds)
+                if probe_seed is None:
+                    probe_seed = shards.shared_seed(dev)
+                Z = rademacher_fill(dev, probe_seed, T, N_local, index_offset=shards.exclusive_offset(N_local, dev))
+                FZ = plan_p.type1(Z, grid.shape).reshape(T, M)
+            else:
+                Z = torch.empty((T, N_local), device=dev, dtype=torch.float64).bernoulli_(0.5).mul_(2).sub_(1)
+                FZ = plan_p.type1(Z, grid.shape).reshape(T, M)
+            shards.sum_(FZ)
+            DFZ = torch.stack([Dp[:, i] * FZ for i in trace_idx], dim=0).reshape(K * T, M)
+            if not adjoint:
+                rhs_k = plan_p.type2(DFZ, grid.shape, batched=True)                       # (K*T, N) complex
+            B_k = ws * top.apply(DFZ)
+        else:
+            DFZ = torch.empty((0, M), dtype=torch.complex128, device=dev)
+            B_k = torch.empty((0, M), dtype=torch.complex128, device=dev)
+        if probes_V is not None:
+            V = probes_V.detach().to(device=dev, dtype=torch.float64).contiguous()
+        else:
+            V = torch.empty((T, M), device=dev, dtype=torch.float64).bernoulli_(0.5).mul_(2).sub_(1)
+            shards.broadcast_(V)                                      # replicated solves need ONE draw (rank 0's)
+        Vc = V.to(torch.complex128)
+        B_n = ws * top.apply(ws * Vc)
+        B_all = torch.cat((B_k, B_n), dim=0)
+        lap("6_monte_carlo_trace")
+
+        # 7) batched CG -----------------------------------------------------------------------------
+        res_t = cg_solve_async(top, ws, sig, 0, B_all, torch.zeros_like(B_all), cg_tol, early_stop=early_stopping,
+                               diag=diag if use_trace_cg_preconditioner else None, batched=True)
+        if res_t is None:
+            res_t = cg_solve(top, ws, sig, 0, B_all, torch.zeros_like(B_all), cg_tol, early_stop=early_stopping,
+                             diag=diag if use_trace_cg_preconditioner else None, batched=True)[:2]
+        Beta_all, trace_iters = res_t
+        lap("7_batch_cg_solve")
+
+        # 7.5) term 1 -------------------------------------------------------------------------------
+        term1 = torch.empty(num_hypers, dtype=torch.float64, device=dev)
+        Beta_k, Beta_n = Beta_all[:K * T], Beta_all[K * T:]
+        if K > 0:
+            if adjoint:
+                # sum_n Z (F(D'F*Z) - F(ws beta))/sigma^2 = Re <F*Z, D'F*Z - ws beta> / sigma^2   (F*Z is already global)
+                diff = (DFZ - ws * Beta_k).reshape(K, T, M)
+                sums = [(FZ.conj() * diff[slot]).sum().real / sig for slot in range(K)]
+            else:
+                fwdB = plan_p.type2(ws * Beta_k, grid.shape, batched=True)
+                Alpha = (rhs_k - fwdB) / sig                                            # (K*T, N)
+                sums = [vdot_real(Z, Alpha[s_ * T:(s_ + 1) * T]) for s_ in range(K)]    # sum_t sum_n Z*Alpha
+                sums = shards.sum_scalars(sums, dev)
+            for slot, ki in enumerate(trace_idx):
+                term1[ki] = sums[slot] / T
+        t1_noise = N / sig - ((Vc.conj() * Beta_n).sum(dim=1).real / sig).mean()
+        if variance_idx is not None:
+            term1[variance_idx] = (N - sig * t1_noise) / float(kernel.get_hyper("variance"))
+        term1[-1] = t1_noise
+        lap("7.5_compute_alpha")
+
+        grad = 0.5 * (term1 - term2)
+        lap("8_gradient_calculation")
+
+        n_rhs = int(B_all.shape[0])
 
     if stats_out is not None:
         stats_out.update({
             "mean_cg_iters": int(mean_iters),
             "trace_cg_iters": int(trace_iters),
-            "trace_num_rhs": int(B_all.shape[0]),
+            "trace_num_rhs": int(n_rhs),
             "feature_count": int(M),
             "mtot": int(grid.mtot),
-            "trace_samples": int(T),
+            "trace_samples": int(trace_samples),
             "mean_cg_warm_start_used": bool(warm),
             "mean_cg_preconditioned": bool(use_mean_cg_preconditioner),
             "trace_cg_preconditioned": bool(use_trace_cg_preconditioner),
             "stage_sec": dict(stages),
         })
         stats_out["mean_beta"] = beta_raw.to(out_device)
-        stats_out["term1"] = term1.detach().cpu()
-        stats_out["term2"] = term2.detach().cpu()
+        if fused:
+            # grad | term1 | term2 | y.alpha live in one device vector: ONE read-back serves the diagnostics and the caller's
+            # host copy of the gradient (EFGPND.compute_gradients)
+            nh_ = int(term1.numel())
+            host_out = out_vec.cpu()
+            stats_out["term1"] = host_out[nh_:2 * nh_].clone()
+            stats_out["term2"] = host_out[2 * nh_:3 * nh_].clone()
+            stats_out["grad_host"] = host_out[:nh_].clone()
+        else:
+            stats_out["term1"] = term1.detach().cpu()
+            stats_out["term2"] = term2.detach().cpu()
 
     log_marginal = None
     if compute_log_marginal:
@@ -637,6 +660,80 @@ def efgpnd_gradient_batched(
 
     grad = grad.to(device=out_device, dtype=rdtype)
     return (grad, log_marginal) if compute_log_marginal else grad
+
+
+def _gradient_tail_native(kernel, grid, top, Fy, v, sig, N, N_local, cg_tol, early_stopping, mean_cg_init, use_mean_pc, use_trace_pc,
+                          plan_p, shards, dev, T, trace_idx, variance_idx, probes_Z, probes_V, probe_seed, y_norm_sq, yd, lap):
+    """Steps 4-8 of efgpnd_gradient_batched (adjoint estimator) in native launches; same quantities, same stage names.
+    Returns (out_vec, grad, term1, term2, y_alpha, beta, mean_iters, trace_iters, n_rhs, warm): out_vec is the device vector
+    grad | term1 | term2 | y.alpha of efgp_gradient_assemble, the next four are views of it."""
+    ws, Dp, M = grid.ws, grid.dprime, grid.M
+    K = len(trace_idx)
+    H = Dp.shape[1]
+    # 4) mean solve (reference :128-153): Jacobi diagonal and rhs = D F*y in one launch, solve, T g
+    vflat = v.reshape(-1)
+    cidx = 0
+    for s_ in v.shape:
+        cidx = cidx * s_ + (s_ - 1) // 2
+    want_diag = use_mean_pc or use_trace_pc
+    diag, rhs = gradient_prepare(ws, Fy, vflat[cidx:cidx + 1], sig, want_diag=want_diag)
+    warm = mean_cg_init is not None and tuple(mean_cg_init.shape) == tuple(rhs.shape)
+    b0 = mean_cg_init.detach().to(device=dev, dtype=torch.complex128) if warm else None
+    res_m = cg_solve_async(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping, diag=diag if use_mean_pc else None,
+                           batched=False, hermitian=True)
+    if res_m is None:
+        res_m = cg_solve(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping, diag=diag if use_mean_pc else None,
+                         batched=False)[:2]
+    beta, mean_iters = res_m
+    Tg = top.apply_scaled(beta, pre=ws)                         # T (D beta)
+    lap("4_solve_cg")
+    lap("5_compute_term2")                                      # term 2 is part of the assemble launch below
+
+    # 6) probes and the right-hand sides of the trace systems (reference :179-203)
+    B_all = torch.empty(((K + 1) * T, M), dtype=torch.complex128, device=dev)
+    FZ = None
+    if K > 0:
+        if probes_Z is not None:
+            Z = probes_Z.detach().to(device=dev, dtype=torch.float64).contiguous()
+            FZ = plan_p.type1(Z, grid.shape).reshape(T, M)
+        else:
+            if probe_seed is None:
+                probe_seed = shards.shared_seed(dev)
+            FZ = plan_p.type1_rademacher(probe_seed, T, grid.shape, index_offset=shards.exclusive_offset(N_local, dev)).reshape(T, M)
+        shards.sum_(FZ)
+        for slot, ki in enumerate(trace_idx):                   # D ws-scaled T (D'_i F*Z): D'_i rides in the pad, ws in the crop
+            top.apply_scaled(FZ, pre=Dp[:, ki].contiguous(), post=ws, out=B_all[slot * T:(slot + 1) * T])
+    if probes_V is not None:
+        V = probes_V.detach().to(device=dev, dtype=torch.float64).contiguous()
+    elif shards.active:
+        V = torch.empty((T, M), device=dev, dtype=torch.float64).bernoulli_(0.5).mul_(2).sub_(1)
+        shards.broadcast_(V)                                    # replicated solves need ONE draw (rank 0's)
+    else:
+        V = rademacher_fill(dev, int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()), T, M)
+    top.apply_scaled(V, pre=ws, post=ws, out=B_all[K * T:])
+    lap("6_monte_carlo_trace")
+
+    # 7) batched CG from zero (reference :205-236)
+    res_t = cg_solve_async(top, ws, sig, 0, B_all, None, cg_tol, early_stop=early_stopping, diag=diag if use_trace_pc else None,
+                           batched=True)
+    if res_t is None:
+        res_t = cg_solve(top, ws, sig, 0, B_all, None, cg_tol, early_stop=early_stopping, diag=diag if use_trace_pc else None,
+                         batched=True)[:2]
+    Beta_all, trace_iters = res_t
+    lap("7_batch_cg_solve")
+
+    # 7.5 / 8) every inner product of terms 1 and 2 and the final algebra: two launches, nothing read back
+    yy = float(y_norm_sq) if y_norm_sq is not None else float(shards.sum_scalars([vdot_real(yd, yd)], dev)[0])
+    variance = 1.0
+    if variance_idx is not None:
+        variance = dict(zip(kernel.hypers, kernel.get_hypers()))["variance"] if hasattr(kernel, "get_hypers") \
+            else float(kernel.get_hyper("variance"))
+    out = gradient_assemble(Fy, Tg, ws, beta, Dp, FZ, V, Beta_all.reshape(-1, M), variance_idx=variance_idx, trace_idx=trace_idx,
+                            sigmasq=sig, n_obs=N, yy=yy, variance=variance)
+    nh = H + 1
+    lap("7.5_compute_alpha")
+    lap("8_gradient_calculation")
+    return out, out[:nh], out[nh:2 * nh], out[2 * nh:3 * nh], out[3 * nh], beta, mean_iters, trace_iters, (K + 1) * T, warm
 
 
 def vdot_m(a, b):
@@ -966,12 +1063,15 @@ class EFGPND(nn.Module):
             log_marginal_steps=log_marginal_steps, shards=self._shards, domain_length=dd["L"], y_norm_sq=dd["yy"],
             points=dd["points"], **kwargs)
         self._last_gradient_beta = stats.pop("mean_beta", None)
+        grad_host = stats.pop("grad_host", None)       # the native tail reads grad | term1 | term2 back in one copy
         self.last_gradient_stats = stats
         grads, log_marginal = res if compute_log_marginal else (res, None)
         if grads.ndim == 0:
             grads = grads.unsqueeze(0)
         raw = self._gp_params.raw
         pos = self._gp_params.pos.detach()
+        if grad_host is not None and raw.device.type == "cpu":
+            grads = grad_host
         raw_grad = (grads.detach().to(device=raw.device, dtype=raw.dtype) * pos).clone()   # chain rule d/dlog
         if apply_gradients:
             with torch.no_grad():

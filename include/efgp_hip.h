@@ -152,6 +152,13 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
 int efgp_toeplitz_destroy(efgp_toeplitz_t* op);
 /* y[b] = T x[b]; x, y (nbatch, prod n_a) complex, may alias.  (ToeplitzND.__call__, :1331-1393) */
 int efgp_toeplitz_apply(efgp_toeplitz_t* op, const void* x, int nbatch, void* y, void* stream);
+/* y[b] = post .* T(pre .* x[b]): the products the hyper-gradient forms around T outside a solve -- T(ws .* beta),
+ * ws .* T(D' F*Z), ws .* T(ws .* V) (efgpnd.py:150-153, :186-189, :203) -- without materialising the scaled vectors.
+ * pre, post: (prod n_a) complex diagonals or NULL; x: (nbatch, prod n_a) complex, or real doubles when x_is_real;
+ * y complex, must not alias x.  On the 2-D 64 x 64 circulant grid (n_0 = n_1 <= 32) this is ONE launch (a workgroup per
+ * row, transforms in LDS); elsewhere pad / FFT / multiply / FFT / crop with the diagonals folded into pad and crop. */
+int efgp_toeplitz_apply_scaled(efgp_toeplitz_t* op, const void* x, int x_is_real, int nbatch, const void* pre, const void* post,
+                               void* y, void* stream);
 /* FFT grid shape chosen (d host int64), for inspection (ToeplitzND.fft_shape) */
 int efgp_toeplitz_fft_shape(efgp_toeplitz_t* op, int64_t* shape_out);
 
@@ -199,6 +206,31 @@ int efgp_spectral_weights_host(int kind, int dim, double nu, double lengthscale,
  * on `stream` instead of a host computation plus a staged upload. */
 int efgp_spectral_weights(int device, int kind, int dim, double nu, double lengthscale, double variance, double c0, double h, int mtot,
                           void* ws, void* dprime, void* stream);
+
+/* ---- M-scale tail of the hyper-parameter gradient: replaces the torch glue of efgpnd_gradient_batched ----------------
+ * (efgpnd.py:128-141, :155-176, :238-262; the adjoint form of this package: every N-length inner product of the reference
+ * evaluated in feature space).  All arrays live on `device`; nothing is read back.
+ *
+ * efgp_gradient_prepare: diag[k] = Re(*v_center) |ws[k]|^2 + sigmasq (the Jacobi diagonal, :128-133; v_center points at
+ * the centre element of the Toeplitz vector ON THE DEVICE) and rhs[k] = ws[k] fy[k] (:141).  diag or rhs may be NULL. */
+int efgp_gradient_prepare(int device, int64_t nmodes, const void* ws, const void* fy, const void* v_center, double sigmasq, double* diag,
+                          void* rhs, void* stream);
+/* efgp_gradient_assemble: with g = ws .* beta and tg = T g,
+ *     fa = (fy - tg) / sigmasq;  term2[i] = Re<fa, dprime[:, i] fa>;  y.z = Re<fy, g>;  |z|^2 = Re<g, tg>;
+ *     |alpha|^2 = (yy - 2 y.z + |z|^2) / sigmasq^2;  y.alpha = (yy - y.z) / sigmasq;                         (:155-176)
+ *     term1[trace_idx[s]] = (1/T) sum_t Re<fz[t], dprime[:, trace_idx[s]] fz[t] - ws .* beta_all[s T + t]> / sigmasq;
+ *     term1[noise] = n_obs / sigmasq - (1/T) sum_t Re<v[t], beta_all[n_trace T + t]> / sigmasq;               (:238-262)
+ *     the variance entries from the noise entries as the reference does; out = grad | term1 | term2 | y.alpha with
+ *     grad = (term1 - term2) / 2, each of length n_kernel_hypers + 1 (3 (n_kernel_hypers + 1) + 1 doubles, DEVICE).
+ * fy, tg, ws, beta: (M) complex; dprime: (M, n_kernel_hypers) complex; fz: (T, M) complex transforms of the data-space
+ * probes (may be NULL when n_trace = 0); v: (T, M) real feature-space probes; beta_all: ((n_trace + 1) T, M) complex
+ * solves; trace_idx: HOST array of n_trace hyper indices; variance_idx: index of the variance hyper or -1.
+ * n_kernel_hypers, n_trace <= 4.  Two launches: per-workgroup partial sums, then one workgroup adds them in a fixed
+ * order (reproducible) and does the scalar algebra. */
+int efgp_gradient_assemble(int device, int64_t nmodes, int nprobes, int n_kernel_hypers, int variance_idx, int n_trace,
+                           const int* trace_idx, const void* fy, const void* tg, const void* ws, const void* beta, const void* dprime,
+                           const void* fz, const double* v, const void* beta_all, double sigmasq, double n_obs, double yy, double variance,
+                           double* out, void* stream);
 
 /* efgp_cg_solve_async for systems whose vectors are Fourier coefficients of REAL functions on the symmetric mode grid:
  * every right-hand side and start vector satisfies u[-k] = conj u[k], ws is real and even, the Toeplitz vector comes
