@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void prepare_kernel(int64_t M, const double2* 
     const double c = v_center ? v_center->x : 0.0;
     for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
         const double2 w = ws[m];
-        if (diag) diag[m] = c * (w.x * w.x + w.y * w.y) + sig;
+        if (diag) diag[m] = __dadd_rn(__dmul_rn(c, __dmul_rn(w.x, w.x) + __dmul_rn(w.y, w.y)), sig);
         if (rhs) {
             const double2 f = fy[m];
             rhs[m] = make_double2(w.x * f.x - w.y * f.y, w.x * f.y + w.y * f.x);

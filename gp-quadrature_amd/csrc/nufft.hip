@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_pad_kernel(SpreadArgs a
 __global__ void rademacher_fill_kernel(unsigned long long seed, int64_t npts, int64_t index_offset, double* __restrict__ out) {
     const int row = blockIdx.y;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < npts; n += (int64_t)gridDim.x * blockDim.x)
-        out[(int64_t)row * npts + n] = efgp_rademacher(seed, row, n + index_offset);
+        out[(int64_t)row * npts + n] = efgp_rademacher(seed, row, (long long)((unsigned long long)n + (unsigned long long)index_offset));
 }
 
 // Fixed-point scales, one per channel: scale[0] = S0 (channel 0), [1] = 1/S0, [2] = S1 (channel 1), [3] = 1/S1,
@@ -1175,7 +1175,7 @@ __device__ __forceinline__ int64_t mode_of_slot(int64_t slot, int64_t nm, int mo
 //   part = 0: plain;  part = 1: (H[k] + conj(H[-k]))/2;  part = 2: (H[k] - conj(H[-k]))/(2i)
 //   part = 3: fine grid g holds real rows (2g, 2g+1): both parts are written, to out rows 2g and 2g+1
 __device__ __forceinline__ void deconvolve_body(const double2* __restrict__ fine, int64_t cells, const ModeGeom& m, int part,
-                                                double2* __restrict__ out, int batch) {
+                                                double2* __restrict__ out, int batch, int rows_limit = 1 << 30) {
     const double2* F = fine + (int64_t)batch * cells;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m.total; t += (int64_t)gridDim.x * blockDim.x) {
         int64_t rem = t;
@@ -1204,7 +1204,7 @@ __device__ __forceinline__ void deconvolve_body(const double2* __restrict__ fine
             const double2 r2 = make_double2(0.5 * (H.y + G.y) * f, 0.5 * (G.x - H.x) * f);
             if (part == 3) {
                 out[(int64_t)(2 * batch) * m.total + t] = r1;
-                out[(int64_t)(2 * batch + 1) * m.total + t] = r2;
+                if (2 * batch + 1 < rows_limit) out[(int64_t)(2 * batch + 1) * m.total + t] = r2;    // padded odd row count
                 continue;
             }
             r = part == 1 ? r1 : r2;
@@ -1213,8 +1213,8 @@ __device__ __forceinline__ void deconvolve_body(const double2* __restrict__ fine
     }
 }
 __global__ void deconvolve_kernel(const double2* __restrict__ fine, int64_t cells, ModeGeom m, int part,
-                                  double2* __restrict__ out) {
-    deconvolve_body(fine, cells, m, part, out, blockIdx.y);
+                                  double2* __restrict__ out, int rows_limit) {
+    deconvolve_body(fine, cells, m, part, out, blockIdx.y, rows_limit);
 }
 // the fit-time pair in one launch: blockIdx.y = 0 -> part 1 into out_a on box ma, 1 -> part 2 into out_b on box mb
 __global__ void deconvolve_pair_kernel(const double2* __restrict__ fine, int64_t cells, ModeGeom ma, double2* __restrict__ out_a,
@@ -2537,14 +2537,14 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
 }
 
 static int run_deconvolve(efgp_nufft_s* plan, WindowSet* w, const double2* fine, const int64_t* nm, int modeord,
-                          int part, int nbatch, void* out, hipStream_t stream) {
+                          int part, int nbatch, void* out, hipStream_t stream, int rows_limit = 1 << 30) {
     ModeGeom m = make_modes(plan, w, nm, modeord);
     int64_t cells = 1;
     for (int a = 0; a < 3; ++a) cells *= w->nf[a];
     int threads = 256;
     int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((m.total + threads - 1) / threads, 2048));
     hipLaunchKernelGGL(deconvolve_kernel, dim3(blocks, nbatch), dim3(threads), 0, stream, fine, cells, m, part,
-                       (double2*)out);
+                       (double2*)out, rows_limit);
     EFGP_HIP_CHECK(hipGetLastError());
     return EFGP_OK;
 }
@@ -2602,23 +2602,28 @@ static int type1_real_rows(efgp_nufft_s* plan, WindowSet* w, const double* c, bo
                            hipStream_t stream) {
     int64_t total = 1;
     for (int a = 0; a < plan->dim; ++a) total *= n_modes[a];
-    const int npair = nbatch / 2;
+    // Generated probes, odd count, 2-D: the last row rides as the real part of one more pair grid whose imaginary row (index nbatch)
+    // is generated and dropped -- one pass and one transform chain instead of two (6 launches; the 2-D spread costs the same per
+    // grid with one channel or two).  Rows read from memory have no row `nbatch` to read, and the 1-D / 3-D passes pay per channel.
+    const bool pad_odd = rng && (nbatch & 1) && nbatch > 1 && plan->dim == 2;
+    const int npair = pad_odd ? (nbatch + 1) / 2 : nbatch / 2;
     double2* fine = nullptr;
     if (npair > 0) {
         int rc = spread_and_fft(plan, w, c, rng ? STR_RNG_PAIR : STR_REAL_PAIR, npair, isign, stream, &fine, seed, index_offset);
         if (rc != EFGP_OK) return rc;
         // for isign = +1 the roles of k and -k swap in the Hermitian split; conjugating H handles both signs:
         // the split below assumes the forward (isign = -1) transform, which is what the reference uses for type 1
-        rc = run_deconvolve(plan, w, fine, n_modes, modeord, 3, npair, out, stream);
+        rc = run_deconvolve(plan, w, fine, n_modes, modeord, 3, npair, out, stream, nbatch);
         if (rc != EFGP_OK) return rc;
     }
-    if (nbatch & 1) {
+    if ((nbatch & 1) && !pad_odd) {
         const int last = nbatch - 1;
-        // single real row: offset the source / the RNG row so that it addresses row `last`
         int rc;
         if (rng) {
-            // STR_RNG uses the fine-grid index as row: shift the seed domain by generating row `last` explicitly
-            rc = spread_and_fft(plan, w, nullptr, STR_RNG, 1, isign, stream, &fine, seed ^ efgp_mix64(0xA5A5A5A5ull + (unsigned long long)last), index_offset);
+            // STR_RNG takes the fine-grid index (0 here) as the row: row `last` of the same seed is row 0 at the point index shifted
+            // by last * kRowStride (efgp_rademacher hashes row * kRowStride + index in wrapping 64-bit arithmetic)
+            rc = spread_and_fft(plan, w, nullptr, STR_RNG, 1, isign, stream, &fine, seed,
+                                (int64_t)((unsigned long long)index_offset + (unsigned long long)last * kRademacherRowStride));
         } else {
             rc = spread_and_fft(plan, w, c + (int64_t)last * plan->npts, STR_REAL, 1, isign, stream, &fine);
         }
@@ -2678,17 +2683,8 @@ int efgp_rademacher_fill(int device, uint64_t seed, int64_t index_offset, int nb
     DeviceGuard guard(device);
     hipStream_t stream = (hipStream_t)stream_;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((npts + 255) / 256, 4096));
-    // rows of an odd last batch element are generated with the same seed derivation as type1_real_rows
-    const int npair_rows = (nbatch / 2) * 2;
-    if (npair_rows > 0)
-        hipLaunchKernelGGL(rademacher_fill_kernel, dim3(blocks, npair_rows), dim3(256), 0, stream, (unsigned long long)seed, npts,
-                           index_offset, out);
-    if (nbatch & 1) {
-        const int last = nbatch - 1;
-        hipLaunchKernelGGL(rademacher_fill_kernel, dim3(blocks, 1), dim3(256), 0, stream,
-                           (unsigned long long)seed ^ efgp_mix64(0xA5A5A5A5ull + (unsigned long long)last), npts, index_offset,
-                           out + (int64_t)last * npts);
-    }
+    hipLaunchKernelGGL(rademacher_fill_kernel, dim3(blocks, nbatch), dim3(256), 0, stream, (unsigned long long)seed, npts, index_offset,
+                       out);
     EFGP_HIP_CHECK(hipGetLastError());
     return EFGP_OK;
 }
@@ -2727,7 +2723,7 @@ int efgp_nufft_type1_pair(efgp_nufft_t* plan, const double* y, const int64_t* n_
         int threads = 256;
         int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((m.total + threads - 1) / threads, 2048));
         hipLaunchKernelGGL(deconvolve_kernel, dim3(blocks, 1), dim3(threads), 0, stream, (const double2*)fine, cells, m,
-                           part, (double2*)out);
+                           part, (double2*)out, 1 << 30);
         EFGP_HIP_CHECK(hipGetLastError());
         return EFGP_OK;
     };

@@ -31,8 +31,11 @@ __host__ __device__ __forceinline__ unsigned long long efgp_mix64(unsigned long 
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
+constexpr unsigned long long kRademacherRowStride = 0xD1342543DE82EF95ull;
+// probe (seed, row, n) = sign bit of a hash of row * kRademacherRowStride + n in WRAPPING 64-bit arithmetic: row r at index n is
+// row 0 at index n + r * kRademacherRowStride (type1_real_rows uses that for a single odd row)
 __host__ __device__ __forceinline__ double efgp_rademacher(unsigned long long seed, long long row, long long n) {
-    const unsigned long long r = efgp_mix64(seed ^ efgp_mix64((unsigned long long)row * 0xD1342543DE82EF95ull +
+    const unsigned long long r = efgp_mix64(seed ^ efgp_mix64((unsigned long long)row * kRademacherRowStride +
                                                              (unsigned long long)n));
     return (r >> 63) ? 1.0 : -1.0;
 }
@@ -61,10 +64,10 @@ __device__ __forceinline__ void fetch_strength(const StrengthSrc& s, int g, int6
             c0 = s.c[(int64_t)(2 * g) * s.npts + n];
             c1 = s.c[(int64_t)(2 * g + 1) * s.npts + n];
             break;
-        case STR_RNG: c0 = efgp_rademacher(s.seed, g, n + s.index_offset); break;
+        case STR_RNG: c0 = efgp_rademacher(s.seed, g, (long long)((unsigned long long)n + (unsigned long long)s.index_offset)); break;
         case STR_RNG_PAIR:
-            c0 = efgp_rademacher(s.seed, 2 * g, n + s.index_offset);
-            c1 = efgp_rademacher(s.seed, 2 * g + 1, n + s.index_offset);
+            c0 = efgp_rademacher(s.seed, 2 * g, (long long)((unsigned long long)n + (unsigned long long)s.index_offset));
+            c1 = efgp_rademacher(s.seed, 2 * g + 1, (long long)((unsigned long long)n + (unsigned long long)s.index_offset));
             break;
         default: break;
     }

@@ -356,6 +356,33 @@ class LazyIterations:
     def __repr__(self):
         return str(int(self))
 
+    # number-like: callers of the reference's API compare, add and format iteration counts
+    def __eq__(self, other):
+        return int(self) == other
+
+    def __lt__(self, other):
+        return int(self) < other
+
+    def __le__(self, other):
+        return int(self) <= other
+
+    def __gt__(self, other):
+        return int(self) > other
+
+    def __ge__(self, other):
+        return int(self) >= other
+
+    def __hash__(self):
+        return hash(int(self))
+
+    def __add__(self, other):
+        return int(self) + other
+
+    __radd__ = __add__
+
+    def __format__(self, spec):
+        return format(int(self), spec)
+
 
 def cg_solve_async(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=True, diag=None, batched=None,
                    hermitian=False):

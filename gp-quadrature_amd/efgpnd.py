@@ -386,6 +386,13 @@ def _center_value(v: torch.Tensor) -> torch.Tensor:
     return v[tuple((s - 1) // 2 for s in v.shape)].real
 
 
+def _center_flat(v: torch.Tensor) -> int:
+    idx = 0
+    for s in v.shape:
+        idx = idx * s + (s - 1) // 2
+    return idx
+
+
 # ======================================================================================
 # hyper-parameter gradient (reference: efgpnd.py:17-317)
 # ======================================================================================
@@ -498,7 +505,9 @@ def efgpnd_gradient_batched(
             use_trace_cg_preconditioner, plan_p, shards, dev, int(trace_samples), trace_idx, variance_idx, probes_Z, probes_V,
             probe_seed, y_norm_sq, yd, lap)
     else:
-        diag = (_center_value(v) * ws.abs().pow(2).real + sig)
+        # the Jacobi diagonal v[0] |ws|^2 + sigma^2 (:128-133) from the same launch as the native tail: a diagonal that differs in
+        # the last bit sends a CG run that ends at its iteration cap (ill-conditioned D T D) to a visibly different iterate
+        diag = gradient_prepare(ws, None, v.reshape(-1)[_center_flat(v):_center_flat(v) + 1], sig, want_rhs=False)[0]
         lap("3_toeplitz_setup")
 
         # 4) mean solve ---------------------------------------------------------------------------
@@ -622,8 +631,10 @@ def efgpnd_gradient_batched(
 
     if stats_out is not None:
         stats_out.update({
-            "mean_cg_iters": int(mean_iters),
-            "trace_cg_iters": int(trace_iters),
+            # iteration counts of the asynchronous solves stay on the device until somebody reads them (int(...), comparison,
+            # formatting all do): two blocking device-to-host copies per step otherwise
+            "mean_cg_iters": mean_iters,
+            "trace_cg_iters": trace_iters,
             "trace_num_rhs": int(n_rhs),
             "feature_count": int(M),
             "mtot": int(grid.mtot),
@@ -671,12 +682,8 @@ def _gradient_tail_native(kernel, grid, top, Fy, v, sig, N, N_local, cg_tol, ear
     K = len(trace_idx)
     H = Dp.shape[1]
     # 4) mean solve (reference :128-153): Jacobi diagonal and rhs = D F*y in one launch, solve, T g
-    vflat = v.reshape(-1)
-    cidx = 0
-    for s_ in v.shape:
-        cidx = cidx * s_ + (s_ - 1) // 2
-    want_diag = use_mean_pc or use_trace_pc
-    diag, rhs = gradient_prepare(ws, Fy, vflat[cidx:cidx + 1], sig, want_diag=want_diag)
+    cidx = _center_flat(v)
+    diag, rhs = gradient_prepare(ws, Fy, v.reshape(-1)[cidx:cidx + 1], sig, want_diag=use_mean_pc or use_trace_pc)
     warm = mean_cg_init is not None and tuple(mean_cg_init.shape) == tuple(rhs.shape)
     b0 = mean_cg_init.detach().to(device=dev, dtype=torch.complex128) if warm else None
     res_m = cg_solve_async(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping, diag=diag if use_mean_pc else None,
@@ -943,7 +950,7 @@ class EFGPND(nn.Module):
         self._fitted = False
         self._cached_params = {}
         self._registered_optimizers = []
-        self.last_gradient_stats = {}
+        self._last_gradient_stats = {}
         self._last_gradient_beta = None
         self._last_fit_stats = {}
         self._devdata = None
@@ -974,6 +981,15 @@ class EFGPND(nn.Module):
     @property
     def sigmasq(self) -> torch.Tensor:
         return self._gp_params.sig2
+
+    @property
+    def last_gradient_stats(self) -> Dict:
+        """Diagnostics of the last gradient step (reading them waits for its asynchronous solves)."""
+        st = self._last_gradient_stats
+        for key in ("mean_cg_iters", "trace_cg_iters"):
+            if key in st and not isinstance(st[key], int):
+                st[key] = int(st[key])
+        return st
 
     @property
     def last_fit_stats(self) -> Dict:
@@ -1064,7 +1080,7 @@ class EFGPND(nn.Module):
             points=dd["points"], **kwargs)
         self._last_gradient_beta = stats.pop("mean_beta", None)
         grad_host = stats.pop("grad_host", None)       # the native tail reads grad | term1 | term2 back in one copy
-        self.last_gradient_stats = stats
+        self._last_gradient_stats = stats
         grads, log_marginal = res if compute_log_marginal else (res, None)
         if grads.ndim == 0:
             grads = grads.unsqueeze(0)
