@@ -158,7 +158,10 @@ def test_type1_lds_path_is_bitwise_reproducible():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
-@pytest.mark.parametrize("d,nm,N,B", [(2, 23, 5000, 5), (2, 141, 40000, 2), (1, 35, 3000, 3), (3, 9, 2000, 1)])
+# odd probe counts: 2-D pads the last row into one more pair grid (one pass); 1-D / 3-D and a lone probe run it as a single row
+# whose hash index is shifted by last * row stride -- either way row r is hash(seed, r, index)
+@pytest.mark.parametrize("d,nm,N,B", [(2, 23, 5000, 5), (2, 141, 40000, 2), (1, 35, 3000, 3), (3, 9, 2000, 1), (3, 9, 2000, 3),
+                                      (2, 23, 5000, 1), (2, 23, 5000, 7)])
 def test_type1_rademacher_equals_type1_of_filled_probes(d, nm, N, B):
     from efgp_hip import NufftPlan, rademacher_fill
     from oracle import efgp_oracle as O
