@@ -313,9 +313,8 @@ int efgp_kernel_timing_read(const char* name, double* total_ms_out, int64_t* lau
 int efgp_window_width(double tol, double sigma) { return es_width_for_tol(tol, sigma); }
 
 int64_t efgp_fine_grid_size(int64_t n_modes, double tol) {
-    (void)tol;
     if (n_modes < 1) return 0;
-    return next_smooth_even(2 * n_modes);
+    return es_fine_size(n_modes, tol, 2);
 }
 
 int efgp_window_eval(double tol, double sigma, double X, int64_t* first_cell_out, double* vals_out, int* w_out,

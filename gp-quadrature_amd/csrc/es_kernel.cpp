@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace efgp {
@@ -168,6 +169,37 @@ int64_t next_smooth_even(int64_t n) {
         while (m % 5 == 0) m /= 5;
         if (m == 1) return n;
     }
+}
+
+// Fine-grid size for n_modes modes.
+// Small grids take the next size of the COARSE ladder 32, 48, 64, 96, 128, 192, ... (2^k and 3 * 2^k): a hyper-parameter
+// optimisation changes mtot every few steps, every new FFT length costs a rocFFT runtime compilation (0.6-1.2 s per length,
+// measured: tools/train_loop_steps.py -- a 2.3 s stall at each of mtot 23 -> 21 -> 19 -> 17 against 0.5 ms steps), and on the
+// ladder all of mtot 17..23 share the lengths 96 (Toeplitz box) and 48 (probes).  The transform of so small a grid costs
+// microseconds whatever its size, the spreaders' work per point does not depend on it, and a larger upsampling ratio only
+// narrows the window.  Larger grids (where cells cost memory and FFT time: beyond 512 per axis, 96 in 3-D) keep the dense
+// choice: among the 2^a3^b5^c even sizes in [2 n, 2.5 n] the one that needs the narrowest window (ties: the smallest grid).
+int64_t es_fine_size(int64_t n_modes, double tol, int dim) {
+    const int64_t lo = std::max<int64_t>(32, next_smooth_even(2 * n_modes));
+    const int64_t hi = std::max<int64_t>(lo, (5 * n_modes) / 2);
+    int64_t best = lo;
+    int best_w = es_width_for_tol(tol, (double)lo / (double)n_modes);
+    for (int64_t c = next_smooth_even(lo + 2); c <= hi; c = next_smooth_even(c + 2)) {
+        const int w = es_width_for_tol(tol, (double)c / (double)n_modes);
+        if (w < best_w) {
+            best_w = w;
+            best = c;
+        }
+    }
+    const int64_t coarse_limit = dim >= 3 ? 96 : 512;
+    if (2 * n_modes <= coarse_limit && std::getenv("EFGP_DENSE_FINE_SIZES") == nullptr) {
+        // the first ladder size that needs no wider a window than the dense choice (the width falls with the ratio)
+        for (int64_t p2 = 32;; p2 *= 2) {
+            for (int64_t c : {p2, p2 + p2 / 2})
+                if (c >= 2 * n_modes && es_width_for_tol(tol, (double)c / (double)n_modes) <= best_w) return c;
+        }
+    }
+    return best;
 }
 
 }  // namespace efgp

@@ -1577,23 +1577,6 @@ struct efgp_nufft_s {
 
 namespace efgp {
 
-// Fine-grid size for n_modes modes: among the 2^a3^b5^c even sizes in [2 n, 2.5 n] take the one that
-// needs the narrowest window (ties: the smallest grid); never below 32 cells.
-static int64_t choose_fine_size(int64_t n_modes, double tol) {
-    const int64_t lo = std::max<int64_t>(32, next_smooth_even(2 * n_modes));
-    const int64_t hi = std::max<int64_t>(lo, (5 * n_modes) / 2);
-    int64_t best = lo;
-    int best_w = es_width_for_tol(tol, (double)lo / (double)n_modes);
-    for (int64_t c = next_smooth_even(lo + 2); c <= hi; c = next_smooth_even(c + 2)) {
-        const int w = es_width_for_tol(tol, (double)c / (double)n_modes);
-        if (w < best_w) {
-            best_w = w;
-            best = c;
-        }
-    }
-    return best;
-}
-
 static void free_window(WindowSet* w) {
     if (!w) return;
     if (w->d_coef) (void)hipFree(w->d_coef);
@@ -1621,7 +1604,7 @@ static int get_window(efgp_nufft_s* plan, const int64_t* n_modes, hipStream_t st
     double sigma_min = 1e30;
     for (int a = 0; a < 3; ++a) {
         w->nm[a] = a < d ? n_modes[a] : 1;
-        w->nf[a] = a < d ? choose_fine_size(n_modes[a], plan->tol) : 1;
+        w->nf[a] = a < d ? es_fine_size(n_modes[a], plan->tol, d) : 1;
         if (a < d) sigma_min = std::min(sigma_min, (double)w->nf[a] / (double)w->nm[a]);
     }
     es_make_params(plan->tol, sigma_min, &w->p);

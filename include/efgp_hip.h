@@ -63,7 +63,10 @@ int efgp_window_width(double tol, double sigma);
  * Horner polynomials the device kernels use.  vals_out holds >= 16 doubles (host). */
 int efgp_window_eval(double tol, double sigma, double X, int64_t* first_cell_out, double* vals_out,
                      int* w_out, double* beta_out);
-/* fine-grid size the library will use for n_modes modes at tolerance tol (per dimension) */
+/* fine-grid size a 1-D / 2-D plan uses for n_modes modes per axis at tolerance tol.  Up to 512 cells per axis (96 in 3-D)
+ * sizes come from the ladder 32, 48, 64, 96, 128, 192, ... (2^k, 3 * 2^k): the first one >= 2 n_modes whose window is no
+ * wider than the best 2^a3^b5^c size in [2, 2.5] n_modes would need; larger grids take that dense choice.  (A training
+ * loop changes n_modes every few steps and every new FFT length is a runtime compilation in rocFFT.) */
 int64_t efgp_fine_grid_size(int64_t n_modes, double tol);
 /* out[i] = Fourier-side correction for CMCL mode i (host array of n_modes doubles) */
 int efgp_window_deconv(double tol, int64_t nf, int64_t n_modes, double* out);

@@ -34,6 +34,44 @@ def test_window_width_monotone():
     assert lib.efgp_fine_grid_size(23, 1e-6) % 2 == 0
 
 
+def test_fine_grid_sizes_sit_on_a_short_ladder():
+    """Small fine grids take 2^k / 3 * 2^k sizes only: every new FFT length is a runtime compilation in rocFFT (0.6-2.5 s,
+    tools/train_loop_steps.py), and a hyper-parameter optimisation walks through many mode counts.  The ladder size is the
+    first one >= 2 n whose window is no wider than the best dense (2^a 3^b 5^c in [2 n, 2.5 n]) size would need."""
+    lib = _lib()
+
+    def smooth(n):
+        n = max(2, n + (n & 1))
+        while True:
+            m = n
+            for p in (2, 3, 5):
+                while m % p == 0:
+                    m //= p
+            if m == 1:
+                return n
+            n += 2
+
+    for tol in (6e-8, 1e-5, 1e-9):
+        seen = set()
+        for n in range(1, 257):
+            nf = lib.efgp_fine_grid_size(n, tol)
+            assert nf >= max(32, 2 * n)
+            m = nf
+            while m % 2 == 0:
+                m //= 2
+            assert m in (1, 3), (n, nf)                       # 2^k or 3 * 2^k
+            lo = max(32, smooth(2 * n))
+            w_dense = min(lib.efgp_window_width(tol, c / n) for c in range(lo, max(lo, 5 * n // 2) + 1, 2) if smooth(c) == c)
+            assert lib.efgp_window_width(tol, nf / n) <= w_dense
+            assert nf <= 4 * max(16, n)                        # at most two ladder steps above the minimum 2 n
+            seen.add(nf)
+        assert len(seen) <= 10                                 # 256 mode counts, ten FFT lengths
+        # the training run of the bench model (mtot 23 -> 17): one length for the Toeplitz boxes, one for the probes
+        assert {lib.efgp_fine_grid_size(4 * m + 1, 6e-8) for m in (8, 9, 10, 11)} == {96}
+        assert {lib.efgp_fine_grid_size(2 * m + 1, 1e-5) for m in (8, 9, 10, 11)} == {48}
+    assert lib.efgp_fine_grid_size(301, 6e-8) % 2 == 0 and lib.efgp_fine_grid_size(301, 6e-8) < 768     # large grids: dense choice
+
+
 @pytest.mark.parametrize("tol", [1e-3, 1e-6, 6e-8, 1e-10, 1e-13])
 def test_window_polynomials_match_closed_form(tol):
     lib = _lib()
