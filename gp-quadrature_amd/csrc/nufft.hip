@@ -1234,6 +1234,168 @@ __global__ void deconvolve_pair_kernel(const double2* __restrict__ fine, int64_t
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Small 2-D fine grids straight from the MFMA spreader's int64 accumulator to the modes, ONE launch: fixed-point
+// conversion, pruned dense DFT (only the mode box is computed: for n modes out of nf >= 2 n cells that is cheaper than the
+// full transform), Hermitian split and correction factors.  Replaces reduce_slabs | FFT rows | FFT columns | deconvolve
+// (four dependent 4-5 us launches, 18 us per type-1 transform) and keeps rocFFT -- whose kernels are compiled at run time,
+// 0.5-2 s per new length -- off the fit / gradient path of 2-D models with mtot <= 64.
+//   H[k0][k1] = sum_x0 w0^(k0 x0) sum_x1 w1^(k1 x1) G[x0][x1],  G = ch0 + i ch1,  w_a = exp(sign 2 pi i / nf_a)
+// A workgroup owns the four rows k0 = +-j, +-(j+1) (the split needs H[k] and H[-k] together):
+//   stage 1: B[r][x1] = sum_x0 G[x0][x1] w0^(k_r x0): lane = x1 (coalesced int64 loads), two x0 classes per workgroup;
+//   stage 2: H[r][k1] = sum_x1 B[r][x1] w1^(k1 x1) for k1 in [-h1, h1] out of LDS;
+//   epilogue: parts as in deconvolve_body (0 plain, 3 real row pairs, 4 = the fit's (F*y, Toeplitz vector) pair on two boxes).
+// The accumulator must be left zeroed for the next pass: the LAST workgroup to have finished reading it (arrival counter)
+// clears it.  Sums of <= 128 terms with exact table twiddles: the result differs from the FFT's by rounding only.
+constexpr int kG2MMaxNf = 128;
+constexpr int kG2MMaxH = 32;                 // modes k in [-32, 32] per axis
+constexpr int kG2MThreads = 256;
+
+struct G2MArgs {
+    long long* gacc;          // [nbatch][channels][nf0 * nf1]
+    const double* scale;      // fixed-point block: [1] = 1/S0, [3] = 1/S1, [4] = channel-0 norm
+    int channels, nf0, nf1, h0, h1;
+    int part;                 // 0, 3, or 4 (pair: part 1 on box ma -> out_a, part 2 on box mb -> out_b)
+    int rows_limit;
+    int sign;                 // -1 forward, +1 backward
+    ModeGeom ma, mb;
+    double2* out_a;
+    double2* out_b;
+    unsigned int* ticket;     // zero on entry, zero again on exit
+    unsigned int total_wgs;
+    long long acc_words;      // words to clear
+};
+
+__device__ __forceinline__ bool g2m_slot(const ModeGeom& m, int k0, int k1, int64_t* t, double* f) {
+    const int lo0 = -(int)(m.nm[0] / 2), hi0 = (int)((m.nm[0] - 1) / 2), lo1 = -(int)(m.nm[1] / 2), hi1 = (int)((m.nm[1] - 1) / 2);
+    if (k0 < lo0 || k0 > hi0 || k1 < lo1 || k1 > hi1) return false;
+    const int64_t s0 = m.modeord == 0 ? k0 - lo0 : (k0 >= 0 ? k0 : k0 + m.nm[0]);
+    const int64_t s1 = m.modeord == 0 ? k1 - lo1 : (k1 >= 0 ? k1 : k1 + m.nm[1]);
+    *t = s0 * m.nm[1] + s1;
+    *f = m.fac[0][k0 - lo0] * m.fac[1][k1 - lo1];
+    return true;
+}
+
+__global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
+    __shared__ double2 T0[kG2MMaxNf], T1[kG2MMaxNf];
+    __shared__ double2 Bp[2][4][kG2MMaxNf];
+    __shared__ double2 Hs[4][2 * kG2MMaxH + 2];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int j0 = 2 * (int)blockIdx.x;
+    for (int q = tid; q < a.nf0; q += kG2MThreads) {
+        double sn, cs;
+        sincospi((double)a.sign * 2.0 * (double)q / (double)a.nf0, &sn, &cs);
+        T0[q] = make_double2(cs, sn);
+    }
+    for (int q = tid; q < a.nf1; q += kG2MThreads) {
+        double sn, cs;
+        sincospi((double)a.sign * 2.0 * (double)q / (double)a.nf1, &sn, &cs);
+        T1[q] = make_double2(cs, sn);
+    }
+    const int kr[4] = {j0, -j0, j0 + 1, -(j0 + 1)};
+    const int64_t cells = (int64_t)a.nf0 * a.nf1;
+    const long long* g0 = a.gacc + (int64_t)b * a.channels * cells;
+    const double s0 = a.scale[1], s1 = a.scale[3];
+    __syncthreads();
+    // stage 1
+    {
+        const int x1 = tid & (kG2MMaxNf - 1), grp = tid >> 7;
+        double2 acc[4];
+        int idx[4], step[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[r] = make_double2(0.0, 0.0);
+            int st = (2 * kr[r]) % a.nf0;
+            if (st < 0) st += a.nf0;
+            step[r] = st;
+            int i0 = (kr[r] * grp) % a.nf0;
+            if (i0 < 0) i0 += a.nf0;
+            idx[r] = i0;
+        }
+        if (x1 < a.nf1) {
+            for (int x0 = grp; x0 < a.nf0; x0 += 2) {
+                const double re = (double)g0[(int64_t)x0 * a.nf1 + x1] * s0;
+                const double im = a.channels == 2 ? (double)g0[cells + (int64_t)x0 * a.nf1 + x1] * s1 : 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double2 tw = T0[idx[r]];
+                    acc[r].x += re * tw.x - im * tw.y;
+                    acc[r].y += re * tw.y + im * tw.x;
+                    idx[r] += step[r];
+                    if (idx[r] >= a.nf0) idx[r] -= a.nf0;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Bp[grp][r][x1] = acc[r];
+    }
+    __syncthreads();
+    // every load of the accumulator by this workgroup has been consumed: arrive; the last one clears it
+    if (tid == 0) {
+        __threadfence();
+        s_last = atomicAdd(a.ticket, 1u) == a.total_wgs - 1u ? 1 : 0;
+    }
+    for (int o = tid; o < 4 * a.nf1; o += kG2MThreads) {
+        const int r = o / a.nf1, x = o - r * a.nf1;
+        const double2 u = Bp[0][r][x], v = Bp[1][r][x];
+        Bp[0][r][x] = make_double2(u.x + v.x, u.y + v.y);
+    }
+    __syncthreads();
+    if (s_last) {
+        for (long long i = tid; i < a.acc_words; i += kG2MThreads) a.gacc[i] = 0;
+        if (tid == 0) *a.ticket = 0u;
+    }
+    // stage 2
+    const int nk1 = 2 * a.h1 + 1;
+    for (int o = tid; o < 4 * nk1; o += kG2MThreads) {
+        const int r = o / nk1, c = o - r * nk1;
+        int st = (c - a.h1) % a.nf1;
+        if (st < 0) st += a.nf1;
+        int idx = 0;
+        double sx = 0.0, sy = 0.0;
+        for (int x = 0; x < a.nf1; ++x) {
+            const double2 bv = Bp[0][r][x], tw = T1[idx];
+            sx += bv.x * tw.x - bv.y * tw.y;
+            sy += bv.x * tw.y + bv.y * tw.x;
+            idx += st;
+            if (idx >= a.nf1) idx -= a.nf1;
+        }
+        Hs[r][c] = make_double2(sx, sy);
+    }
+    __syncthreads();
+    // epilogue
+    for (int o = tid; o < 4 * nk1; o += kG2MThreads) {
+        const int r = o / nk1, c = o - r * nk1;
+        const int j = r < 2 ? j0 : j0 + 1;
+        if (j > a.h0 || (j == 0 && (r & 1))) continue;            // beyond the box; -0 duplicates +0
+        const int k0 = kr[r], k1 = c - a.h1;
+        const double2 H = Hs[r][c], G = Hs[r ^ 1][nk1 - 1 - c];    // modes k and -k
+        int64_t t;
+        double f;
+        if (a.part == 0) {
+            if (g2m_slot(a.ma, k0, k1, &t, &f)) a.out_a[(int64_t)b * a.ma.total + t] = make_double2(H.x * f, H.y * f);
+            continue;
+        }
+        if (g2m_slot(a.ma, k0, k1, &t, &f)) {
+            double2 r1 = make_double2(0.5 * (H.x + G.x) * f, 0.5 * (H.y - G.y) * f);
+            if (a.part == 3) {
+                a.out_a[(int64_t)(2 * b) * a.ma.total + t] = r1;
+                if (2 * b + 1 < a.rows_limit)
+                    a.out_a[(int64_t)(2 * b + 1) * a.ma.total + t] = make_double2(0.5 * (H.y + G.y) * f, 0.5 * (G.x - H.x) * f);
+            } else {
+                const double norm0 = a.scale[4];                   // channel 0 was carried normalised (fixed_scale_kernel)
+                if (norm0 != 1.0) {
+                    r1.x *= norm0;
+                    r1.y *= norm0;
+                }
+                a.out_a[t] = r1;
+            }
+        }
+        if (a.part == 4 && g2m_slot(a.mb, k0, k1, &t, &f)) a.out_b[t] = make_double2(0.5 * (H.y + G.y) * f, 0.5 * (G.x - H.x) * f);
+    }
+}
+
 // type 2: fine[b][k mod nf] = fac * f[b][slot] (* mul[slot] when given), zero outside the mode box: every
 // fine cell is written, so the grid needs no memset.  herm != 0 stores the Hermitian part
 // (f[k] + conj f[-k])/2, whose transform is the real part of the full one (real_only outputs).
@@ -2184,10 +2346,31 @@ static SortedLevel* pick_level(efgp_nufft_s* plan, const WindowSet* w, const Gri
     return lvl;
 }
 
+// What the caller wants from the transformed grid; when the pass runs on the MFMA spreader's single int64 grid and the grid
+// is small, spread_and_fft hands the accumulator straight to grid_to_modes_kernel and sets `done` (no fine grid is produced).
+struct G2MRequest {
+    int part = 0;              // 0 | 3 | 4 (see G2MArgs)
+    int rows_limit = 1 << 30;
+    ModeGeom ma, mb;
+    void* out_a = nullptr;
+    void* out_b = nullptr;
+    bool done = false;
+};
+
+static bool g2m_eligible(const efgp_nufft_s* plan, const GridGeom& g, const G2MRequest* req) {
+    if (!req || plan->dim != 2 || std::getenv("EFGP_NO_GRID_TO_MODES")) return false;
+    if (g.nf[0] > kG2MMaxNf || g.nf[1] > kG2MMaxNf) return false;
+    for (int a = 0; a < 2; ++a) {
+        if (req->ma.nm[a] / 2 > kG2MMaxH) return false;
+        if (req->part == 4 && req->mb.nm[a] / 2 > kG2MMaxH) return false;
+    }
+    return true;
+}
+
 // spread + reduce + FFT; leaves the transformed fine grids in SLOT_FINE
 static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int mode, int nbatch, int isign,
                           hipStream_t stream, double2** fine_out, unsigned long long seed = 0, int64_t index_offset = 0,
-                          const double** scale_out = nullptr) {
+                          const double** scale_out = nullptr, G2MRequest* req = nullptr) {
     DeviceCtx* ctx = plan->ctx;
     const GridGeom g = make_geom(plan, w);
     if (scale_out) *scale_out = nullptr;
@@ -2253,6 +2436,33 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         EFGP_HIP_CHECK(hipGetLastError());
         int rc = spread_mfma_launch(ctx, lvl, ys, src, g, w->p.w, w->d_coef, w->p.degree, channels, nbatch, gacc, d_scale, stream);
         if (rc != EFGP_OK) return rc;
+        if (g2m_eligible(plan, g, req)) {
+            G2MArgs ga;
+            ga.gacc = (long long*)gacc;
+            ga.scale = d_scale;
+            ga.channels = channels;
+            ga.nf0 = (int)g.nf[0];
+            ga.nf1 = (int)g.nf[1];
+            ga.h0 = (int)std::max(req->ma.nm[0] / 2, req->part == 4 ? req->mb.nm[0] / 2 : (int64_t)0);
+            ga.h1 = (int)std::max(req->ma.nm[1] / 2, req->part == 4 ? req->mb.nm[1] / 2 : (int64_t)0);
+            ga.part = req->part;
+            ga.rows_limit = req->rows_limit;
+            ga.sign = isign < 0 ? -1 : 1;
+            ga.ma = req->ma;
+            ga.mb = req->part == 4 ? req->mb : req->ma;
+            ga.out_a = (double2*)req->out_a;
+            ga.out_b = (double2*)req->out_b;
+            ga.ticket = (unsigned int*)(misc + 40);
+            const unsigned tiles = (unsigned)(ga.h0 / 2 + 1);
+            ga.total_wgs = tiles * (unsigned)nbatch;
+            ga.acc_words = (long long)(acc_bytes / sizeof(long long));
+            hipLaunchKernelGGL(grid_to_modes_kernel, dim3(tiles, nbatch), dim3(kG2MThreads), 0, stream, ga);
+            EFGP_HIP_CHECK(hipGetLastError());
+            ctx->slabs_zero_bytes = acc_bytes;
+            req->done = true;
+            *fine_out = nullptr;
+            return EFGP_OK;
+        }
         const int rb = (int)((g.cells + 63) / 64);
         hipLaunchKernelGGL((reduce_slabs_kernel<true>), dim3(rb, nbatch), dim3(512), 0, stream, (const double*)gacc, 1,
                            channels, g.cells, (const double*)d_scale, fine, 1);
@@ -2592,26 +2802,37 @@ static int type1_real_rows(efgp_nufft_s* plan, WindowSet* w, const double* c, bo
     const int npair = pad_odd ? (nbatch + 1) / 2 : nbatch / 2;
     double2* fine = nullptr;
     if (npair > 0) {
-        int rc = spread_and_fft(plan, w, c, rng ? STR_RNG_PAIR : STR_REAL_PAIR, npair, isign, stream, &fine, seed, index_offset);
+        G2MRequest req;
+        req.part = 3;
+        req.rows_limit = nbatch;
+        req.ma = make_modes(plan, w, n_modes, modeord);
+        req.out_a = out;
+        int rc = spread_and_fft(plan, w, c, rng ? STR_RNG_PAIR : STR_REAL_PAIR, npair, isign, stream, &fine, seed, index_offset, nullptr,
+                                &req);
         if (rc != EFGP_OK) return rc;
         // for isign = +1 the roles of k and -k swap in the Hermitian split; conjugating H handles both signs:
         // the split below assumes the forward (isign = -1) transform, which is what the reference uses for type 1
-        rc = run_deconvolve(plan, w, fine, n_modes, modeord, 3, npair, out, stream, nbatch);
+        if (!req.done) rc = run_deconvolve(plan, w, fine, n_modes, modeord, 3, npair, out, stream, nbatch);
         if (rc != EFGP_OK) return rc;
     }
     if ((nbatch & 1) && !pad_odd) {
         const int last = nbatch - 1;
         int rc;
+        G2MRequest req;
+        req.part = 0;
+        req.ma = make_modes(plan, w, n_modes, modeord);
+        req.out_a = (double2*)out + (int64_t)last * total;
         if (rng) {
             // STR_RNG takes the fine-grid index (0 here) as the row: row `last` of the same seed is row 0 at the point index shifted
             // by last * kRowStride (efgp_rademacher hashes row * kRowStride + index in wrapping 64-bit arithmetic)
             rc = spread_and_fft(plan, w, nullptr, STR_RNG, 1, isign, stream, &fine, seed,
-                                (int64_t)((unsigned long long)index_offset + (unsigned long long)last * kRademacherRowStride));
+                                (int64_t)((unsigned long long)index_offset + (unsigned long long)last * kRademacherRowStride), nullptr,
+                                &req);
         } else {
-            rc = spread_and_fft(plan, w, c + (int64_t)last * plan->npts, STR_REAL, 1, isign, stream, &fine);
+            rc = spread_and_fft(plan, w, c + (int64_t)last * plan->npts, STR_REAL, 1, isign, stream, &fine, 0, 0, nullptr, &req);
         }
         if (rc != EFGP_OK) return rc;
-        rc = run_deconvolve(plan, w, fine, n_modes, modeord, 0, 1, (double2*)out + (int64_t)last * total, stream);
+        if (!req.done) rc = run_deconvolve(plan, w, fine, n_modes, modeord, 0, 1, (double2*)out + (int64_t)last * total, stream);
         if (rc != EFGP_OK) return rc;
     }
     return EFGP_OK;
@@ -2632,8 +2853,13 @@ int efgp_nufft_type1(efgp_nufft_t* plan, const void* c, int c_is_complex, int nb
     if (!c_is_complex && isign == -1 && plan->npts > 0)
         return type1_real_rows(plan, w, (const double*)c, false, 0, 0, nbatch, n_modes, isign, modeord, out, stream);
     double2* fine = nullptr;
-    rc = spread_and_fft(plan, w, (const double*)c, c_is_complex ? STR_COMPLEX : STR_REAL, nbatch, isign, stream, &fine);
+    G2MRequest req;
+    req.part = 0;
+    req.ma = make_modes(plan, w, n_modes, modeord);
+    req.out_a = out;
+    rc = spread_and_fft(plan, w, (const double*)c, c_is_complex ? STR_COMPLEX : STR_REAL, nbatch, isign, stream, &fine, 0, 0, nullptr, &req);
     if (rc != EFGP_OK) return rc;
+    if (req.done) return EFGP_OK;
     return run_deconvolve(plan, w, fine, n_modes, modeord, 0, nbatch, out, stream);
 }
 
@@ -2695,8 +2921,23 @@ int efgp_nufft_type1_pair(efgp_nufft_t* plan, const double* y, const int64_t* n_
     int mode = (out_y && out_ones) ? STR_REAL_AND_ONES : (out_y ? STR_REAL : STR_ONES);
     double2* fine = nullptr;
     const double* pair_scale = nullptr;
-    rc = spread_and_fft(plan, w, y, mode, 1, -1, stream, &fine, 0, 0, &pair_scale);
+    G2MRequest req;
+    G2MRequest* reqp = nullptr;
+    if (mode == STR_REAL_AND_ONES) {
+        req.part = 4;
+        req.ma = make_modes(plan, w, n_modes_y, 0);
+        req.mb = make_modes(plan, w, n_modes_one, 0);
+        for (int a = 0; a < plan->dim; ++a) {
+            req.ma.fac[a] = w->d_fac[a] + (box[a] / 2 - n_modes_y[a] / 2);
+            req.mb.fac[a] = w->d_fac[a] + (box[a] / 2 - n_modes_one[a] / 2);
+        }
+        req.out_a = out_y;
+        req.out_b = out_ones;
+        reqp = &req;
+    }
+    rc = spread_and_fft(plan, w, y, mode, 1, -1, stream, &fine, 0, 0, &pair_scale, reqp);
     if (rc != EFGP_OK) return rc;
+    if (req.done) return EFGP_OK;
     // correction factors were built for `box`; a smaller centred box indexes them with an offset
     auto sub = [&](const int64_t* nm, int part, void* out) -> int {
         ModeGeom m = make_modes(plan, w, nm, 0);

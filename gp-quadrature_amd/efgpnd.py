@@ -1125,9 +1125,11 @@ class EFGPND(nn.Module):
             res = cg_solve_mean_async(toeplitz._op, grid.ws, sig, _center_value(v) if use_precond else None, Fy, tol,
                                       early_stop=True)
         if res is None:
-            rhs = grid.ws * Fy
-            diag = _center_value(v) * grid.ws.abs().pow(2).real + sig if use_precond else None
-            b0 = self._beta.detach().to(device=dev, dtype=torch.complex128) if warm else torch.zeros_like(rhs)
+            # rhs = D F*y (:792) and the Jacobi diagonal (:795-799) in one native launch (four torch launches otherwise, whose first
+            # use in a process costs 0.3 s of torch's own lazy kernel loading)
+            cidx = _center_flat(v)
+            diag, rhs = gradient_prepare(grid.ws, Fy, v.reshape(-1)[cidx:cidx + 1], sig, want_diag=use_precond)
+            b0 = self._beta.detach().to(device=dev, dtype=torch.complex128) if warm else None
             res = cg_solve_async(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False,
                                  hermitian=True)
             if res is None:

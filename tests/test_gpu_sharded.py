@@ -52,7 +52,9 @@ def _worker(rank, world, port, q):
         Z = torch.ones(2, hi - lo, dtype=torch.float64)
         Z[0, ::3] = -1
         grad = m.compute_gradients(trace_samples=2, cg_tol=1e-10, probes_Z=Z, probes_V=V)
-        q.put((rank, mean.cpu(), grad.detach().cpu(), m.last_fit_stats["mean_cg_iters"]))
+        # numpy arrays travel through the queue BY VALUE; torch tensors travel as file descriptors the receiver must fetch from a
+        # sender that is still alive -- a worker that exits first makes q.get fail with ConnectionResetError
+        q.put((rank, mean.cpu().numpy(), grad.detach().cpu().numpy(), int(m.last_fit_stats["mean_cg_iters"])))
     finally:
         dist.destroy_process_group()
 
@@ -88,6 +90,7 @@ def test_two_shards_equal_unsharded():
         Zs.append(z)
     grad = m.compute_gradients(trace_samples=2, cg_tol=1e-10, probes_Z=torch.cat(Zs, dim=1), probes_V=V).detach().cpu()
     for rank, smean, sgrad, its in res:
+        smean, sgrad = torch.from_numpy(smean), torch.from_numpy(sgrad)
         # both solves stop at |r| < 1e-10 |b|, possibly one iteration apart (asserted below): the means agree to a small
         # multiple of cond(A) * tol, not to rounding
         assert float((smean - mean.cpu()).abs().max() / mean.cpu().abs().max()) < 3e-8
@@ -125,7 +128,7 @@ def _worker_free(rank, world, port, q):
             opt.step()
         _, var = m.predict(xn.cuda(), variance_method="stochastic", hutchinson_probes=8)
         hyp = [float(m.kernel.get_hyper(n)) for n in m.kernel.hypers] + [float(m.sigmasq.detach())]
-        q.put((rank, torch.stack(grads), mtots, hyp, var.cpu()))
+        q.put((rank, torch.stack(grads).numpy(), mtots, hyp, var.cpu().numpy()))       # by value, see above
     finally:
         dist.destroy_process_group()
 
@@ -143,6 +146,7 @@ def test_two_shards_stay_identical_without_injected_probes():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, g0, m0, h0, v0), (_, g1, m1, h1, v1) = res
+    g0, g1, v0, v1 = (torch.from_numpy(t) for t in (g0, g1, v0, v1))
     assert torch.equal(g0, g1), (g0, g1)               # bit-identical gradients on both ranks, both steps
     assert m0 == m1 and h0 == h1                       # same grids and hyper-parameters after two optimizer steps
     assert torch.equal(v0, v1)                         # the stochastic variance uses rank 0's probes too

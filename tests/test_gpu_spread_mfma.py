@@ -153,3 +153,42 @@ def test_many_probe_rows_in_one_pass(T):
     C = torch.complex(Z[:3], Z[1:4])
     outc = plan.type1(C.cuda(), (nm, nm))
     assert _rel(outc, plain.type1(C.cuda(), (nm, nm))) < 5 * tol
+
+
+@pytest.mark.parametrize("nm,big,h,tol", [((23, 23), (45, 45), 0.31, 6e-8), ((17, 29), (33, 57), 0.22, 1e-5), ((8, 12), (15, 23), 0.9, 1e-9),
+                                           ((63, 63), (63, 63), 0.12, 1e-5)])
+def test_grid_to_modes_launch_equals_fft_sequence(nm, big, h, tol, monkeypatch):
+    """Small 2-D grids go from the spreader's int64 accumulator to the modes in one launch (pruned dense DFT, Hermitian split,
+    correction factors: grid_to_modes_kernel) instead of reduce | rocFFT rows | rocFFT columns | deconvolve.  Same sums in
+    another order: every variant must agree with the FFT sequence to rounding -- the fit's (F*y, Toeplitz vector) pair on two
+    boxes, real rows in pairs (even and odd counts), a lone real row, complex rows, generated probes, both mode orders -- and
+    leave the accumulator clean for the next pass (each call below starts from what the previous one left)."""
+    from efgp_hip import NufftPlan, PointSet
+    N = 50000
+    x, y = _data(N, 17)
+    xd, yd = x.cuda(), y.cuda()
+    g = torch.Generator().manual_seed(4)
+    Z = torch.randn(5, N, generator=g, dtype=torch.float64).cuda()
+    Cx = torch.complex(Z[:2], Z[2:4]).contiguous()
+
+    def run():
+        plan = NufftPlan(xd, h, tol, points=PointSet(xd, values=yd))
+        outs = list(plan.type1_pair(yd, nm, big))
+        outs.append(plan.type1(Z, nm))                         # 5 real rows: two pair grids + a lone row
+        outs.append(plan.type1(Z[:4], nm, modeord=1))          # pairs only, FFT mode order
+        outs.append(plan.type1(Z[0], nm))
+        outs.append(plan.type1(Cx, nm))                        # complex rows
+        outs.append(plan.type1(Cx, nm, modeord=1, isign=1))
+        outs.append(plan.type1_rademacher(99, 5, nm, index_offset=3))
+        outs.append(plan.type1_rademacher(99, 1, nm, modeord=1))
+        outs.extend(plan.type1_pair(yd, nm, big))              # again, after all of the above
+        return outs
+
+    a = run()
+    monkeypatch.setenv("EFGP_NO_GRID_TO_MODES", "1")
+    b = run()
+    monkeypatch.delenv("EFGP_NO_GRID_TO_MODES")
+    for u, v in zip(a, b):
+        assert u.shape == v.shape
+        assert float((u - v).abs().max() / v.abs().max()) < 1e-12
+    assert torch.equal(a[0], a[-2]) and torch.equal(a[1], a[-1])       # nothing left behind in the accumulator
