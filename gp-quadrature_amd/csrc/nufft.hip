@@ -1242,14 +1242,15 @@ __global__ void deconvolve_pair_kernel(const double2* __restrict__ fine, int64_t
 // 0.5-2 s per new length -- off the fit / gradient path of 2-D models with mtot <= 64.
 //   H[k0][k1] = sum_x0 w0^(k0 x0) sum_x1 w1^(k1 x1) G[x0][x1],  G = ch0 + i ch1,  w_a = exp(sign 2 pi i / nf_a)
 // A workgroup owns the four rows k0 = +-j, +-(j+1) (the split needs H[k] and H[-k] together):
-//   stage 1: B[r][x1] = sum_x0 G[x0][x1] w0^(k_r x0): lane = x1 (coalesced int64 loads), two x0 classes per workgroup;
+//   stage 1: B[r][x1] = sum_x0 G[x0][x1] w0^(k_r x0): lane = x1 (coalesced int64 loads), eight x0 classes per workgroup;
 //   stage 2: H[r][k1] = sum_x1 B[r][x1] w1^(k1 x1) for k1 in [-h1, h1] out of LDS;
 //   epilogue: parts as in deconvolve_body (0 plain, 3 real row pairs, 4 = the fit's (F*y, Toeplitz vector) pair on two boxes).
 // The accumulator must be left zeroed for the next pass: the LAST workgroup to have finished reading it (arrival counter)
 // clears it.  Sums of <= 128 terms with exact table twiddles: the result differs from the FFT's by rounding only.
 constexpr int kG2MMaxNf = 128;
 constexpr int kG2MMaxH = 32;                 // modes k in [-32, 32] per axis
-constexpr int kG2MThreads = 256;
+constexpr int kG2MThreads = 1024;
+constexpr int kG2MGroups = kG2MThreads / kG2MMaxNf;      // x0 classes of stage 1
 
 struct G2MArgs {
     long long* gacc;          // [nbatch][channels][nf0 * nf1]
@@ -1278,7 +1279,7 @@ __device__ __forceinline__ bool g2m_slot(const ModeGeom& m, int k0, int k1, int6
 
 __global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
     __shared__ double2 T0[kG2MMaxNf], T1[kG2MMaxNf];
-    __shared__ double2 Bp[2][4][kG2MMaxNf];
+    __shared__ double2 Bp[kG2MGroups][4][kG2MMaxNf];          // 64 KB
     __shared__ double2 Hs[4][2 * kG2MMaxH + 2];
     __shared__ int s_last;
     const int tid = threadIdx.x, b = blockIdx.y;
@@ -1293,83 +1294,119 @@ __global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
         sincospi((double)a.sign * 2.0 * (double)q / (double)a.nf1, &sn, &cs);
         T1[q] = make_double2(cs, sn);
     }
-    const int kr[4] = {j0, -j0, j0 + 1, -(j0 + 1)};
     const int64_t cells = (int64_t)a.nf0 * a.nf1;
     const long long* g0 = a.gacc + (int64_t)b * a.channels * cells;
     const double s0 = a.scale[1], s1 = a.scale[3];
-    __syncthreads();
-    // stage 1
+    // stage 1: lane = x1, group = x0 mod 8.  ALL of a thread's loads (<= 16 rows x 2 channels) are issued before the first is
+    // used: the accumulator was written by device-scope atomics and comes from memory, and with two groups and one load per
+    // iteration this stage was 48 dependent round trips long (33 us for the 96 x 96 pair grid).
     {
         const int x1 = tid & (kG2MMaxNf - 1), grp = tid >> 7;
-        double2 acc[4];
-        int idx[4], step[4];
+        constexpr int U = kG2MMaxNf / kG2MGroups;             // 16
+        long long ire[U], iim[U];
+        const bool lane_on = x1 < a.nf1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            acc[r] = make_double2(0.0, 0.0);
-            int st = (2 * kr[r]) % a.nf0;
-            if (st < 0) st += a.nf0;
-            step[r] = st;
-            int i0 = (kr[r] * grp) % a.nf0;
-            if (i0 < 0) i0 += a.nf0;
-            idx[r] = i0;
+        for (int u = 0; u < U; ++u) {
+            const int x0 = grp + kG2MGroups * u;
+            const bool in = lane_on && x0 < a.nf0;
+            ire[u] = in ? g0[(int64_t)x0 * a.nf1 + x1] : 0;
+            iim[u] = (in && a.channels == 2) ? g0[cells + (int64_t)x0 * a.nf1 + x1] : 0;
         }
-        if (x1 < a.nf1) {
-            for (int x0 = grp; x0 < a.nf0; x0 += 2) {
-                const double re = (double)g0[(int64_t)x0 * a.nf1 + x1] * s0;
-                const double im = a.channels == 2 ? (double)g0[cells + (int64_t)x0 * a.nf1 + x1] * s1 : 0.0;
+        __syncthreads();                                       // twiddle tables
+        // rows +j and -j share their products: with w0^(j x0) = c + i s and G = re + i im,
+        //   B(+j) = (P - S) + i (Q + R),  B(-j) = (P + S) + i (R - Q),  P = sum re c, Q = sum re s, R = sum im c, S = sum im s
+        double2 pq[2], rs[2];
+        int idx[2], step[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double2 tw = T0[idx[r]];
-                    acc[r].x += re * tw.x - im * tw.y;
-                    acc[r].y += re * tw.y + im * tw.x;
-                    idx[r] += step[r];
-                    if (idx[r] >= a.nf0) idx[r] -= a.nf0;
-                }
+        for (int jj = 0; jj < 2; ++jj) {
+            const int k = j0 + jj;
+            pq[jj] = rs[jj] = make_double2(0.0, 0.0);
+            step[jj] = (kG2MGroups * k) % a.nf0;
+            idx[jj] = (k * grp) % a.nf0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double re = (double)ire[u] * s0, im = (double)iim[u] * s1;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const double2 tw = T0[idx[jj]];
+                pq[jj].x += re * tw.x;
+                pq[jj].y += re * tw.y;
+                rs[jj].x += im * tw.x;
+                rs[jj].y += im * tw.y;
+                idx[jj] += step[jj];
+                if (idx[jj] >= a.nf0) idx[jj] -= a.nf0;
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Bp[grp][r][x1] = acc[r];
+        for (int jj = 0; jj < 2; ++jj) {
+            Bp[grp][2 * jj][x1] = pq[jj];
+            Bp[grp][2 * jj + 1][x1] = rs[jj];
+        }
     }
     __syncthreads();
-    // every load of the accumulator by this workgroup has been consumed: arrive; the last one clears it
-    if (tid == 0) {
-        __threadfence();
-        s_last = atomicAdd(a.ticket, 1u) == a.total_wgs - 1u ? 1 : 0;
-    }
-    for (int o = tid; o < 4 * a.nf1; o += kG2MThreads) {
-        const int r = o / a.nf1, x = o - r * a.nf1;
-        const double2 u = Bp[0][r][x], v = Bp[1][r][x];
-        Bp[0][r][x] = make_double2(u.x + v.x, u.y + v.y);
+    // every load of the accumulator by this workgroup has been consumed: arrive (the answer is looked at after stage 2);
+    // the last workgroup to arrive clears the accumulator
+    unsigned int arrived = 0u;
+    if (tid == 0) arrived = atomicAdd(a.ticket, 1u);          // no fence: the loads were consumed (barrier above), nothing was stored
+    for (int o = tid; o < 2 * a.nf1; o += kG2MThreads) {
+        const int jj = o / a.nf1, x = o - jj * a.nf1;
+        double2 u = Bp[0][2 * jj][x], v = Bp[0][2 * jj + 1][x];
+#pragma unroll
+        for (int g = 1; g < kG2MGroups; ++g) {
+            u.x += Bp[g][2 * jj][x].x;
+            u.y += Bp[g][2 * jj][x].y;
+            v.x += Bp[g][2 * jj + 1][x].x;
+            v.y += Bp[g][2 * jj + 1][x].y;
+        }
+        Bp[0][2 * jj][x] = make_double2(u.x - v.y, u.y + v.x);          // row +j
+        Bp[0][2 * jj + 1][x] = make_double2(u.x + v.y, v.x - u.y);      // row -j
     }
     __syncthreads();
-    if (s_last) {
-        for (long long i = tid; i < a.acc_words; i += kG2MThreads) a.gacc[i] = 0;
-        if (tid == 0) *a.ticket = 0u;
-    }
-    // stage 2
+    // stage 2: four quarter ranges of x1 per output, combined through LDS
     const int nk1 = 2 * a.h1 + 1;
-    for (int o = tid; o < 4 * nk1; o += kG2MThreads) {
-        const int r = o / nk1, c = o - r * nk1;
+    double2* const Hq = &Bp[1][0][0];                          // [4 quarters][4 rows][nk1 <= 65]: Bp[1..] is free now
+    for (int o = tid; o < 16 * nk1; o += kG2MThreads) {
+        const int qtr = o / (4 * nk1), rc = o - qtr * 4 * nk1;
+        const int r = rc / nk1, c = rc - r * nk1;
         int st = (c - a.h1) % a.nf1;
         if (st < 0) st += a.nf1;
-        int idx = 0;
+        const int xa = (a.nf1 * qtr) / 4, xe = (a.nf1 * (qtr + 1)) / 4;
+        int idx = (int)(((long long)st * xa) % a.nf1);
         double sx = 0.0, sy = 0.0;
-        for (int x = 0; x < a.nf1; ++x) {
+        for (int x = xa; x < xe; ++x) {
             const double2 bv = Bp[0][r][x], tw = T1[idx];
             sx += bv.x * tw.x - bv.y * tw.y;
             sy += bv.x * tw.y + bv.y * tw.x;
             idx += st;
             if (idx >= a.nf1) idx -= a.nf1;
         }
-        Hs[r][c] = make_double2(sx, sy);
+        Hq[(qtr * 4 + r) * (2 * kG2MMaxH + 2) + c] = make_double2(sx, sy);
+    }
+    if (tid == 0) s_last = arrived == a.total_wgs - 1u ? 1 : 0;        // the counter's answer has had stage 2 to come back
+    __syncthreads();
+    if (s_last) {                                                      // these stores drain behind the epilogue
+        for (long long i = tid; i < a.acc_words; i += kG2MThreads) a.gacc[i] = 0;
+        if (tid == 0) *a.ticket = 0u;
+    }
+    for (int o = tid; o < 4 * nk1; o += kG2MThreads) {
+        const int r = o / nk1, c = o - r * nk1;
+        double2 u = Hq[r * (2 * kG2MMaxH + 2) + c];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const double2 v = Hq[(q * 4 + r) * (2 * kG2MMaxH + 2) + c];
+            u.x += v.x;
+            u.y += v.y;
+        }
+        Hs[r][c] = u;
     }
     __syncthreads();
     // epilogue
     for (int o = tid; o < 4 * nk1; o += kG2MThreads) {
         const int r = o / nk1, c = o - r * nk1;
-        const int j = r < 2 ? j0 : j0 + 1;
+        const int j = j0 + (r >> 1);
         if (j > a.h0 || (j == 0 && (r & 1))) continue;            // beyond the box; -0 duplicates +0
-        const int k0 = kr[r], k1 = c - a.h1;
+        const int k0 = (r & 1) ? -j : j, k1 = c - a.h1;
         const double2 H = Hs[r][c], G = Hs[r ^ 1][nk1 - 1 - c];    // modes k and -k
         int64_t t;
         double f;
