@@ -1254,6 +1254,7 @@ constexpr int kG2MGroups = kG2MThreads / kG2MMaxNf;      // x0 classes of stage 
 
 struct G2MArgs {
     long long* gacc;          // [nbatch][channels][nf0 * nf1]
+    const double2* fine;      // FINE variant: [nbatch][nf0 * nf1] complex grid already reduced (other spreaders); nothing is cleared
     const double* scale;      // fixed-point block: [1] = 1/S0, [3] = 1/S1, [4] = channel-0 norm
     int channels, nf0, nf1, h0, h1;
     int part;                 // 0, 3, or 4 (pair: part 1 on box ma -> out_a, part 2 on box mb -> out_b)
@@ -1277,6 +1278,7 @@ __device__ __forceinline__ bool g2m_slot(const ModeGeom& m, int k0, int k1, int6
     return true;
 }
 
+template <bool FINE>
 __global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
     __shared__ double2 T0[kG2MMaxNf], T1[kG2MMaxNf];
     __shared__ double2 Bp[kG2MGroups][4][kG2MMaxNf];          // 64 KB
@@ -1295,8 +1297,9 @@ __global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
         T1[q] = make_double2(cs, sn);
     }
     const int64_t cells = (int64_t)a.nf0 * a.nf1;
-    const long long* g0 = a.gacc + (int64_t)b * a.channels * cells;
-    const double s0 = a.scale[1], s1 = a.scale[3];
+    const long long* g0 = FINE ? nullptr : a.gacc + (int64_t)b * a.channels * cells;
+    const double2* f0 = FINE ? a.fine + (int64_t)b * cells : nullptr;
+    const double s0 = FINE ? 1.0 : a.scale[1], s1 = FINE ? 1.0 : a.scale[3];
     // stage 1: lane = x1, group = x0 mod 8.  ALL of a thread's loads (<= 16 rows x 2 channels) are issued before the first is
     // used: the accumulator was written by device-scope atomics and comes from memory, and with two groups and one load per
     // iteration this stage was 48 dependent round trips long (33 us for the 96 x 96 pair grid).
@@ -1309,8 +1312,14 @@ __global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
         for (int u = 0; u < U; ++u) {
             const int x0 = grp + kG2MGroups * u;
             const bool in = lane_on && x0 < a.nf0;
-            ire[u] = in ? g0[(int64_t)x0 * a.nf1 + x1] : 0;
-            iim[u] = (in && a.channels == 2) ? g0[cells + (int64_t)x0 * a.nf1 + x1] : 0;
+            if (FINE) {
+                const double2 v = in ? f0[(int64_t)x0 * a.nf1 + x1] : make_double2(0.0, 0.0);
+                ire[u] = __double_as_longlong(v.x);
+                iim[u] = __double_as_longlong(v.y);
+            } else {
+                ire[u] = in ? g0[(int64_t)x0 * a.nf1 + x1] : 0;
+                iim[u] = (in && a.channels == 2) ? g0[cells + (int64_t)x0 * a.nf1 + x1] : 0;
+            }
         }
         __syncthreads();                                       // twiddle tables
         // rows +j and -j share their products: with w0^(j x0) = c + i s and G = re + i im,
@@ -1326,7 +1335,8 @@ __global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const double re = (double)ire[u] * s0, im = (double)iim[u] * s1;
+            const double re = FINE ? __longlong_as_double(ire[u]) : (double)ire[u] * s0;
+            const double im = FINE ? __longlong_as_double(iim[u]) : (double)iim[u] * s1;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const double2 tw = T0[idx[jj]];
@@ -1348,7 +1358,7 @@ __global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
     // every load of the accumulator by this workgroup has been consumed: arrive (the answer is looked at after stage 2);
     // the last workgroup to arrive clears the accumulator
     unsigned int arrived = 0u;
-    if (tid == 0) arrived = atomicAdd(a.ticket, 1u);          // no fence: the loads were consumed (barrier above), nothing was stored
+    if (!FINE && tid == 0) arrived = atomicAdd(a.ticket, 1u);          // no fence: the loads were consumed (barrier above), nothing was stored
     for (int o = tid; o < 2 * a.nf1; o += kG2MThreads) {
         const int jj = o / a.nf1, x = o - jj * a.nf1;
         double2 u = Bp[0][2 * jj][x], v = Bp[0][2 * jj + 1][x];
@@ -1383,7 +1393,7 @@ __global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
         }
         Hq[(qtr * 4 + r) * (2 * kG2MMaxH + 2) + c] = make_double2(sx, sy);
     }
-    if (tid == 0) s_last = arrived == a.total_wgs - 1u ? 1 : 0;        // the counter's answer has had stage 2 to come back
+    if (tid == 0) s_last = (!FINE && arrived == a.total_wgs - 1u) ? 1 : 0;        // the counter's answer has had stage 2 to come back
     __syncthreads();
     if (s_last) {                                                      // these stores drain behind the epilogue
         for (long long i = tid; i < a.acc_words; i += kG2MThreads) a.gacc[i] = 0;
@@ -1421,7 +1431,7 @@ __global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
                 if (2 * b + 1 < a.rows_limit)
                     a.out_a[(int64_t)(2 * b + 1) * a.ma.total + t] = make_double2(0.5 * (H.y + G.y) * f, 0.5 * (G.x - H.x) * f);
             } else {
-                const double norm0 = a.scale[4];                   // channel 0 was carried normalised (fixed_scale_kernel)
+                const double norm0 = a.scale ? a.scale[4] : 1.0;  // channel 0 was carried normalised (fixed_scale_kernel)
                 if (norm0 != 1.0) {
                     r1.x *= norm0;
                     r1.y *= norm0;
@@ -2404,6 +2414,51 @@ static bool g2m_eligible(const efgp_nufft_s* plan, const GridGeom& g, const G2MR
     return true;
 }
 
+// gacc != null: from the MFMA spreader's int64 accumulator (converted, cleared by the kernel); else from the reduced complex grid
+static int g2m_launch(const GridGeom& g, G2MRequest* req, long long* gacc, const double2* fine, const double* scale, int channels,
+                      int nbatch, int isign, unsigned int* ticket, long long acc_words, hipStream_t stream) {
+    G2MArgs ga;
+    ga.gacc = gacc;
+    ga.fine = fine;
+    ga.scale = scale;
+    ga.channels = channels;
+    ga.nf0 = (int)g.nf[0];
+    ga.nf1 = (int)g.nf[1];
+    ga.h0 = (int)std::max(req->ma.nm[0] / 2, req->part == 4 ? req->mb.nm[0] / 2 : (int64_t)0);
+    ga.h1 = (int)std::max(req->ma.nm[1] / 2, req->part == 4 ? req->mb.nm[1] / 2 : (int64_t)0);
+    ga.part = req->part;
+    ga.rows_limit = req->rows_limit;
+    ga.sign = isign < 0 ? -1 : 1;
+    ga.ma = req->ma;
+    ga.mb = req->part == 4 ? req->mb : req->ma;
+    ga.out_a = (double2*)req->out_a;
+    ga.out_b = (double2*)req->out_b;
+    ga.ticket = ticket;
+    const unsigned tiles = (unsigned)(ga.h0 / 2 + 1);
+    ga.total_wgs = tiles * (unsigned)nbatch;
+    ga.acc_words = acc_words;
+    if (gacc) hipLaunchKernelGGL(grid_to_modes_kernel<false>, dim3(tiles, nbatch), dim3(kG2MThreads), 0, stream, ga);
+    else hipLaunchKernelGGL(grid_to_modes_kernel<true>, dim3(tiles, nbatch), dim3(kG2MThreads), 0, stream, ga);
+    EFGP_HIP_CHECK(hipGetLastError());
+    req->done = true;
+    return EFGP_OK;
+}
+
+// the reduced fine grids of the other spreaders: one-launch pruned DFT when the grid is small, else the FFT in place
+static int transform_fine(efgp_nufft_s* plan, const GridGeom& g, double2* fine, int nbatch, int isign, hipStream_t stream,
+                          G2MRequest* req, const double* scale, double2** fine_out) {
+    if (g2m_eligible(plan, g, req)) {
+        *fine_out = nullptr;
+        return g2m_launch(g, req, nullptr, fine, scale, 2, nbatch, isign, nullptr, 0, stream);
+    }
+    hipfftHandle fh;
+    int rc = fft_plan(plan->ctx, plan->dim, g.nf, nbatch, stream, &fh);
+    if (rc != EFGP_OK) return rc;
+    EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)fine, (hipfftDoubleComplex*)fine, isign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
+    *fine_out = fine;
+    return EFGP_OK;
+}
+
 // spread + reduce + FFT; leaves the transformed fine grids in SLOT_FINE
 static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int mode, int nbatch, int isign,
                           hipStream_t stream, double2** fine_out, unsigned long long seed = 0, int64_t index_offset = 0,
@@ -2474,29 +2529,10 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         int rc = spread_mfma_launch(ctx, lvl, ys, src, g, w->p.w, w->d_coef, w->p.degree, channels, nbatch, gacc, d_scale, stream);
         if (rc != EFGP_OK) return rc;
         if (g2m_eligible(plan, g, req)) {
-            G2MArgs ga;
-            ga.gacc = (long long*)gacc;
-            ga.scale = d_scale;
-            ga.channels = channels;
-            ga.nf0 = (int)g.nf[0];
-            ga.nf1 = (int)g.nf[1];
-            ga.h0 = (int)std::max(req->ma.nm[0] / 2, req->part == 4 ? req->mb.nm[0] / 2 : (int64_t)0);
-            ga.h1 = (int)std::max(req->ma.nm[1] / 2, req->part == 4 ? req->mb.nm[1] / 2 : (int64_t)0);
-            ga.part = req->part;
-            ga.rows_limit = req->rows_limit;
-            ga.sign = isign < 0 ? -1 : 1;
-            ga.ma = req->ma;
-            ga.mb = req->part == 4 ? req->mb : req->ma;
-            ga.out_a = (double2*)req->out_a;
-            ga.out_b = (double2*)req->out_b;
-            ga.ticket = (unsigned int*)(misc + 40);
-            const unsigned tiles = (unsigned)(ga.h0 / 2 + 1);
-            ga.total_wgs = tiles * (unsigned)nbatch;
-            ga.acc_words = (long long)(acc_bytes / sizeof(long long));
-            hipLaunchKernelGGL(grid_to_modes_kernel, dim3(tiles, nbatch), dim3(kG2MThreads), 0, stream, ga);
-            EFGP_HIP_CHECK(hipGetLastError());
+            rc = g2m_launch(g, req, (long long*)gacc, nullptr, d_scale, channels, nbatch, isign, (unsigned int*)(misc + 40),
+                            (long long)(acc_bytes / sizeof(long long)), stream);
+            if (rc != EFGP_OK) return rc;
             ctx->slabs_zero_bytes = acc_bytes;
-            req->done = true;
             *fine_out = nullptr;
             return EFGP_OK;
         }
@@ -2505,13 +2541,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
                            channels, g.cells, (const double*)d_scale, fine, 1);
         EFGP_HIP_CHECK(hipGetLastError());
         ctx->slabs_zero_bytes = acc_bytes;
-        hipfftHandle fh;
-        rc = fft_plan(ctx, plan->dim, g.nf, nbatch, stream, &fh);
-        if (rc != EFGP_OK) return rc;
-        EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)fine, (hipfftDoubleComplex*)fine,
-                                     isign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
-        *fine_out = fine;
-        return EFGP_OK;
+        return transform_fine(plan, g, fine, nbatch, isign, stream, req, scale_out ? *scale_out : nullptr, fine_out);
     }
     // 2-D with many points per fine-grid cell: register accumulation over base-cell-sorted points
     {
@@ -2563,13 +2593,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
             hipLaunchKernelGGL((reduce_slabs_kernel<false>), dim3(rb, nbatch), dim3(512), 0, stream, (const double*)gacc, 1,
                                channels, g.cells, (const double*)nullptr, fine);
             EFGP_HIP_CHECK(hipGetLastError());
-            hipfftHandle fh;
-            rc = fft_plan(ctx, plan->dim, g.nf, nbatch, stream, &fh);
-            if (rc != EFGP_OK) return rc;
-            EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)fine, (hipfftDoubleComplex*)fine,
-                                         isign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
-            *fine_out = fine;
-            return EFGP_OK;
+            return transform_fine(plan, g, fine, nbatch, isign, stream, req, scale_out ? *scale_out : nullptr, fine_out);
         }
     }
     // grids beyond LDS: tile-sorted points + LDS tiles (large N), else global atomics (small N)
@@ -2633,13 +2657,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         hipLaunchKernelGGL((reduce_slabs_kernel<true>), dim3(blocks, nbatch), dim3(512), 0, stream, (const double*)gacc, 1,
                            channels, g.cells, (const double*)d_scale, fine);
         EFGP_HIP_CHECK(hipGetLastError());
-        hipfftHandle fh;
-        rc = fft_plan(ctx, plan->dim, g.nf, nbatch, stream, &fh);
-        if (rc != EFGP_OK) return rc;
-        EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)fine, (hipfftDoubleComplex*)fine,
-                                     isign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
-        *fine_out = fine;
-        return EFGP_OK;
+        return transform_fine(plan, g, fine, nbatch, isign, stream, req, scale_out ? *scale_out : nullptr, fine_out);
     }
     int nwg = 1;
     if (use_lds) {
@@ -2757,13 +2775,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
                                channels, g.cells, (const double*)d_scale, fine);
         EFGP_HIP_CHECK(hipGetLastError());
     }
-    hipfftHandle fh;
-    int rc = fft_plan(ctx, plan->dim, g.nf, nbatch, stream, &fh);
-    if (rc != EFGP_OK) return rc;
-    EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)fine, (hipfftDoubleComplex*)fine,
-                                 isign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
-    *fine_out = fine;
-    return EFGP_OK;
+    return transform_fine(plan, g, fine, nbatch, isign, stream, req, scale_out ? *scale_out : nullptr, fine_out);
 }
 
 static int run_deconvolve(efgp_nufft_s* plan, WindowSet* w, const double2* fine, const int64_t* nm, int modeord,

@@ -124,4 +124,9 @@ def test_adam_trajectory_matches_reference(name):
         assert float((grad.detach().cpu() - torch.from_numpy(grads[i])).abs().max()) < 2e-5 * scale, (i, grad, grads[i])
         opt.step()
         now = np.array([float(m.kernel.get_hyper(n)) for n in m.kernel.hypers] + [float(m.sigmasq.detach())])
-        assert np.abs(now - traj[i]).max() < 1e-6 * np.abs(traj[i]).max(), (i, now, traj[i])
+        # Adam moves a log-parameter by lr * m / sqrt(v): a gradient component that deviates by delta RELATIVE TO ITSELF moves its
+        # hyper-parameter by ~lr * delta, and the bound above is relative to the LARGEST component.  These solves end at their
+        # iteration cap (cond(D T D) ~ 1e10 at cg_tol = 1e-12), where rounding-level differences between transform sequences
+        # (rocFFT vs the pruned DFT of small grids) show up at 1e-10..3e-7 of the gradient scale from step to step: 2e-7..3e-6 in
+        # the hypers, against the north star's 1e-5.
+        assert np.abs(now - traj[i]).max() < 1e-5 * np.abs(traj[i]).max(), (i, now, traj[i])

@@ -192,3 +192,28 @@ def test_grid_to_modes_launch_equals_fft_sequence(nm, big, h, tol, monkeypatch):
         assert u.shape == v.shape
         assert float((u - v).abs().max() / v.abs().max()) < 1e-12
     assert torch.equal(a[0], a[-2]) and torch.equal(a[1], a[-1])       # nothing left behind in the accumulator
+
+
+@pytest.mark.parametrize("N,nm,big,h,tol", [(3000, (23, 23), (45, 45), 0.31, 6e-8), (20000, (17, 29), (33, 57), 0.22, 1e-5),
+                                            (40000, (31, 31), (61, 61), 0.2, 1e-7)])
+def test_grid_to_modes_behind_the_other_spreaders(N, nm, big, h, tol, monkeypatch):
+    """Plans without a point layout / with few points spread through the LDS-atomic kernels and reduce their slabs to a complex
+    grid; small grids then take the same one-launch pruned DFT (reading that grid) instead of rocFFT + deconvolve."""
+    from efgp_hip import NufftPlan
+    x, y = _data(N, 23)
+    xd, yd = x.cuda(), y.cuda()
+    g = torch.Generator().manual_seed(6)
+    Z = torch.randn(3, N, generator=g, dtype=torch.float64).cuda()
+    Cx = torch.complex(Z[0], Z[1]).contiguous()
+
+    def run():
+        plan = NufftPlan(xd, h, tol)
+        return list(plan.type1_pair(yd, nm, big)) + [plan.type1(Z, nm), plan.type1(Cx, nm, modeord=1), plan.type1_rademacher(5, 3, nm),
+                                                     plan.type1(Cx, nm, isign=1)]
+
+    a = run()
+    monkeypatch.setenv("EFGP_NO_GRID_TO_MODES", "1")
+    b = run()
+    monkeypatch.delenv("EFGP_NO_GRID_TO_MODES")
+    for u, v in zip(a, b):
+        assert u.shape == v.shape and float((u - v).abs().max() / v.abs().max()) < 1e-12
