@@ -14,25 +14,36 @@ namespace efgp {
 struct LagGeom {
     int d;
     int n[3];       // mtot per dimension (unused = 1)
-    int s[3];       // 2 n - 1
-    int64_t M, S;   // prod n, prod s
+    int s[3];       // 2 n - 1: the lag box of the result
+    int p[3];       // transform length per dimension: the next 2^k / 3 * 2^k size >= s (see lag_length)
+    int64_t M, S, P;   // prod n, prod s, prod p
 };
+
+// Transform length of the zero-padded correlation: any length >= 2 n - 1 gives the same lags, so it comes from the short ladder
+// 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, ...  The exact lag-box size 2 mtot - 1 is an odd length that changes with every mtot, and
+// every FFT length new to the process is a runtime compilation in rocFFT (0.5-2 s each).
+static int lag_length(int s) {
+    for (int p2 = 1;; p2 *= 2) {
+        if (p2 >= s) return p2;
+        if (p2 >= 2 && p2 + p2 / 2 >= s) return p2 + p2 / 2;
+    }
+}
 
 // zero-padded copies: pad[j][0][...] = gamma_j, pad[j][1][...] = eta_j  (two transforms per probe in one batch)
 __global__ __launch_bounds__(256) void lag_pad_kernel(LagGeom g, const double2* __restrict__ gam, const double* __restrict__ eta,
                                                       double2* __restrict__ pad) {
     const int j = blockIdx.y;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < g.S; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < g.P; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t r = i;
-        const int i2 = (int)(r % g.s[2]);
-        r /= g.s[2];
-        const int i1 = (int)(r % g.s[1]);
-        const int i0 = (int)(r / g.s[1]);
+        const int i2 = (int)(r % g.p[2]);
+        r /= g.p[2];
+        const int i1 = (int)(r % g.p[1]);
+        const int i0 = (int)(r / g.p[1]);
         const bool in = i0 < g.n[0] && i1 < g.n[1] && i2 < g.n[2];
         const int64_t src = ((int64_t)i0 * g.n[1] + i1) * g.n[2] + i2;
-        double2* row = pad + (int64_t)2 * j * g.S;
+        double2* row = pad + (int64_t)2 * j * g.P;
         row[i] = in ? gam[(int64_t)j * g.M + src] : make_double2(0.0, 0.0);
-        row[g.S + i] = in ? make_double2(eta[(int64_t)j * g.M + src], 0.0) : make_double2(0.0, 0.0);
+        row[g.P + i] = in ? make_double2(eta[(int64_t)j * g.M + src], 0.0) : make_double2(0.0, 0.0);
     }
 }
 
@@ -54,9 +65,22 @@ __global__ __launch_bounds__(256) void lag_mul_sum_kernel(int64_t S, int J, cons
     }
 }
 
-__global__ __launch_bounds__(256) void lag_scale_kernel(int64_t S, double factor, const double2* __restrict__ in, double2* __restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = make_double2(in[i].x * factor, in[i].y * factor);
+// out (lag box s, FFT order) = factor * the same lags of the padded correlation (length p per dimension, FFT order)
+__global__ __launch_bounds__(256) void lag_scale_kernel(LagGeom g, double factor, const double2* __restrict__ in, double2* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < g.S; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        int c[3];
+        c[2] = (int)(r % g.s[2]);
+        r /= g.s[2];
+        c[1] = (int)(r % g.s[1]);
+        c[0] = (int)(r / g.s[1]);
+        int64_t src = 0;
+        for (int a = 0; a < 3; ++a) {
+            const int lag = c[a] < g.n[a] ? c[a] : c[a] - g.s[a];      // FFT order of the lag box: 0..n-1, -(n-1)..-1
+            src = src * g.p[a] + (lag >= 0 ? lag : lag + g.p[a]);
+        }
+        out[i] = make_double2(in[src].x * factor, in[src].y * factor);
+    }
 }
 
 // phase 2 pi h k . x for mode index t of the (mtot,)*d box, k = i - (mtot-1)/2 per dimension, last dimension fastest
@@ -159,22 +183,25 @@ int efgp_lag_sums(int device, int dim, int64_t mtot, const void* gamma, const do
     g.d = dim;
     g.M = 1;
     g.S = 1;
+    g.P = 1;
     int64_t sizes[3] = {1, 1, 1};
     // slots are right-aligned so that the LAST real dimension is the fastest one (n[2] / s[2])
     for (int a = 0; a < 3; ++a) {
         const bool real = a >= 3 - dim;
         g.n[a] = real ? (int)mtot : 1;
         g.s[a] = real ? (int)(2 * mtot - 1) : 1;
+        g.p[a] = real ? lag_length(g.s[a]) : 1;
         g.M *= g.n[a];
         g.S *= g.s[a];
+        g.P *= g.p[a];
     }
-    for (int a = 0; a < dim; ++a) sizes[a] = 2 * mtot - 1;
+    for (int a = 0; a < dim; ++a) sizes[a] = lag_length((int)(2 * mtot - 1));
     // probes are processed in slabs so that the padded transforms stay within ~256 MB of scratch
-    const int64_t per = std::max<int64_t>(1, std::min<int64_t>(nprobes, ((int64_t)256 << 20) / (int64_t)(2 * g.S * sizeof(double2))));
-    double2* pad = (double2*)scratch(ctx, SLOT_TOEP_PAD, (size_t)(2 * per + 1) * g.S * sizeof(double2));
+    const int64_t per = std::max<int64_t>(1, std::min<int64_t>(nprobes, ((int64_t)256 << 20) / (int64_t)(2 * g.P * sizeof(double2))));
+    double2* pad = (double2*)scratch(ctx, SLOT_TOEP_PAD, (size_t)(2 * per + 1) * g.P * sizeof(double2));
     if (!pad) return EFGP_ENOMEM;
-    double2* acc = pad + (int64_t)2 * per * g.S;
-    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((g.S + 255) / 256, 1024));
+    double2* acc = pad + (int64_t)2 * per * g.P;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((g.P + 255) / 256, 1024));
     for (int64_t j0 = 0; j0 < nprobes; j0 += per) {
         const int J = (int)std::min<int64_t>(per, nprobes - j0);
         hipLaunchKernelGGL(lag_pad_kernel, dim3(blocks, J), dim3(256), 0, stream, g, (const double2*)gamma + j0 * g.M, eta + j0 * g.M, pad);
@@ -183,14 +210,15 @@ int efgp_lag_sums(int device, int dim, int64_t mtot, const void* gamma, const do
         int rc = fft_plan(ctx, dim, sizes, 2 * J, stream, &fh);
         if (rc != EFGP_OK) return rc;
         EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)pad, (hipfftDoubleComplex*)pad, HIPFFT_FORWARD));
-        hipLaunchKernelGGL(lag_mul_sum_kernel, dim3(blocks), dim3(256), 0, stream, g.S, J, (const double2*)pad, acc, j0 > 0 ? 1 : 0);
+        hipLaunchKernelGGL(lag_mul_sum_kernel, dim3(blocks), dim3(256), 0, stream, g.P, J, (const double2*)pad, acc, j0 > 0 ? 1 : 0);
         EFGP_HIP_CHECK(hipGetLastError());
     }
     hipfftHandle fi;
     int rc = fft_plan(ctx, dim, sizes, 1, stream, &fi);
     if (rc != EFGP_OK) return rc;
     EFGP_FFT_CHECK(hipfftExecZ2Z(fi, (hipfftDoubleComplex*)acc, (hipfftDoubleComplex*)acc, HIPFFT_BACKWARD));
-    hipLaunchKernelGGL(lag_scale_kernel, dim3(blocks), dim3(256), 0, stream, g.S, 1.0 / ((double)g.S * (double)nprobes), (const double2*)acc,
+    const int oblocks = (int)std::max<int64_t>(1, std::min<int64_t>((g.S + 255) / 256, 1024));
+    hipLaunchKernelGGL(lag_scale_kernel, dim3(oblocks), dim3(256), 0, stream, g, 1.0 / ((double)g.P * (double)nprobes), (const double2*)acc,
                        (double2*)out);
     EFGP_HIP_CHECK(hipGetLastError());
     return EFGP_OK;

@@ -8,7 +8,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("d,mtot,J", [(1, 35, 5), (2, 23, 7), (2, 8, 3), (3, 9, 4)])
+# the transform runs at the next 2^k / 3 * 2^k length >= 2 mtot - 1 (exact at mtot 1, 2; padded elsewhere): same lags
+@pytest.mark.parametrize("d,mtot,J", [(1, 35, 5), (2, 23, 7), (2, 8, 3), (3, 9, 4), (1, 1, 2), (2, 2, 3), (2, 17, 2), (3, 13, 2), (1, 301, 2)])
 def test_lag_sums_match_fft_correlation(d, mtot, J):
     from efgp_hip import lag_sums
     g = torch.Generator().manual_seed(3)
