@@ -513,7 +513,7 @@ def efgpnd_gradient_batched(
         # 4) mean solve ---------------------------------------------------------------------------
         rhs = ws * Fy
         warm = mean_cg_init is not None and tuple(mean_cg_init.shape) == tuple(rhs.shape)
-        b0 = mean_cg_init.detach().to(device=dev, dtype=torch.complex128) if warm else torch.zeros_like(rhs)
+        b0 = mean_cg_init.detach().to(device=dev, dtype=torch.complex128) if warm else None          # None: the solver starts from zeros it allocates itself (no copy)
         # rhs = D F*y of the real y (and a warm start from an earlier solve of the same kind): coefficients of real functions
         res_m = cg_solve_async(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping,
                                diag=diag if use_mean_cg_preconditioner else None, batched=False, hermitian=True)
@@ -595,10 +595,10 @@ def efgpnd_gradient_batched(
         lap("6_monte_carlo_trace")
 
         # 7) batched CG -----------------------------------------------------------------------------
-        res_t = cg_solve_async(top, ws, sig, 0, B_all, torch.zeros_like(B_all), cg_tol, early_stop=early_stopping,
+        res_t = cg_solve_async(top, ws, sig, 0, B_all, None, cg_tol, early_stop=early_stopping,
                                diag=diag if use_trace_cg_preconditioner else None, batched=True)
         if res_t is None:
-            res_t = cg_solve(top, ws, sig, 0, B_all, torch.zeros_like(B_all), cg_tol, early_stop=early_stopping,
+            res_t = cg_solve(top, ws, sig, 0, B_all, None, cg_tol, early_stop=early_stopping,
                              diag=diag if use_trace_cg_preconditioner else None, batched=True)[:2]
         Beta_all, trace_iters = res_t
         lap("7_batch_cg_solve")
@@ -772,7 +772,7 @@ def diag_sums_nd(A_apply, J, xis_flat, max_cg_iter, cg_tol, ws, probes: Optional
         etas = probes.detach().to(device=dev, dtype=torch.float64)
     wsd = ws.to(device=dev, dtype=torch.complex128)
     rhs = wsd[None, :] * etas
-    us, _, _ = cg_solve(op.toeplitz._op, wsd, op.sigmasq, op.variant, rhs, torch.zeros_like(rhs), cg_tol,
+    us, _, _ = cg_solve(op.toeplitz._op, wsd, op.sigmasq, op.variant, rhs, None, cg_tol,
                         max_iter=max_cg_iter, early_stop=True, diag=None, batched=True)
     # zero-padded correlation of every probe pair and the mean over probes (:1660-1664): hipFFT + three small kernels
     return lag_sums(wsd[None, :] * us, etas, m_loc, d_loc)
@@ -866,7 +866,7 @@ def compute_prediction_variance(x_new, xis, ws, A_var, cg_tol, max_cg_iter, vari
         out = []
         for xb in torch.split(xn, 8192, dim=0):
             rhs = variance_rhs(xb, hval, mtot_loc, wsd)                  # ws * conj(f(x*)): explicit feature rows (b, M)
-            gamma, _, _ = cg_solve(op.toeplitz._op, wsd, op.sigmasq, op.variant, rhs, torch.zeros_like(rhs), cg_tol,
+            gamma, _, _ = cg_solve(op.toeplitz._op, wsd, op.sigmasq, op.variant, rhs, None, cg_tol,
                                    max_iter=max_cg_iter, early_stop=True, diag=None, batched=True,
                                    hermitian=True)     # feature rows of real points: conjugate-even
             out.append(variance_contract(xb, hval, mtot_loc, wsd, gamma))
