@@ -1281,6 +1281,87 @@ __global__ __launch_bounds__(kThreads) void toeplitz_vhat_2d64_kernel(const doub
     for (int t = 0; t < 8; ++t) vhat[(j + 8 * t) * F + c] = x[t];
 }
 
+// Batched variant for the lag-sum correlation of the stochastic variance (variance_ops.hip): transform b reads the
+// L0 x L1 array src + b * src_stride (complex, or real doubles when REAL), zero-pads it to 64 x 64 and writes the forward
+// transform in natural order to dst + b * dst_stride.  One workgroup per transform, no rocFFT (no run-time compilation).
+template <bool REAL>
+__global__ __launch_bounds__(kThreads) void fft2d64_batch_kernel(const void* __restrict__ src, int64_t src_stride, int L0, int L1,
+                                                                 double2* __restrict__ dst, int64_t dst_stride) {
+    using namespace s64;
+    extern __shared__ double2 lds2[];
+    double2* const bufA = lds2;
+    double2* const bufB = lds2 + BUF;
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    for (int t = tid; t < F * F; t += kThreads) {
+        const int i0 = t >> 6, i1 = t & 63;
+        double2 x = make_double2(0.0, 0.0);
+        if (i0 < L0 && i1 < L1) {
+            if (REAL) x.x = ((const double*)src)[b * src_stride + i0 * L1 + i1];
+            else x = ((const double2*)src)[b * src_stride + i0 * L1 + i1];
+        }
+        bufA[i0 * LD + i1] = x;
+    }
+    const int c = tid & 63, j = tid >> 6;
+    double2 tw[7];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) {
+        double sn, cs;
+        sincospi(-(double)(j * t) / 32.0, &sn, &cs);
+        tw[t - 1] = make_double2(cs, sn);
+    }
+    __syncthreads();
+    double2 x[8];
+    load8_all<8>(bufA + c * LD + j, x);
+    dft_fwd<8>(x);
+    store8_all<1>(bufB + c * LD + j * 8, x);
+    __syncthreads();
+    load8_all<8>(bufB + c * LD + j, x);
+    twiddle8(x, tw);
+    dft_fwd<8>(x);
+    store8_all<8>(bufA + c * LD + j, x);
+    __syncthreads();
+    load8_all<8 * LD>(bufA + j * LD + c, x);
+    dft_fwd<8>(x);
+    store8_all<LD>(bufB + j * 8 * LD + c, x);
+    __syncthreads();
+    load8_all<8 * LD>(bufB + j * LD + c, x);
+    twiddle8(x, tw);
+    dft_fwd<8>(x);
+    double2* out = dst + b * dst_stride;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) out[(j + 8 * t) * F + c] = x[t];
+}
+
+}  // namespace pcg
+
+int fft2d64_batch_launch(const void* src, int src_is_real, int64_t src_stride, int L0, int L1, double2* dst, int64_t dst_stride,
+                         int nbatch, hipStream_t stream) {
+    using namespace pcg;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)fft2d64_batch_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)fft2d64_batch_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        if (e != hipSuccess) {
+            set_error("64 x 64 batched transform: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return EFGP_EHIP;
+        }
+        attr = true;
+    }
+    const size_t lds = (size_t)2 * s64::BUF * sizeof(double2);
+    if (src_is_real) hipLaunchKernelGGL(fft2d64_batch_kernel<true>, dim3(nbatch), dim3(kThreads), lds, stream, src, src_stride, L0, L1, dst, dst_stride);
+    else hipLaunchKernelGGL(fft2d64_batch_kernel<false>, dim3(nbatch), dim3(kThreads), lds, stream, src, src_stride, L0, L1, dst, dst_stride);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("64 x 64 batched transform launch failed: %s", hipGetErrorString(e));
+        return EFGP_EHIP;
+    }
+    return EFGP_OK;
+}
+
+namespace pcg {
+
 }  // namespace pcg
 
 bool toeplitz_vhat_fused_eligible(const ToepGeom& g) {

@@ -33,6 +33,9 @@ int persistent_cg_launch(const ToepGeom& g, const double2* const* twiddles, cons
 // spectrum of the Toeplitz vector on the 64 x 64 circulant grid in one launch (cg_persistent.hip)
 bool toeplitz_vhat_fused_eligible(const ToepGeom& g);
 int toeplitz_vhat_fused_launch(const double2* v, int L0, int L1, double factor, double2* vhat, hipStream_t stream);
+// forward 64 x 64 transforms of nbatch zero-padded L0 x L1 arrays (complex or real), one workgroup each (cg_persistent.hip)
+int fft2d64_batch_launch(const void* src, int src_is_real, int64_t src_stride, int L0, int L1, double2* dst, int64_t dst_stride,
+                         int nbatch, hipStream_t stream);
 
 // y[row] = post .* T(pre .* x[row]) on the 64 x 64 circulant grid in one launch (cg_persistent.hip)
 bool toeplitz_apply_fused_eligible(const ToepGeom& g);

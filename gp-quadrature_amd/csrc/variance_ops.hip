@@ -6,8 +6,10 @@
 // so a caller that binds only include/efgp_hip.h can compute a variance end to end.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.hpp"
+#include "toeplitz_cg.hpp"
 
 namespace efgp {
 
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void lag_pad_kernel(LagGeom g, const double2* 
 
 // acc[i] (+)= sum_j G_j[i] conj(E_j[i])   (the inverse transform is linear: one inverse FFT of the probe sum)
 __global__ __launch_bounds__(256) void lag_mul_sum_kernel(int64_t S, int J, const double2* __restrict__ pad, double2* __restrict__ acc,
-                                                          int add) {
+                                                          int add, int conj_out = 0) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
         double re = 0.0, im = 0.0;
         for (int j = 0; j < J; ++j) {
@@ -59,14 +61,15 @@ __global__ __launch_bounds__(256) void lag_mul_sum_kernel(int64_t S, int J, cons
         }
         if (add) {
             re += acc[i].x;
-            im += acc[i].y;
+            im += conj_out ? -acc[i].y : acc[i].y;
         }
-        acc[i] = make_double2(re, im);
+        acc[i] = make_double2(re, conj_out ? -im : im);       // conj_out: the accumulator holds conj(sum) throughout
     }
 }
 
 // out (lag box s, FFT order) = factor * the same lags of the padded correlation (length p per dimension, FFT order)
-__global__ __launch_bounds__(256) void lag_scale_kernel(LagGeom g, double factor, const double2* __restrict__ in, double2* __restrict__ out) {
+__global__ __launch_bounds__(256) void lag_scale_kernel(LagGeom g, double factor, const double2* __restrict__ in, double2* __restrict__ out,
+                                                        int conj_in = 0) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < g.S; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t r = i;
         int c[3];
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void lag_scale_kernel(LagGeom g, double factor
             const int lag = c[a] < g.n[a] ? c[a] : c[a] - g.s[a];      // FFT order of the lag box: 0..n-1, -(n-1)..-1
             src = src * g.p[a] + (lag >= 0 ? lag : lag + g.p[a]);
         }
-        out[i] = make_double2(in[src].x * factor, in[src].y * factor);
+        out[i] = make_double2(in[src].x * factor, (conj_in ? -in[src].y : in[src].y) * factor);
     }
 }
 
@@ -196,6 +199,34 @@ int efgp_lag_sums(int device, int dim, int64_t mtot, const void* gamma, const do
         g.P *= g.p[a];
     }
     for (int a = 0; a < dim; ++a) sizes[a] = lag_length((int)(2 * mtot - 1));
+    if (dim == 2 && 2 * mtot - 1 <= 64 && std::getenv("EFGP_NO_LAG64") == nullptr) {
+        // 2-D lag boxes up to 64 x 64 (mtot <= 32): every transform on the library's own one-workgroup 64 x 64 kernel -- the first
+        // variance of a process otherwise waits 1.8 s for rocFFT to compile a length-48 kernel.  The inverse transform is the forward
+        // one on the conjugate: the accumulator is kept conjugated and the copy-out conjugates back.
+        g.p[1] = g.p[2] = 64;
+        g.P = 4096;
+        const int64_t per64 = std::max<int64_t>(1, std::min<int64_t>(nprobes, ((int64_t)256 << 20) / (int64_t)(2 * g.P * sizeof(double2))));
+        double2* pad64 = (double2*)scratch(ctx, SLOT_TOEP_PAD, (size_t)(2 * per64 + 2) * g.P * sizeof(double2));
+        if (!pad64) return EFGP_ENOMEM;
+        double2* acc64 = pad64 + (int64_t)2 * per64 * g.P;
+        double2* inv64 = acc64 + g.P;
+        for (int64_t j0 = 0; j0 < nprobes; j0 += per64) {
+            const int J = (int)std::min<int64_t>(per64, nprobes - j0);
+            int rc = fft2d64_batch_launch((const double2*)gamma + j0 * g.M, 0, g.M, (int)mtot, (int)mtot, pad64, 2 * g.P, J, stream);
+            if (rc != EFGP_OK) return rc;
+            rc = fft2d64_batch_launch(eta + j0 * g.M, 1, g.M, (int)mtot, (int)mtot, pad64 + g.P, 2 * g.P, J, stream);
+            if (rc != EFGP_OK) return rc;
+            hipLaunchKernelGGL(lag_mul_sum_kernel, dim3(16), dim3(256), 0, stream, g.P, J, (const double2*)pad64, acc64, j0 > 0 ? 1 : 0, 1);
+            EFGP_HIP_CHECK(hipGetLastError());
+        }
+        int rc = fft2d64_batch_launch(acc64, 0, g.P, 64, 64, inv64, g.P, 1, stream);
+        if (rc != EFGP_OK) return rc;
+        const int ob = (int)std::max<int64_t>(1, std::min<int64_t>((g.S + 255) / 256, 1024));
+        hipLaunchKernelGGL(lag_scale_kernel, dim3(ob), dim3(256), 0, stream, g, 1.0 / ((double)g.P * (double)nprobes), (const double2*)inv64,
+                           (double2*)out, 1);
+        EFGP_HIP_CHECK(hipGetLastError());
+        return EFGP_OK;
+    }
     // probes are processed in slabs so that the padded transforms stay within ~256 MB of scratch
     const int64_t per = std::max<int64_t>(1, std::min<int64_t>(nprobes, ((int64_t)256 << 20) / (int64_t)(2 * g.P * sizeof(double2))));
     double2* pad = (double2*)scratch(ctx, SLOT_TOEP_PAD, (size_t)(2 * per + 1) * g.P * sizeof(double2));

@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 
 
 # the transform runs at the next 2^k / 3 * 2^k length >= 2 mtot - 1 (exact at mtot 1, 2; padded elsewhere): same lags
-@pytest.mark.parametrize("d,mtot,J", [(1, 35, 5), (2, 23, 7), (2, 8, 3), (3, 9, 4), (1, 1, 2), (2, 2, 3), (2, 17, 2), (3, 13, 2), (1, 301, 2)])
+@pytest.mark.parametrize("d,mtot,J", [(1, 35, 5), (2, 23, 7), (2, 8, 3), (3, 9, 4), (1, 1, 2), (2, 2, 3), (2, 17, 2), (3, 13, 2), (1, 301, 2),
+                                      (2, 32, 2), (2, 33, 2)])     # 2-D lag boxes up to 64 x 64 run on the library's own 64 x 64 transforms
 def test_lag_sums_match_fft_correlation(d, mtot, J):
     from efgp_hip import lag_sums
     g = torch.Generator().manual_seed(3)
