@@ -42,3 +42,12 @@ lap("first predict at the N points", lambda: model.predict(x, return_variance=Fa
 lap("second predict", lambda: model.predict(x, return_variance=False))
 lap("first gradient step (T=5)", lambda: model.compute_gradients(trace_samples=5, cg_tol=1e-3))
 lap("second gradient step", lambda: model.compute_gradients(trace_samples=5, cg_tol=1e-3))
+xq = x[:2000].contiguous()
+import contextlib  # noqa: E402
+import io  # noqa: E402
+with contextlib.redirect_stdout(io.StringIO()):
+    lap_v1 = lambda: model.predict(xq, return_variance=True, variance_method="stochastic", hutchinson_probes=100)  # noqa: E731
+    t = time.perf_counter(); lap_v1(); torch.cuda.synchronize(); t1 = time.perf_counter() - t  # noqa: E702
+    t = time.perf_counter(); lap_v1(); torch.cuda.synchronize(); t2 = time.perf_counter() - t  # noqa: E702
+print(f"{'first stochastic variance (100 probes)':34s} {1e3 * t1:10.2f} ms")
+print(f"{'second stochastic variance':34s} {1e3 * t2:10.2f} ms")
