@@ -2373,8 +2373,10 @@ static char* scale_slot(DeviceCtx* ctx, hipStream_t stream) {
 
 // Level of the plan's point layout the MFMA spreader can use for this fine grid, or nullptr (no layout, not 2-D,
 // window wider than the register tile, too few points per run to amortise the tile flushes, EFGP_NO_MFMA_SPREAD).
-// Bands may be at most 8 cells high: the tile's 16 columns hold the 8-cell stencil at offsets 0..8.
-static SortedLevel* pick_level(efgp_nufft_s* plan, const WindowSet* w, const GridGeom& g, hipStream_t stream) {
+// *band_cells = bound on the height of the level's bands in fine cells: 1 for dense point sets (>= 192 points per run at
+// one-cell bands: the spreader then needs W + 1 tile columns, fits three waves per SIMD and stores seven zeros less per point),
+// else 8 (the tile's 16 columns hold the 8-cell stencil at offsets 0..8).  EFGP_MFMA_BAND_CELLS = 1 | 8 forces one.
+static SortedLevel* pick_level(efgp_nufft_s* plan, const WindowSet* w, const GridGeom& g, hipStream_t stream, int* band_cells) {
     efgp_points_s* pts = plan->points;
     if (!pts || plan->dim != 2 || w->p.w > kMfmaMaxW || plan->npts < 32768 || std::getenv("EFGP_NO_MFMA_SPREAD")) return nullptr;
     double span[2], far = 0.0;
@@ -2383,13 +2385,24 @@ static SortedLevel* pick_level(efgp_nufft_s* plan, const WindowSet* w, const Gri
         far = std::max(far, std::max(std::fabs(pts->hi[a] - plan->xcen[a]), std::fabs(pts->lo[a] - plan->xcen[a])) * std::fabs(g.scale[a]));
     }
     if (!(far < 1e9) || !(g.scale[0] > 0.0) || !(g.scale[1] > 0.0)) return nullptr;      // cell indices are kept in 32-bit ints
-    int nb = 1;
-    while (span[1] / nb > 8.0 - 1e-6 && nb <= kMaxBands) nb *= 2;
-    if (nb > kMaxBands) return nullptr;
-    const double runs = (double)nb * std::max(1.0, span[0]);
-    if ((double)plan->npts / runs < 24.0) return nullptr;
+    const char* force = std::getenv("EFGP_MFMA_BAND_CELLS");
+    const int forced = force ? std::atoi(force) : 0;
+    int nb = 0, cells = 0;
+    for (int hb : {1, 8}) {
+        if (forced && forced != hb) continue;
+        int n = 1;
+        while (span[1] / n > (double)hb - 1e-6 && n <= kMaxBands) n *= 2;
+        if (n > kMaxBands) continue;
+        const double per_run = (double)plan->npts / ((double)n * std::max(1.0, span[0]));
+        if (per_run < (forced ? 1.0 : (hb == 1 ? 192.0 : 24.0))) continue;
+        nb = n;
+        cells = hb;
+        break;
+    }
+    if (!nb) return nullptr;
     SortedLevel* lvl = nullptr;
     if (points_level(pts, nb, stream, &lvl) != EFGP_OK) return nullptr;
+    *band_cells = cells;
     return lvl;
 }
 
@@ -2482,7 +2495,8 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     const bool use_lds = lds_bytes <= (size_t)ctx->max_lds && plan->npts > 0;
     // 2-D plans made on a per-model point layout (efgp_nufft_create_on): MFMA register accumulation over
     // (band, x_0)-sorted points, no per-plan sorting (spread_mfma.hip)
-    if (SortedLevel* lvl = pick_level(plan, w, g, stream)) {
+    int band_cells = 8;
+    if (SortedLevel* lvl = pick_level(plan, w, g, stream, &band_cells)) {
         const double* ys = nullptr;
         if (c && c == plan->points->values && (mode == STR_REAL_AND_ONES || (mode == STR_REAL && nbatch == 1))) {
             int rc = points_level_values(plan->points, lvl, stream);
@@ -2526,7 +2540,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
                                job.scale, job.sum_bits);
         }
         EFGP_HIP_CHECK(hipGetLastError());
-        int rc = spread_mfma_launch(ctx, lvl, ys, src, g, w->p.w, w->d_coef, w->p.degree, channels, nbatch, gacc, d_scale, stream);
+        int rc = spread_mfma_launch(ctx, lvl, band_cells, ys, src, g, w->p.w, w->d_coef, w->p.degree, channels, nbatch, gacc, d_scale, stream);
         if (rc != EFGP_OK) return rc;
         if (g2m_eligible(plan, g, req)) {
             rc = g2m_launch(g, req, (long long*)gacc, nullptr, d_scale, channels, nbatch, isign, (unsigned int*)(misc + 40),

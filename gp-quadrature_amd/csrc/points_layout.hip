@@ -124,10 +124,13 @@ static void free_level(SortedLevel* l) {
     delete l;
 }
 
-// Chunk length: two waves per SIMD each get R chunks of at most ~1536 points (R rounds keep the tail of the
-// grid-stride loop short); multiples of 64 (one point per lane per batch).
+// Chunk length: every resident wave gets R chunks of at most ~1536 points (R rounds keep the tail of the grid-stride loop
+// short); multiples of 64 (one point per lane per batch).  The spreader runs 8 waves per CU (band levels up to 8 cells high) or
+// 12 (one-cell bands, dense point sets): from 4e6 points on the chunk count is sized for 24 waves per CU, a multiple of both
+// (N = 1e7: 12 k chunks of 832 points = 4.0 / 5.9 rounds).  Smaller sets keep the 8-wave sizing: every chunk end is a tile
+// flush (256 atomics), which must stay rare next to the points.
 static int chunk_length(int64_t npts, int num_cu) {
-    const int64_t waves = (int64_t)num_cu * 8;
+    const int64_t waves = (int64_t)num_cu * (npts >= 4000000 ? 24 : 8);
     const int64_t rounds = std::max<int64_t>(1, (npts + waves * 1536 - 1) / (waves * 1536));
     int64_t len = (npts + waves * rounds - 1) / (waves * rounds);
     len = (len + 63) / 64 * 64;

@@ -32,9 +32,12 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMfmaRow = 66;                  // doubles per LDS row: 64 points + 2 (bank spread)
 constexpr int kMfmaMaxWaves = 4;              // waves per workgroup (independent; 3 or 4, chosen at launch)
-constexpr int kMfmaRows = 32;                 // A: (channel, x cell) 16 rows; B: y cell + offset, 16 rows
-constexpr int kMfmaWaveDoubles = kMfmaRows * kMfmaRow + 32;   // + 64 ints: x cell of every point
-static size_t mfma_lds_bytes(int waves) { return (size_t)waves * kMfmaWaveDoubles * sizeof(double); }
+// LDS rows of a wave: A = (channel, x cell) 16 rows, then B = y cell + offset, W + HB rows, where HB bounds the height of a band
+// in fine cells (the stencils of a band start at offsets 0..HB).  HB = 8: any band level, B fills the tile's 16 columns; HB = 1
+// (dense point sets, round 3): 9 rows at W = 8 -- 13.2 KB per wave instead of 16.9, seven zero-fill stores less per point, and
+// with 168 VGPRs THREE waves per SIMD instead of two.  The x cell of every point (64 ints) lives in the rows' padding doubles.
+__host__ __device__ constexpr int mfma_rows(int W, int HB) { return 16 + W + HB; }
+static size_t mfma_lds_bytes(int waves, int W, int HB) { return (size_t)waves * mfma_rows(W, HB) * kMfmaRow * sizeof(double); }
 
 struct MfmaSpreadArgs {
     const double* xs;
@@ -52,7 +55,7 @@ struct MfmaSpreadArgs {
     int channels;
     unsigned long long* gacc;
     const double* scale;
-    int diag;                  // diagnostics (EFGP_MFMA_DIAG): 1 skips the MFMA phase, 2 the window polynomials, 4 the LDS writes
+    int diag;                  // diagnostic build only (-DEFGP_MFMA_DIAG, env EFGP_MFMA_DIAG): 1 skips the MFMA phase, 2 the window polynomials, 4 the LDS writes
 };
 
 // Window values of both dimensions from the offsets s in [-1, 1): symmetric Horner (see window_eval).
@@ -153,14 +156,15 @@ __device__ __forceinline__ int pos_mod(int a, int n) {
     return r < 0 ? r + n : r;
 }
 
+// `live`: this lane's tile column exists (c16 < W + HB; the columns beyond accumulate whatever the clamped operand reads return)
 template <int W>
-__device__ __forceinline__ void flush_tile(const d4& acc, int cur_bx, int q, int ycell, int nf0, int nf1, int64_t cells, int channels,
-                                           double S0, double S1, unsigned long long* __restrict__ gch) {
+__device__ __forceinline__ void flush_tile(const d4& acc, int cur_bx, int q, int ycell, bool live, int nf0, int nf1, int64_t cells,
+                                           int channels, double S0, double S1, unsigned long long* __restrict__ gch) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = q + 4 * r, ch = row >> 3, i = row & 7;       // ch is a compile-time function of r
         const double v = acc[r];
-        if (i < W && ch < channels && v != 0.0) {
+        if (live && i < W && ch < channels && v != 0.0) {
             const int xc = pos_mod(cur_bx + i, nf0);
             const long long f = __double2ll_rn(v * (ch ? S1 : S0));
             __hip_atomic_fetch_add(gch + (int64_t)ch * cells + (int64_t)xc * nf1 + ycell, (unsigned long long)f, __ATOMIC_RELAXED,
@@ -189,13 +193,23 @@ __device__ __forceinline__ PointIn load_point(const MfmaSpreadArgs& a, int batch
     return r;
 }
 
-template <int W, int DEG, bool SORTED>
-__global__ __launch_bounds__(64 * kMfmaMaxWaves, 2) void spread_mfma_kernel(MfmaSpreadArgs a) {
+#ifdef EFGP_MFMA_DIAG
+#define EFGP_DIAG(bit_) (a.diag & (bit_))
+#else
+#define EFGP_DIAG(bit_) false
+#endif
+
+template <int W, int DEG, bool SORTED, int HB>
+__global__ __launch_bounds__(64 * kMfmaMaxWaves, HB == 1 ? 3 : 2) void spread_mfma_kernel(MfmaSpreadArgs a) {
     extern __shared__ double lds_raw[];
+    constexpr int BR = W + HB;                    // B rows = tile columns in use
+    constexpr int kWaveDoubles = mfma_rows(W, HB) * kMfmaRow;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-    double* A = lds_raw + (size_t)wave * kMfmaWaveDoubles;
+    double* A = lds_raw + (size_t)wave * kWaveDoubles;
     double* B = A + 16 * kMfmaRow;
-    int* bxs = reinterpret_cast<int*>(A + kMfmaRows * kMfmaRow);
+    // x cell of point l: an int in the padding of row l >> 2 (two doubles = four ints behind the 64 points of every row)
+    int* bxs = reinterpret_cast<int*>(A + 64);
+    constexpr int kBxRow = 2 * kMfmaRow;          // ints per row
     WindowCoef<W, DEG> wc;
     wc.load(a.coef);
     const int batch = blockIdx.y;
@@ -204,6 +218,7 @@ __global__ __launch_bounds__(64 * kMfmaMaxWaves, 2) void spread_mfma_kernel(Mfma
     const double S0 = a.scale[0], S1 = a.scale[2];
     unsigned long long* gch = a.gacc + (int64_t)batch * a.channels * cells;
     const int q = lane >> 4, c16 = lane & 15;
+    const bool live = c16 < BR;
     if (W < 8) {                                  // A rows of the unused stencil cells stay zero
 #pragma unroll
         for (int r = W; r < 8; ++r) {
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(64 * kMfmaMaxWaves, 2) void spread_mfma_kernel(Mfma
         }
     }
     const double* Ard = A + c16 * kMfmaRow + q;   // this lane's operand elements of step g: Ard[4 g], Brd[4 g]
-    const double* Brd = B + c16 * kMfmaRow + q;
+    const double* Brd = B + (live ? c16 : 0) * kMfmaRow + q;      // columns beyond BR: a valid row, the products are never flushed
     for (int chunk = blockIdx.x * nwaves + wave; chunk < a.nchunks; chunk += a.total_waves) {
         const int4 ci = reinterpret_cast<const int4*>(a.chunks)[chunk];
         const int start = __builtin_amdgcn_readfirstlane(ci.x), count = __builtin_amdgcn_readfirstlane(ci.y);
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(64 * kMfmaMaxWaves, 2) void spread_mfma_kernel(Mfma
             const double X0 = a.scale0 * (cur.xy.x - a.xcen0), X1 = a.scale1 * (cur.xy.y - a.xcen1);
             const double i0 = ceil(X0 - 0.5 * W), j0 = ceil(X1 - 0.5 * W);
             double v0[W], v1[W];
-            if (a.diag & 2) {
+            if (EFGP_DIAG(2)) {
 #pragma unroll
                 for (int i = 0; i < W; ++i) {
                     v0[i] = X0 + i;
@@ -247,8 +262,8 @@ __global__ __launch_bounds__(64 * kMfmaMaxWaves, 2) void spread_mfma_kernel(Mfma
             } else {
                 horner2<W, DEG>(wc, a.coef, a.degree, 2.0 * (i0 - X0 + 0.5 * W) - 1.0, 2.0 * (j0 - X1 + 0.5 * W) - 1.0, v0, v1);
             }
-            const int bx = (int)i0, off = (int)j0 - by0;                      // 0 <= off <= 8 (bands are at most 8 cells high)
-            if (!(a.diag & 4)) {
+            const int bx = (int)i0, off = (int)j0 - by0;                      // 0 <= off <= HB (bands are at most HB cells high)
+            if (!EFGP_DIAG(4)) {
 #pragma unroll
                 for (int i = 0; i < W; ++i) {
                     A[i * kMfmaRow + lane] = c0 * v0[i];
@@ -256,22 +271,25 @@ __global__ __launch_bounds__(64 * kMfmaMaxWaves, 2) void spread_mfma_kernel(Mfma
                     B[(off + i) * kMfmaRow + lane] = v1[i];
                 }
 #pragma unroll
-                for (int i = 0; i < 16 - W; ++i)                              // the 16 - W columns outside [off, off + W) are zero
+                for (int i = 0; i < HB; ++i)                                  // the HB rows outside [off, off + W) are zero
                     B[((i < off) ? i : i + W) * kMfmaRow + lane] = 0.0;
             } else {
                 acc[0] += v0[0] * c0 + v1[W - 1] * c1 + v0[W / 2] + v1[W / 2];
             }
-            bxs[lane] = bx;
+            bxs[(lane >> 2) * kBxRow + (lane & 3)] = bx;
             if (b0 == 0) cur_bx = __builtin_amdgcn_readfirstlane(bx);
             int prev = __shfl_up(bx, 1, 64);
             if (lane == 0) prev = cur_bx;
             const unsigned long long mask = __ballot(bx != prev);              // run starts inside this batch
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (a.diag & 1) {
+            if (EFGP_DIAG(1)) {
                 acc[1] += A[lane] + B[lane];
             } else if (mask == 0ull && rem >= 64) {
                 // whole batch continues the current run: 16 operand pairs, 16 back-to-back MFMAs, no branches
+                // (round 3, measured: a sched_barrier between the reads and the MFMAs -- all 16 operand reads in flight, counted
+                // lgkmcnt waits -- changes nothing, 212 us either way at N = 1e7: the other waves of the SIMD hide the round
+                // trips, and the 64 operand VGPRs would stand in the way of a third wave)
                 double av[16], bv[16];
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
@@ -290,9 +308,9 @@ __global__ __launch_bounds__(64 * kMfmaMaxWaves, 2) void spread_mfma_kernel(Mfma
                     } else {
                         for (int k = 0; k < 4; ++k) {                          // a run ends inside these four points
                             if ((bits >> k) & 1u) {
-                                flush_tile<W>(acc, cur_bx, q, ycell, nf0, nf1, cells, a.channels, S0, S1, gch);
+                                flush_tile<W>(acc, cur_bx, q, ycell, live, nf0, nf1, cells, a.channels, S0, S1, gch);
                                 acc = d4{0.0, 0.0, 0.0, 0.0};
-                                cur_bx = __builtin_amdgcn_readfirstlane(bxs[4 * g + k]);
+                                cur_bx = __builtin_amdgcn_readfirstlane(bxs[g * kBxRow + k]);
                             }
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(q == k ? av : 0.0, bv, acc, 0, 0, 0);
                         }
@@ -302,15 +320,15 @@ __global__ __launch_bounds__(64 * kMfmaMaxWaves, 2) void spread_mfma_kernel(Mfma
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();                                   // the next batch overwrites the rows
         }
-        flush_tile<W>(acc, cur_bx, q, ycell, nf0, nf1, cells, a.channels, S0, S1, gch);
+        flush_tile<W>(acc, cur_bx, q, ycell, live, nf0, nf1, cells, a.channels, S0, S1, gch);
     }
 }
 
-template <int W>
+template <int W, int HB>
 static hipError_t launch_w(dim3 grid, int waves, hipStream_t s, const MfmaSpreadArgs& a) {
     const bool fixed_deg = a.degree == W + 1;          // what es_make_params picks for every standard tolerance
     const bool sorted = a.ys != nullptr;
-    const size_t lds = mfma_lds_bytes(waves);
+    const size_t lds = mfma_lds_bytes(waves, W, HB);
     const dim3 block(64 * waves);
 #define EFGP_GO(kern_)                                                                                               \
     do {                                                                                                             \
@@ -321,17 +339,18 @@ static hipError_t launch_w(dim3 grid, int waves, hipStream_t s, const MfmaSpread
         }                                                                                                            \
         hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                               \
     } while (0)
-    if (fixed_deg && sorted) EFGP_GO((spread_mfma_kernel<W, W + 1, true>));
-    else if (fixed_deg) EFGP_GO((spread_mfma_kernel<W, W + 1, false>));
-    else if (sorted) EFGP_GO((spread_mfma_kernel<W, 0, true>));
-    else EFGP_GO((spread_mfma_kernel<W, 0, false>));
+    if (fixed_deg && sorted) EFGP_GO((spread_mfma_kernel<W, W + 1, true, HB>));
+    else if (fixed_deg) EFGP_GO((spread_mfma_kernel<W, W + 1, false, HB>));
+    else if (sorted) EFGP_GO((spread_mfma_kernel<W, 0, true, HB>));
+    else EFGP_GO((spread_mfma_kernel<W, 0, false, HB>));
 #undef EFGP_GO
     return hipGetLastError();
 }
 
-int spread_mfma_launch(DeviceCtx* ctx, const SortedLevel* lvl, const double* ys_sorted, const StrengthSrc& src, const GridGeom& g,
-                       int W, const double* coef, int degree, int channels, int nbatch, unsigned long long* gacc,
+int spread_mfma_launch(DeviceCtx* ctx, const SortedLevel* lvl, int band_cells, const double* ys_sorted, const StrengthSrc& src,
+                       const GridGeom& g, int W, const double* coef, int degree, int channels, int nbatch, unsigned long long* gacc,
                        const double* scale, hipStream_t stream) {
+    EFGP_REQUIRE(band_cells == 1 || band_cells == 8, "spread_mfma: band height bound must be 1 or 8 cells");
     EFGP_REQUIRE(W >= 2 && W <= kMfmaMaxW, "spread_mfma: window width %d outside 2..%d", W, kMfmaMaxW);
     EFGP_REQUIRE(channels == 1 || channels == 2, "spread_mfma: channels must be 1 or 2");
     EFGP_REQUIRE(lvl && lvl->nchunks > 0, "spread_mfma: empty level");
@@ -361,7 +380,9 @@ int spread_mfma_launch(DeviceCtx* ctx, const SortedLevel* lvl, const double* ys_
     // waves and compact rows 231-241 us; a software-pipelined one-wave-per-SIMD variant with double-buffered rows that
     // interleaves the polynomials of batch n + 1 with the MFMAs of batch n 288-296 us -- the compiler's conservative
     // s_waitcnt vmcnt(0) at the merge of its two paths exposes the HBM latency of the prefetched points.)
-    int waves = 4, per_cu = 2;
+    // Round 3, bands at most ONE cell high (band_cells = 1; pick_level chooses it for dense point sets): 13.2 KB of rows per
+    // wave and 168 VGPRs -> three workgroups of four waves per CU.
+    int waves = 4, per_cu = band_cells == 1 ? 3 : 2;
     if (const char* e1 = std::getenv("EFGP_MFMA_WAVES")) waves = std::max(1, std::min(kMfmaMaxWaves, std::atoi(e1)));
     if (const char* e2 = std::getenv("EFGP_MFMA_BLOCKS_PER_CU")) per_cu = std::max(1, std::atoi(e2));
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)lvl->nchunks + waves - 1) / waves, (int64_t)ctx->num_cu * per_cu));
@@ -374,7 +395,11 @@ int spread_mfma_launch(DeviceCtx* ctx, const SortedLevel* lvl, const double* ys_
     {
         KernelTimer timer("spread", stream);
         switch (W) {
-#define EFGP_CASE(w_) case w_: e = launch_w<w_>(dim3(blocks, nbatch), waves, stream, a); break;
+#define EFGP_CASE(w_)                                                                                  \
+    case w_:                                                                                           \
+        e = band_cells == 1 ? launch_w<w_, 1>(dim3(blocks, nbatch), waves, stream, a)                  \
+                            : launch_w<w_, 8>(dim3(blocks, nbatch), waves, stream, a);                 \
+        break;
             EFGP_CASE(2) EFGP_CASE(3) EFGP_CASE(4) EFGP_CASE(5) EFGP_CASE(6) EFGP_CASE(7) EFGP_CASE(8)
 #undef EFGP_CASE
             default: e = hipErrorInvalidValue;

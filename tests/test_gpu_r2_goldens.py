@@ -105,28 +105,39 @@ def test_slq_logdet_and_log_marginals(name):
 @pytest.mark.parametrize("name", ["c1_se1d_n5000", "c2_se2d_n100000", "c3_matern52_usatemp"])
 def test_adam_trajectory_matches_reference(name):
     """Three Adam steps of the reference's training loop (efgpnd.py:1068-1226: compute_gradients -> opt.step, lr 0.05)
-    with the probes the reference drew at every step: gradients and hyper-parameters after each step."""
+    with the probes the reference drew at every step: gradients and hyper-parameters after each step.
+
+    Bounds (round 3): 10 x what the REFERENCE's own trajectory moves by -- under a 1e-13 perturbation of its Toeplitz vector and
+    with every NUFFT result carrying a relative error of 1e-11 / 1e-10 (oracle/gen_golden_r3.py stores those moves as `sens_cold_*`
+    in <case>_r3.npz) -- with floors of 1e-9 (hyper-parameters) and 1e-8 of the gradient scale.  Round 2 had to allow 1e-5 here and
+    called it rounding; it was the Hermitian 64 x 64 solver handing the anti-Hermitian rounding noise of its k0 = 0 row to the
+    operator (cg_persistent.hip, phase B): the true residual of these cg_tol = 1e-12 solves stalled at 2e-6 where the reference
+    reaches 7e-10.  With the projection in place the trajectory sits at the reference's own sensitivity (c2: 2.8e-9 against 4.7e-9)."""
     g, x, y = load_case(name)
     r2 = load_r2(name)
+    r3 = dict(np.load(f"{GOLDEN}/{name}_r3.npz", allow_pickle=False))
+    s_traj = max(float(r3["sens_cold_traj"]), float(r3["sens_cold_nufft1e11_traj"]), float(r3["sens_cold_nufft1e10_traj"]))
+    s_grad = max(float(r3["sens_cold_grad"]), float(r3["sens_cold_nufft1e11_grad"]), float(r3["sens_cold_nufft1e10_grad"]))
     traj, grads, Ms = r2["adam_traj"], r2["adam_grads"], r2["adam_M"]
+    assert np.abs(r3["cold_traj"] - traj).max() < 1e-12 * np.abs(traj).max()      # the sensitivity runs restate this trajectory
     T = int(r2["adam_T"])
     N = x.shape[0]
-    m = make_model(name, g, x.cuda(), y.cuda(), 1e-12)
+    m = make_model(name, g, x.cuda(), y.cuda(), 1e-12, nufft_eps=1e-12)
     opt = torch.optim.Adam(m._gp_params.parameters(), lr=float(r2["adam_lr"]))
     m.register_optimizer(opt)
+    worst = worst_g = 0.0
     for i in range(traj.shape[0]):
         Z = torch.from_numpy(np.unpackbits(r2[f"adam_Z{i}"], axis=1)[:, :N].astype(np.float64) * 2 - 1)
         V = torch.from_numpy(r2[f"adam_V{i}"].astype(np.float64))
         opt.zero_grad()
-        grad = m.compute_gradients(trace_samples=T, nufft_eps=1e-9, cg_tol=1e-12, probes_Z=Z, probes_V=V)
+        grad = m.compute_gradients(trace_samples=T, nufft_eps=1e-12, cg_tol=1e-12, probes_Z=Z, probes_V=V)
         assert int(m.last_gradient_stats["feature_count"]) == int(Ms[i])
         scale = float(np.abs(grads[i]).max())
-        assert float((grad.detach().cpu() - torch.from_numpy(grads[i])).abs().max()) < 2e-5 * scale, (i, grad, grads[i])
+        worst_g = max(worst_g, float((grad.detach().cpu() - torch.from_numpy(grads[i])).abs().max()) / scale)
         opt.step()
         now = np.array([float(m.kernel.get_hyper(n)) for n in m.kernel.hypers] + [float(m.sigmasq.detach())])
-        # Adam moves a log-parameter by lr * m / sqrt(v): a gradient component that deviates by delta RELATIVE TO ITSELF moves its
-        # hyper-parameter by ~lr * delta, and the bound above is relative to the LARGEST component.  These solves end at their
-        # iteration cap (cond(D T D) ~ 1e10 at cg_tol = 1e-12), where rounding-level differences between transform sequences
-        # (rocFFT vs the pruned DFT of small grids) show up at 1e-10..3e-7 of the gradient scale from step to step: 2e-7..3e-6 in
-        # the hypers, against the north star's 1e-5.
-        assert np.abs(now - traj[i]).max() < 1e-5 * np.abs(traj[i]).max(), (i, now, traj[i])
+        worst = max(worst, float(np.abs(now - traj[i]).max() / np.abs(traj[i]).max()))
+    print(f"\n{name}: 3 cold Adam steps: gradients deviate by at most {worst_g:.2e} of their scale (the reference's own move: "
+          f"{s_grad:.2e}), hyper-parameters by {worst:.2e} (the reference's own: {s_traj:.2e})")
+    assert worst_g < max(10.0 * s_grad, 1e-8), (name, worst_g, s_grad)
+    assert worst < max(10.0 * s_traj, 1e-9), (name, worst, s_traj)

@@ -37,9 +37,13 @@ def _data(N, seed, lo=-1.0, hi=1.0, cluster=False):
     (40000, 0.31, 23, 45, 6e-8, {"cluster": True}),
     (40000, 0.05, 23, 45, 6e-8, {"lo": 2.0, "hi": 9.0}),   # shifted box, one band
 ])
-def test_pair_on_layout_vs_exact(N, h, nm_y, nm_o, tol, kw):
+@pytest.mark.parametrize("band_cells", [8, 1])
+def test_pair_on_layout_vs_exact(N, h, nm_y, nm_o, tol, kw, band_cells, monkeypatch):
+    """band_cells: the two tile geometries of the spreader -- band levels up to 8 fine cells high (16 tile columns) and
+    one-cell bands (W + 1 columns, three waves per SIMD; chosen by itself from 192 points per run on, forced here)."""
     from efgp_hip import NufftPlan, PointSet
     from oracle import efgp_oracle as O
+    monkeypatch.setenv("EFGP_MFMA_BAND_CELLS", str(band_cells))
     x, y = _data(N, 3, **kw)
     xd, yd = x.cuda(), y.cuda()
     pts = PointSet(xd, values=yd)
