@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Benchmark of the EFGP solve path on MI355X: GP-fits/s and CG-iter/s.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU -- under torch.distributed.run as the
+                                                            driver starts it, or started by bench.py itself when WORLD_SIZE is unset;
+                                                            every rank checks WORLD_SIZE == N and exits non-zero otherwise)
 
 Workload (BASELINE.json metric "GP-fits/sec + CG-iter/sec, N=1e6 d=2 SE kernel"; inputs as in the
 reference's timing driver test_timing_profiling.py:18-44): x ~ U[-1,1]^2 (float64, seeded),
@@ -151,6 +153,21 @@ def north_star(dev, rank, world, distributed, barrier):
             "survey_bytes": survey_bytes, "actual_bytes": actual_bytes}
 
 
+def launch_ranks(n, argv):
+    """One child process per GPU via torch.distributed.run on 127.0.0.1 (a free port), started BEFORE anything in this process
+    touches the GPU; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,16 +176,31 @@ def main():
     ap.add_argument("--global-n", type=int, default=N_PER_GPU, help="points of the GLOBAL problem, sharded over the ranks")
     ap.add_argument("--no-extras", action="store_true", help="skip the weak-scaling and north-star legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-launch", action="store_true", help="print this rank's place in the job and exit (no GPU needed): "
+                                                                "checks the launcher and the WORLD_SIZE == --gpus rule")
     ap.add_argument("--main-only", action="store_true",
                     help="timed steps only (no CG-rate / gradient / CPU-baseline extras): for rocprofv3 --pmc passes, so "
                          "that every profiled launch belongs to the fit step")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU yet -- start the N ranks as children through
+        # torch.distributed.run (one process per GPU, RCCL over xGMI) and leave with their exit code
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # a line that claims n_gpus = world while the caller asked for another count would be a wrong measurement
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    if args.check_launch:
+        print(f"bench.py rank {rank} of {world} (local {local})", flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU (no CPU fallback in the product path)")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local} but this node shows {torch.cuda.device_count()} device(s)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     distributed = world > 1
@@ -352,7 +384,8 @@ def main():
             "metric": "GP-fits/sec (fit + posterior mean at the N training points), N=1e6 d=2 SE kernel",
             "value": fits_per_s,
             "unit": "GP fits/s of the global N=1e6 problem (whole job; the points are sharded over the GPUs)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "rccl_ranks": world if distributed else 0, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D squared-exponential l=0.2 var=2 sigma2=0.2, eps=1e-4, global N=1e6 synthetic "
                                    "(BASELINE configs[1] at the metric's N=1e6), points sharded over the GPUs",

@@ -55,6 +55,7 @@ enum Slot {
     SLOT_CG_SCALARS,   // per-row scalars and flags of the CG solver
     SLOT_MISC,         // reductions
     SLOT_SCALE,        // fixed-point scale of the spreader
+    SLOT_G2M,          // grid_to_modes_kernel: per-tile arrival counters (first 64 KB, zero between launches) + partial sums
     SLOT_COUNT
 };
 
@@ -83,6 +84,8 @@ struct DeviceCtx {
     std::map<int64_t, void*> twiddles;
     // SLOT_SCALE holds the spreader's max|c| accumulator: zeroed once, then reset by the kernel that consumes it
     bool scale_slot_ready = false;
+    // SLOT_G2M's counter block has been zeroed for the buffer currently allocated (the kernel leaves it zero)
+    const void* g2m_zeroed_for = nullptr;
     // leading bytes of SLOT_SLABS known to be zero: the MFMA spreader's int64 grid is reset by the kernel that converts it,
     // so the next spread needs no memset launch (any other request for the slot clears this)
     size_t slabs_zero_bytes = 0;

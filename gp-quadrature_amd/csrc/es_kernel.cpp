@@ -14,17 +14,21 @@ double es_window(double z, double beta) {
     return std::exp(beta * (std::sqrt(q) - 1.0));
 }
 
-static const double kSigmaCalibrated = 3.0;   // upper end of the upsampling ratios the width formula was fitted on
+static const double kSigmaCalibrated = 5.0;   // upper end of the upsampling ratios the width formula was fitted on
+
+// Measured l2 error of this window (1-D, exact window values, against the exact sums; round 3 re-measured for sigma up to 5):
+//   err ~ C(sigma) exp(-pi w sqrt(1 - 1/sigma)),   C = e^1.5 for sigma <= 2.6, growing linearly to ~3 e^1.5 at sigma = 5
+// (the shape parameter beta = 0.976 pi w (1 - 1/(2 sigma)) is the sigma = 2 optimum carried along; it loses a factor 2-3 on
+// fine grids: w = 7 at sigma = 3.2 / 4.3 measured 1.2e-7 / 5e-8).
+static double es_log_error_constant(double sigma) { return 1.5 + std::log1p(std::max(0.0, sigma - 2.6)); }
 
 int es_width_for_tol(double tol, double sigma) {
-    // Measured l2 error of this window is ~5 exp(-pi w sqrt(1-1/sigma)) (calibrated against the
-    // exact transform for sigma in [1.25, 3]); invert it for w.
     if (!(tol > 0.0)) tol = 1e-16;
     if (tol < 1e-16) tol = 1e-16;
     if (sigma < 1.1) sigma = 1.1;
     if (sigma > kSigmaCalibrated) sigma = kSigmaCalibrated;
     double rate = M_PI * std::sqrt(1.0 - 1.0 / sigma);
-    int w = (int)std::ceil((std::log(1.0 / tol) + 1.5) / rate);
+    int w = (int)std::ceil((std::log(1.0 / tol) + es_log_error_constant(sigma)) / rate);
     return std::min(kMaxWidth, std::max(2, w));
 }
 
@@ -89,7 +93,7 @@ int es_make_params(double tol, double sigma, EsParams* p) {
     if (!p) return -1;
     std::memset(p, 0, sizeof(*p));
     // Tiny mode boxes sit on the 32-cell minimum grid (sigma up to ~10), outside the range the error model was
-    // calibrated on: design the window as for sigma = 3 (a finer grid than assumed only moves the aliases further
+    // calibrated on: design the window as for sigma = 5 (a finer grid than assumed only moves the aliases further
     // out).  Found by tools/fuzz_nufft.py: 3-D, 4 modes per axis, tol 1e-7 gave 1.2e-6 with the sigma = 8 window.
     if (sigma > kSigmaCalibrated) sigma = kSigmaCalibrated;
     p->w = es_width_for_tol(tol, sigma);
@@ -179,7 +183,7 @@ int64_t next_smooth_even(int64_t n) {
 // microseconds whatever its size, the spreaders' work per point does not depend on it, and a larger upsampling ratio only
 // narrows the window.  Larger grids (where cells cost memory and FFT time: beyond 512 per axis, 96 in 3-D) keep the dense
 // choice: among the 2^a3^b5^c even sizes in [2 n, 2.5 n] the one that needs the narrowest window (ties: the smallest grid).
-int64_t es_fine_size(int64_t n_modes, double tol, int dim) {
+int64_t es_fine_size(int64_t n_modes, double tol, int dim, bool dense) {
     const int64_t lo = std::max<int64_t>(32, next_smooth_even(2 * n_modes));
     const int64_t hi = std::max<int64_t>(lo, (5 * n_modes) / 2);
     int64_t best = lo;
@@ -192,14 +196,34 @@ int64_t es_fine_size(int64_t n_modes, double tol, int dim) {
         }
     }
     const int64_t coarse_limit = dim >= 3 ? 96 : 512;
+    int64_t pick = best;
     if (2 * n_modes <= coarse_limit && std::getenv("EFGP_DENSE_FINE_SIZES") == nullptr) {
         // the first ladder size that needs no wider a window than the dense choice (the width falls with the ratio)
-        for (int64_t p2 = 32;; p2 *= 2) {
+        pick = 0;
+        for (int64_t p2 = 32; !pick; p2 *= 2) {
             for (int64_t c : {p2, p2 + p2 / 2})
-                if (c >= 2 * n_modes && es_width_for_tol(tol, (double)c / (double)n_modes) <= best_w) return c;
+                if (!pick && c >= 2 * n_modes && es_width_for_tol(tol, (double)c / (double)n_modes) <= best_w) pick = c;
         }
     }
-    return best;
+    // Dense 2-D point sets (round 3): when millions of points share a few thousand fine cells the grid is nearly free (the MFMA
+    // spreader flushes register tiles into an L2-resident accumulator, the small-grid transforms are dense DFT launches of
+    // microseconds) while every point pays for the window width: W rows of operand stores and W + 1 tile columns in the spreader,
+    // W^2 multiply-adds and W * ceil(W/2) 16-byte LDS reads in the gather.  Take the smallest 2^a3^b5^c grid (<= 256 cells, ratio
+    // <= 5) whose window is one cell narrower.  Grids of <= 128 cells must keep the gather's two 16-byte-aligned copies inside the
+    // 160 KB of LDS (interp_real2_pair_kernel).
+    if (dense && dim == 2) {
+        const int w0 = es_width_for_tol(tol, (double)pick / (double)n_modes);
+        const int64_t top = std::min<int64_t>(256, 5 * n_modes);
+        for (int64_t c = next_smooth_even(pick + 2); c <= top; c = next_smooth_even(c + 2)) {
+            const int w = es_width_for_tol(tol, (double)c / (double)n_modes);
+            if (w >= w0) continue;
+            const int64_t pitch = (c + 2 * ((w + 1) / 2) + 1) & ~(int64_t)1;
+            const bool gather_fits = 2 * (c + w - 1) * pitch * 8 <= 160 * 1024;
+            if (c > 128 || gather_fits) pick = c;
+            break;
+        }
+    }
+    return pick;
 }
 
 }  // namespace efgp

@@ -41,7 +41,8 @@ void es_deconv_factors(const EsParams& p, int64_t nf, int64_t n_modes, std::vect
 
 // smallest size >= n of the form 2^a 3^b 5^c (and even)
 int64_t next_smooth_even(int64_t n);
-// fine-grid size a plan takes for n_modes modes per axis at tolerance tol in `dim` dimensions (see es_kernel.cpp)
-int64_t es_fine_size(int64_t n_modes, double tol, int dim);
+// fine-grid size a plan takes for n_modes modes per axis at tolerance tol in `dim` dimensions (see es_kernel.cpp);
+// dense: a 2-D plan over millions of points trades a finer grid for a window one cell narrower
+int64_t es_fine_size(int64_t n_modes, double tol, int dim, bool dense = false);
 
 }  // namespace efgp

@@ -1246,11 +1246,16 @@ __global__ void deconvolve_pair_kernel(const double2* __restrict__ fine, int64_t
 //   stage 2: H[r][k1] = sum_x1 B[r][x1] w1^(k1 x1) for k1 in [-h1, h1] out of LDS;
 //   epilogue: parts as in deconvolve_body (0 plain, 3 real row pairs, 4 = the fit's (F*y, Toeplitz vector) pair on two boxes).
 // The accumulator must be left zeroed for the next pass: the LAST workgroup to have finished reading it (arrival counter)
-// clears it.  Sums of <= 128 terms with exact table twiddles: the result differs from the FFT's by rounding only.
-constexpr int kG2MMaxNf = 128;
+// clears it.  Sums of <= 256 terms with exact table twiddles: the result differs from the FFT's by rounding only.
+// Round 3: on the finer grids of dense point sets (144..256 cells per axis) stage 1 -- 45 rows x0 per thread group, each value
+// an int64 -> double conversion and eight multiply-adds on 12 of the chip's CUs -- is split over 4 workgroups per row tile (every
+// 4th row x0 each); their partial B rows meet in global memory behind a per-tile arrival counter and the last arriver does
+// stage 2 and the epilogue.  Small grids keep one workgroup per tile (the exchange costs more than it saves there).
+// LOG2NF = 7: grids up to 128 x 128 (lane = x1, eight x0 classes); LOG2NF = 8 (round 3: the finer grids dense point sets take,
+// 144..256 cells per axis): 256 lanes per row, four x0 classes, the rows of a class in rounds of 16 loads.
+constexpr int kG2MMaxNf = 256;
 constexpr int kG2MMaxH = 32;                 // modes k in [-32, 32] per axis
 constexpr int kG2MThreads = 1024;
-constexpr int kG2MGroups = kG2MThreads / kG2MMaxNf;      // x0 classes of stage 1
 
 struct G2MArgs {
     long long* gacc;          // [nbatch][channels][nf0 * nf1]
@@ -1266,6 +1271,10 @@ struct G2MArgs {
     unsigned int* ticket;     // zero on entry, zero again on exit
     unsigned int total_wgs;
     long long acc_words;      // words to clear
+    // stage 1 split over gridDim.z workgroups per (tile, batch) (round 3): each takes every gridDim.z-th row x0, writes its
+    // partial B rows to `partial` and arrives at the tile's counter; the last one adds the partials up and goes on alone
+    double2* partial;         // [nbatch][tiles][split][4][nf1]
+    unsigned int* tile_ticket;   // [nbatch][tiles], zero on entry, zero again on exit
 };
 
 __device__ __forceinline__ bool g2m_slot(const ModeGeom& m, int k0, int k1, int64_t* t, double* f) {
@@ -1278,14 +1287,16 @@ __device__ __forceinline__ bool g2m_slot(const ModeGeom& m, int k0, int k1, int6
     return true;
 }
 
-template <bool FINE>
+template <bool FINE, int LOG2NF>
 __global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
-    __shared__ double2 T0[kG2MMaxNf], T1[kG2MMaxNf];
-    __shared__ double2 Bp[kG2MGroups][4][kG2MMaxNf];          // 64 KB
+    constexpr int kNf = 1 << LOG2NF, kGroups = kG2MThreads / kNf;       // lanes per row, x0 classes of stage 1
+    __shared__ double2 T0[kNf], T1[kNf];
+    __shared__ double2 Bp[kGroups][4][kNf];                   // 64 KB
     __shared__ double2 Hs[4][2 * kG2MMaxH + 2];
     __shared__ int s_last;
     const int tid = threadIdx.x, b = blockIdx.y;
     const int j0 = 2 * (int)blockIdx.x;
+    const int split = (int)blockIdx.z, nsplit = (int)gridDim.z;
     for (int q = tid; q < a.nf0; q += kG2MThreads) {
         double sn, cs;
         sincospi((double)a.sign * 2.0 * (double)q / (double)a.nf0, &sn, &cs);
@@ -1300,28 +1311,13 @@ __global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
     const long long* g0 = FINE ? nullptr : a.gacc + (int64_t)b * a.channels * cells;
     const double2* f0 = FINE ? a.fine + (int64_t)b * cells : nullptr;
     const double s0 = FINE ? 1.0 : a.scale[1], s1 = FINE ? 1.0 : a.scale[3];
-    // stage 1: lane = x1, group = x0 mod 8.  ALL of a thread's loads (<= 16 rows x 2 channels) are issued before the first is
-    // used: the accumulator was written by device-scope atomics and comes from memory, and with two groups and one load per
-    // iteration this stage was 48 dependent round trips long (33 us for the 96 x 96 pair grid).
+    // stage 1: lane = x1, group = x0 mod kGroups.  ALL loads of a round (16 rows x 2 channels per thread) are issued before the
+    // first is used: the accumulator was written by device-scope atomics and comes from memory, and with two groups and one load
+    // per iteration this stage was 48 dependent round trips long (33 us for the 96 x 96 pair grid).
     {
-        const int x1 = tid & (kG2MMaxNf - 1), grp = tid >> 7;
-        constexpr int U = kG2MMaxNf / kG2MGroups;             // 16
-        long long ire[U], iim[U];
+        const int x1 = tid & (kNf - 1), grp = tid >> LOG2NF;
+        constexpr int U = 16;
         const bool lane_on = x1 < a.nf1;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int x0 = grp + kG2MGroups * u;
-            const bool in = lane_on && x0 < a.nf0;
-            if (FINE) {
-                const double2 v = in ? f0[(int64_t)x0 * a.nf1 + x1] : make_double2(0.0, 0.0);
-                ire[u] = __double_as_longlong(v.x);
-                iim[u] = __double_as_longlong(v.y);
-            } else {
-                ire[u] = in ? g0[(int64_t)x0 * a.nf1 + x1] : 0;
-                iim[u] = (in && a.channels == 2) ? g0[cells + (int64_t)x0 * a.nf1 + x1] : 0;
-            }
-        }
-        __syncthreads();                                       // twiddle tables
         // rows +j and -j share their products: with w0^(j x0) = c + i s and G = re + i im,
         //   B(+j) = (P - S) + i (Q + R),  B(-j) = (P + S) + i (R - Q),  P = sum re c, Q = sum re s, R = sum im c, S = sum im s
         double2 pq[2], rs[2];
@@ -1330,22 +1326,39 @@ __global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
         for (int jj = 0; jj < 2; ++jj) {
             const int k = j0 + jj;
             pq[jj] = rs[jj] = make_double2(0.0, 0.0);
-            step[jj] = (kG2MGroups * k) % a.nf0;
-            idx[jj] = (k * grp) % a.nf0;
+            step[jj] = (int)(((long long)nsplit * kGroups * k) % a.nf0);
+            idx[jj] = (int)(((long long)k * (split + nsplit * grp)) % a.nf0);
         }
+        for (int r0 = 0; split + nsplit * kGroups * r0 < a.nf0; r0 += U) {
+            long long ire[U], iim[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const double re = FINE ? __longlong_as_double(ire[u]) : (double)ire[u] * s0;
-            const double im = FINE ? __longlong_as_double(iim[u]) : (double)iim[u] * s1;
+            for (int u = 0; u < U; ++u) {
+                const int x0 = split + nsplit * (grp + kGroups * (r0 + u));
+                const bool in = lane_on && x0 < a.nf0;
+                if (FINE) {
+                    const double2 v = in ? f0[(int64_t)x0 * a.nf1 + x1] : make_double2(0.0, 0.0);
+                    ire[u] = __double_as_longlong(v.x);
+                    iim[u] = __double_as_longlong(v.y);
+                } else {
+                    ire[u] = in ? g0[(int64_t)x0 * a.nf1 + x1] : 0;
+                    iim[u] = (in && a.channels == 2) ? g0[cells + (int64_t)x0 * a.nf1 + x1] : 0;
+                }
+            }
+            if (r0 == 0) __syncthreads();                          // twiddle tables
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const double2 tw = T0[idx[jj]];
-                pq[jj].x += re * tw.x;
-                pq[jj].y += re * tw.y;
-                rs[jj].x += im * tw.x;
-                rs[jj].y += im * tw.y;
-                idx[jj] += step[jj];
-                if (idx[jj] >= a.nf0) idx[jj] -= a.nf0;
+            for (int u = 0; u < U; ++u) {
+                const double re = FINE ? __longlong_as_double(ire[u]) : (double)ire[u] * s0;
+                const double im = FINE ? __longlong_as_double(iim[u]) : (double)iim[u] * s1;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const double2 tw = T0[idx[jj]];
+                    pq[jj].x += re * tw.x;
+                    pq[jj].y += re * tw.y;
+                    rs[jj].x += im * tw.x;
+                    rs[jj].y += im * tw.y;
+                    idx[jj] += step[jj];
+                    if (idx[jj] >= a.nf0) idx[jj] -= a.nf0;
+                }
             }
         }
 #pragma unroll
@@ -1363,7 +1376,7 @@ __global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
         const int jj = o / a.nf1, x = o - jj * a.nf1;
         double2 u = Bp[0][2 * jj][x], v = Bp[0][2 * jj + 1][x];
 #pragma unroll
-        for (int g = 1; g < kG2MGroups; ++g) {
+        for (int g = 1; g < kGroups; ++g) {
             u.x += Bp[g][2 * jj][x].x;
             u.y += Bp[g][2 * jj][x].y;
             v.x += Bp[g][2 * jj + 1][x].x;
@@ -1373,6 +1386,44 @@ __global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
         Bp[0][2 * jj + 1][x] = make_double2(u.x + v.y, v.x - u.y);      // row -j
     }
     __syncthreads();
+    if (nsplit > 1) {
+        // this workgroup's share of the four B rows goes to global memory; the last of the tile's workgroups to arrive adds all
+        // shares up (in split order: the sum does not depend on who arrives last) and carries on, the others are done
+        double2* const mine = a.partial + ((((int64_t)b * gridDim.x + blockIdx.x) * nsplit + split) * 4) * a.nf1;
+        for (int o = tid; o < 4 * a.nf1; o += kG2MThreads) mine[o] = Bp[0][o / a.nf1][o % a.nf1];
+        __threadfence();                                               // release: the shares before the arrival
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned int t = atomicAdd(a.tile_ticket + (int64_t)b * gridDim.x + blockIdx.x, 1u);
+            s_last = (t == (unsigned)nsplit - 1u) ? 1 : 0;
+        }
+        __syncthreads();
+        const bool tile_last = s_last != 0;
+        __syncthreads();                                               // s_last is reused below
+        if (!tile_last) {
+            // not the tile's finisher; still possibly the last reader of the accumulator
+            if (tid == 0) s_last = (!FINE && arrived == a.total_wgs - 1u) ? 1 : 0;
+            __syncthreads();
+            if (s_last) {
+                for (long long i = tid; i < a.acc_words; i += kG2MThreads) a.gacc[i] = 0;
+                if (tid == 0) *a.ticket = 0u;
+            }
+            return;
+        }
+        __threadfence();                                               // acquire: the other workgroups' shares
+        const double2* const all = a.partial + (((int64_t)b * gridDim.x + blockIdx.x) * nsplit * 4) * a.nf1;
+        for (int o = tid; o < 4 * a.nf1; o += kG2MThreads) {
+            double2 u = all[o];
+            for (int sp = 1; sp < nsplit; ++sp) {
+                const double2 v = all[(int64_t)sp * 4 * a.nf1 + o];
+                u.x += v.x;
+                u.y += v.y;
+            }
+            Bp[0][o / a.nf1][o % a.nf1] = u;
+        }
+        if (tid == 0) a.tile_ticket[(int64_t)b * gridDim.x + blockIdx.x] = 0u;
+        __syncthreads();
+    }
     // stage 2: four quarter ranges of x1 per output, combined through LDS
     const int nk1 = 2 * a.h1 + 1;
     double2* const Hq = &Bp[1][0][0];                          // [4 quarters][4 rows][nk1 <= 65]: Bp[1..] is free now
@@ -1734,18 +1785,25 @@ __global__ __launch_bounds__(kInterpThreads) void interp_real2_pair_kernel(Inter
     }
 }
 
+// (Round 3, measured and dropped: ONE halo-padded copy read with 8-byte ds_read_b64 -- same bytes per LDS cycle as ds_read_b128, no
+// alignment copy, so two workgroups per CU where the two copies of a 72 x 72 grid leave room for one.  N = 1e7, W = 7: 178 us
+// against 130 us for the two-copy kernel below: 49 read instructions per point instead of 28 fill the LDS command queue, and
+// 32 lanes spread over 32 bank pairs collide more often than 16 lanes over 16 quads.)
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 struct WindowSet {          // device copies of the window data for one (tolerance, sigma, nf, n_modes) setting
     double tol = 0.0;
     int dim = 0;
+    bool dense = false;     // es_fine_size's rule for dense 2-D point sets
     EsParams p;
     double* d_coef = nullptr;       // [kMaxDegree+1][W], rows above `degree` are zero
     double* d_fac[3] = {nullptr, nullptr, nullptr};
     int64_t nm[3] = {0, 0, 0};
     int64_t nf[3] = {0, 0, 0};
 };
+
+constexpr int64_t kDensePoints = 8000000;
 
 struct ClassOrder {         // see class_order_kernel
     int64_t nf[3];
@@ -1798,9 +1856,13 @@ static void free_window(WindowSet* w) {
 // only on (tolerance, dimension, mode box), not on the points, so they are cached per device.
 static int get_window(efgp_nufft_s* plan, const int64_t* n_modes, hipStream_t stream, WindowSet** out) {
     const int d = plan->dim;
+    // from 8e6 points on a 2-D plan takes the finer grid / narrower window (N = 1e7, mtot = 23: spread + gather 316 -> 283 us on
+    // the same box; the accumulator -> modes launch behind them grows from 20 to 47 us with the grid, which is why the rule
+    // waits for 8e6 points: at 4e6 the step as a whole was 13 us slower with it)
+    const bool dense = d == 2 && plan->npts >= kDensePoints && std::getenv("EFGP_NO_DENSE_SIGMA") == nullptr;
     for (void* vp : plan->ctx->window_cache) {
         WindowSet* w = (WindowSet*)vp;
-        bool same = w->dim == d && w->tol == plan->tol;
+        bool same = w->dim == d && w->tol == plan->tol && w->dense == dense;
         for (int a = 0; a < d && same; ++a) same = w->nm[a] == n_modes[a];
         if (same) {
             *out = w;
@@ -1810,10 +1872,11 @@ static int get_window(efgp_nufft_s* plan, const int64_t* n_modes, hipStream_t st
     auto* w = new WindowSet();
     w->tol = plan->tol;
     w->dim = d;
+    w->dense = dense;
     double sigma_min = 1e30;
     for (int a = 0; a < 3; ++a) {
         w->nm[a] = a < d ? n_modes[a] : 1;
-        w->nf[a] = a < d ? es_fine_size(n_modes[a], plan->tol, d) : 1;
+        w->nf[a] = a < d ? es_fine_size(n_modes[a], plan->tol, d, dense) : 1;
         if (a < d) sigma_min = std::min(sigma_min, (double)w->nf[a] / (double)w->nm[a]);
     }
     es_make_params(plan->tol, sigma_min, &w->p);
@@ -2428,8 +2491,8 @@ static bool g2m_eligible(const efgp_nufft_s* plan, const GridGeom& g, const G2MR
 }
 
 // gacc != null: from the MFMA spreader's int64 accumulator (converted, cleared by the kernel); else from the reduced complex grid
-static int g2m_launch(const GridGeom& g, G2MRequest* req, long long* gacc, const double2* fine, const double* scale, int channels,
-                      int nbatch, int isign, unsigned int* ticket, long long acc_words, hipStream_t stream) {
+static int g2m_launch(DeviceCtx* ctx, const GridGeom& g, G2MRequest* req, long long* gacc, const double2* fine, const double* scale,
+                      int channels, int nbatch, int isign, unsigned int* ticket, long long acc_words, hipStream_t stream) {
     G2MArgs ga;
     ga.gacc = gacc;
     ga.fine = fine;
@@ -2448,10 +2511,37 @@ static int g2m_launch(const GridGeom& g, G2MRequest* req, long long* gacc, const
     ga.out_b = (double2*)req->out_b;
     ga.ticket = ticket;
     const unsigned tiles = (unsigned)(ga.h0 / 2 + 1);
-    ga.total_wgs = tiles * (unsigned)nbatch;
+    const bool small = ga.nf0 <= 128 && ga.nf1 <= 128;
+    // stage-1 split, measured (rocprofv3, launch average): 96 x 96 grid 20.0 / 27.7 / 32.4 / 45.7 us at 1 / 2 / 4 / 8 workgroups
+    // per tile -- the shares' round trip through memory (two device-scope fences, an atomic) costs more than a quarter of stage 1
+    // saves; 180 x 180 grid 59.8 / 51.2 / 47.5 / 56.2 us.
+    int split = small ? 1 : 4;
+    if (const char* e = std::getenv("EFGP_G2M_SPLIT")) split = std::max(1, std::min(16, std::atoi(e)));
+    while (split > 1 && (int64_t)tiles * nbatch * split > 4096) split /= 2;
+    constexpr size_t kTicketBytes = 65536;
+    ga.partial = nullptr;
+    ga.tile_ticket = nullptr;
+    if (split > 1) {
+        if ((size_t)tiles * nbatch * sizeof(unsigned int) > kTicketBytes) split = 1;
+    }
+    if (split > 1) {
+        const size_t bytes = kTicketBytes + (size_t)nbatch * tiles * split * 4 * ga.nf1 * sizeof(double2);
+        char* base = (char*)scratch(ctx, SLOT_G2M, bytes);
+        if (!base) return EFGP_ENOMEM;
+        if (ctx->g2m_zeroed_for != (const void*)base) {
+            EFGP_HIP_CHECK(hipMemsetAsync(base, 0, kTicketBytes, stream));
+            ctx->g2m_zeroed_for = base;
+        }
+        ga.tile_ticket = (unsigned int*)base;
+        ga.partial = (double2*)(base + kTicketBytes);
+    }
+    ga.total_wgs = tiles * (unsigned)nbatch * (unsigned)split;
     ga.acc_words = acc_words;
-    if (gacc) hipLaunchKernelGGL(grid_to_modes_kernel<false>, dim3(tiles, nbatch), dim3(kG2MThreads), 0, stream, ga);
-    else hipLaunchKernelGGL(grid_to_modes_kernel<true>, dim3(tiles, nbatch), dim3(kG2MThreads), 0, stream, ga);
+    const dim3 grid(tiles, nbatch, split);
+    if (gacc && small) hipLaunchKernelGGL((grid_to_modes_kernel<false, 7>), grid, dim3(kG2MThreads), 0, stream, ga);
+    else if (gacc) hipLaunchKernelGGL((grid_to_modes_kernel<false, 8>), grid, dim3(kG2MThreads), 0, stream, ga);
+    else if (small) hipLaunchKernelGGL((grid_to_modes_kernel<true, 7>), grid, dim3(kG2MThreads), 0, stream, ga);
+    else hipLaunchKernelGGL((grid_to_modes_kernel<true, 8>), grid, dim3(kG2MThreads), 0, stream, ga);
     EFGP_HIP_CHECK(hipGetLastError());
     req->done = true;
     return EFGP_OK;
@@ -2462,7 +2552,7 @@ static int transform_fine(efgp_nufft_s* plan, const GridGeom& g, double2* fine, 
                           G2MRequest* req, const double* scale, double2** fine_out) {
     if (g2m_eligible(plan, g, req)) {
         *fine_out = nullptr;
-        return g2m_launch(g, req, nullptr, fine, scale, 2, nbatch, isign, nullptr, 0, stream);
+        return g2m_launch(plan->ctx, g, req, nullptr, fine, scale, 2, nbatch, isign, nullptr, 0, stream);
     }
     hipfftHandle fh;
     int rc = fft_plan(plan->ctx, plan->dim, g.nf, nbatch, stream, &fh);
@@ -2543,7 +2633,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         int rc = spread_mfma_launch(ctx, lvl, band_cells, ys, src, g, w->p.w, w->d_coef, w->p.degree, channels, nbatch, gacc, d_scale, stream);
         if (rc != EFGP_OK) return rc;
         if (g2m_eligible(plan, g, req)) {
-            rc = g2m_launch(g, req, (long long*)gacc, nullptr, d_scale, channels, nbatch, isign, (unsigned int*)(misc + 40),
+            rc = g2m_launch(ctx, g, req, (long long*)gacc, nullptr, d_scale, channels, nbatch, isign, (unsigned int*)(misc + 40),
                             (long long)(acc_bytes / sizeof(long long)), stream);
             if (rc != EFGP_OK) return rc;
             ctx->slabs_zero_bytes = acc_bytes;

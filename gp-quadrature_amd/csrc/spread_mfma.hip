@@ -173,6 +173,28 @@ __device__ __forceinline__ void flush_tile(const d4& acc, int cur_bx, int q, int
     }
 }
 
+// Tile flush of the 4 x 4 x 4 layout (tiles of at most 8 columns): lane holds D[row = 4 blk + (lane >> 4)][col = (lane & 3) + 4 half]
+// of accumulator `half`, blk = (lane >> 2) & 3.
+template <int W>
+__device__ __forceinline__ void flush_tile_small(double acc0, double acc1, int cur_bx, int lane, int by0, int ncols, int nf0, int nf1,
+                                                 int64_t cells, int channels, double S0, double S1, unsigned long long* __restrict__ gch) {
+    const int row = 4 * ((lane >> 2) & 3) + (lane >> 4), ch = row >> 3, i = row & 7;
+    if (i < W && ch < channels) {
+        const int xc = pos_mod(cur_bx + i, nf0);
+        const double S = ch ? S1 : S0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const double v = half ? acc1 : acc0;
+            const int col = (lane & 3) + 4 * half;
+            if (col < ncols && v != 0.0) {
+                const long long f = __double2ll_rn(v * S);
+                __hip_atomic_fetch_add(gch + (int64_t)ch * cells + (int64_t)xc * nf1 + pos_mod(by0 + col, nf1), (unsigned long long)f,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 struct PointIn {
     double2 xy;
     double c0, c1;
@@ -217,6 +239,13 @@ __global__ __launch_bounds__(64 * kMfmaMaxWaves, HB == 1 ? 3 : 2) void spread_mf
     const int64_t cells = (int64_t)nf0 * nf1;
     const double S0 = a.scale[0], S1 = a.scale[2];
     unsigned long long* gch = a.gacc + (int64_t)batch * a.channels * cells;
+    // Tiles of at most 8 columns (one-cell bands, W <= 7) go through v_mfma_f64_4x4x4: four independent 4 x 4 x 4 blocks per
+    // instruction, 9.3 ns against the 29.4 ns of the 16 x 16 x 4 (tools/r3/mfma_f64_4x4_bench.hip) -- two instructions cover the
+    // 16 x 8 tile of four points, 18.6 ns instead of 29.4 with half the columns idle.  Lane map (measured): A and B elements of
+    // block blk = (lane >> 2) & 3, point k = lane >> 4, row / column lane & 3; D[blk][i = lane >> 4][j = lane & 3].  Block blk
+    // takes the tile rows 4 blk .. 4 blk + 3 (so the A element of a lane is row lane & 15 of point k: the same LDS read as for the
+    // large shape) and the columns 0..3 (first instruction) / 4..7 (second).
+    constexpr bool SMALL = BR <= 8;
     const int q = lane >> 4, c16 = lane & 15;
     const bool live = c16 < BR;
     if (W < 8) {                                  // A rows of the unused stencil cells stay zero
@@ -227,7 +256,9 @@ __global__ __launch_bounds__(64 * kMfmaMaxWaves, HB == 1 ? 3 : 2) void spread_mf
         }
     }
     const double* Ard = A + c16 * kMfmaRow + q;   // this lane's operand elements of step g: Ard[4 g], Brd[4 g]
-    const double* Brd = B + (live ? c16 : 0) * kMfmaRow + q;      // columns beyond BR: a valid row, the products are never flushed
+    const double* Brd = SMALL ? B + ((lane & 3) < BR ? (lane & 3) : 0) * kMfmaRow + q      // columns lane & 3 and 4 + (lane & 3)
+                              : B + (live ? c16 : 0) * kMfmaRow + q;  // columns beyond BR: a valid row, the products are never flushed
+    const double* Brd2 = B + (4 + (lane & 3) < BR ? 4 + (lane & 3) : 0) * kMfmaRow + q;
     for (int chunk = blockIdx.x * nwaves + wave; chunk < a.nchunks; chunk += a.total_waves) {
         const int4 ci = reinterpret_cast<const int4*>(a.chunks)[chunk];
         const int start = __builtin_amdgcn_readfirstlane(ci.x), count = __builtin_amdgcn_readfirstlane(ci.y);
@@ -235,6 +266,7 @@ __global__ __launch_bounds__(64 * kMfmaMaxWaves, HB == 1 ? 3 : 2) void spread_mf
         const int by0 = (int)ceil(a.scale1 * (a.band_lo[band] - a.xcen1) - 0.5 * W);
         const int ycell = pos_mod(by0 + c16, nf1);
         d4 acc = {0.0, 0.0, 0.0, 0.0};
+        double sa0 = 0.0, sa1 = 0.0;                                          // SMALL: the two 4 x 4 x 4 accumulators
         int cur_bx = 0;
         PointIn nxt = load_point<SORTED>(a, batch, start + (lane < count ? lane : count - 1));
         for (int b0 = 0; b0 < count; b0 += 64) {
@@ -285,6 +317,36 @@ __global__ __launch_bounds__(64 * kMfmaMaxWaves, HB == 1 ? 3 : 2) void spread_mf
             __builtin_amdgcn_wave_barrier();
             if (EFGP_DIAG(1)) {
                 acc[1] += A[lane] + B[lane];
+            } else if (SMALL) {
+                if (mask == 0ull && rem >= 64) {
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const double av = Ard[4 * g], b0v = Brd[4 * g], b1v = Brd2[4 * g];
+                        sa0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b0v, sa0, 0, 0, 0);
+                        sa1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b1v, sa1, 0, 0, 0);
+                    }
+                } else {
+                    for (int g = 0; g < 16; ++g) {
+                        if (4 * g >= rem) break;
+                        const double av = Ard[4 * g], b0v = Brd[4 * g], b1v = Brd2[4 * g];
+                        const unsigned bits = (unsigned)(mask >> (4 * g)) & 15u;   // wave-uniform
+                        if (bits == 0u) {
+                            sa0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b0v, sa0, 0, 0, 0);
+                            sa1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b1v, sa1, 0, 0, 0);
+                        } else {
+                            for (int k = 0; k < 4; ++k) {                      // a run ends inside these four points
+                                if ((bits >> k) & 1u) {
+                                    flush_tile_small<W>(sa0, sa1, cur_bx, lane, by0, BR, nf0, nf1, cells, a.channels, S0, S1, gch);
+                                    sa0 = sa1 = 0.0;
+                                    cur_bx = __builtin_amdgcn_readfirstlane(bxs[g * kBxRow + k]);
+                                }
+                                const double am = q == k ? av : 0.0;
+                                sa0 = __builtin_amdgcn_mfma_f64_4x4x4f64(am, b0v, sa0, 0, 0, 0);
+                                sa1 = __builtin_amdgcn_mfma_f64_4x4x4f64(am, b1v, sa1, 0, 0, 0);
+                            }
+                        }
+                    }
+                }
             } else if (mask == 0ull && rem >= 64) {
                 // whole batch continues the current run: 16 operand pairs, 16 back-to-back MFMAs, no branches
                 // (round 3, measured: a sched_barrier between the reads and the MFMAs -- all 16 operand reads in flight, counted
@@ -320,13 +382,16 @@ __global__ __launch_bounds__(64 * kMfmaMaxWaves, HB == 1 ? 3 : 2) void spread_mf
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();                                   // the next batch overwrites the rows
         }
-        flush_tile<W>(acc, cur_bx, q, ycell, live, nf0, nf1, cells, a.channels, S0, S1, gch);
+        if (SMALL) flush_tile_small<W>(sa0, sa1, cur_bx, lane, by0, BR, nf0, nf1, cells, a.channels, S0, S1, gch);
+        else flush_tile<W>(acc, cur_bx, q, ycell, live, nf0, nf1, cells, a.channels, S0, S1, gch);
     }
 }
 
 template <int W, int HB>
 static hipError_t launch_w(dim3 grid, int waves, hipStream_t s, const MfmaSpreadArgs& a) {
-    const bool fixed_deg = a.degree == W + 1;          // what es_make_params picks for every standard tolerance
+    // W + 1 is what es_make_params picks for every standard tolerance at upsampling ratios around 2, W + 2 on the finer grids of
+    // dense point sets (W = 7 at ratio 4, tolerance 6e-8: degree 9); other degrees take the run-time Horner loop (DEG = 0)
+    const int fixed = a.degree == W + 1 ? 1 : (a.degree == W + 2 ? 2 : 0);
     const bool sorted = a.ys != nullptr;
     const size_t lds = mfma_lds_bytes(waves, W, HB);
     const dim3 block(64 * waves);
@@ -339,8 +404,10 @@ static hipError_t launch_w(dim3 grid, int waves, hipStream_t s, const MfmaSpread
         }                                                                                                            \
         hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                               \
     } while (0)
-    if (fixed_deg && sorted) EFGP_GO((spread_mfma_kernel<W, W + 1, true, HB>));
-    else if (fixed_deg) EFGP_GO((spread_mfma_kernel<W, W + 1, false, HB>));
+    if (fixed == 1 && sorted) EFGP_GO((spread_mfma_kernel<W, W + 1, true, HB>));
+    else if (fixed == 1) EFGP_GO((spread_mfma_kernel<W, W + 1, false, HB>));
+    else if (fixed == 2 && sorted) EFGP_GO((spread_mfma_kernel<W, W + 2, true, HB>));
+    else if (fixed == 2) EFGP_GO((spread_mfma_kernel<W, W + 2, false, HB>));
     else if (sorted) EFGP_GO((spread_mfma_kernel<W, 0, true, HB>));
     else EFGP_GO((spread_mfma_kernel<W, 0, false, HB>));
 #undef EFGP_GO

@@ -4,7 +4,9 @@ The EFGP solve path touches the N points only in NUFFT passes; CG works on M-siz
 points are partitioned into contiguous blocks, every rank runs the spread kernels on its block,
 and the small gridded partial sums (F*y: mtot^d, Toeplitz vector: (4m+1)^d, batched F*Z) plus a
 handful of N-length scalar reductions are summed with ONE all-reduce each (RCCL over xGMI when the
-backend is "nccl"; gloo in the CPU tests).  CG itself is replicated: no communication inside it.
+backend is "nccl"; gloo in the CPU tests).  The mean solve is replicated: no communication inside it.  The
+BATCHED solves (2T trace systems of a gradient, J Hutchinson probes of the variance) are independent systems and
+are split by rows over the ranks, with one all-reduce to gather the solutions (`solve_rows_sharded`, round 3).
 (The reference has no distributed code at all)
 """
 import torch
@@ -48,6 +50,27 @@ def rccl_comm_from_env(device):
     else:
         uid = bytes(store.get("efgp_rccl_id"))
     return RcclComm(device, rank, world, uid)
+
+
+def solve_rows_sharded(shards, rhs, solve):
+    """Independent systems over the GPUs (SURVEY 8e's alternative to replicating every solve; the reference's batched solves are
+    efgpnd.py:205-236 -- the 2T trace systems of a gradient -- and :1651-1657 -- the J Hutchinson probes of the variance).
+
+    `rhs` (R, M) is IDENTICAL on every rank (it is built from all-reduced / broadcast data).  Rank r solves the contiguous row
+    block shard_bounds(R, world, r) with `solve(block) -> (x (r, M), rows)` (`rows`: per-system iteration counts, a device
+    tensor or a list), and ONE all-reduce of a buffer that is zero outside the rank's own rows gathers the solutions: adding
+    zeros is exact, so every rank ends with bit-for-bit the result of the replicated solve.  Returns (x (R, M), rows (R,) int32
+    device tensor), identical on all ranks."""
+    R = rhs.shape[0]
+    lo, hi = shard_bounds(R, shards.world_size, shards.rank)
+    full = torch.zeros_like(rhs)
+    rows = torch.zeros(R, dtype=torch.float64, device=rhs.device)
+    if hi > lo:
+        x, its = solve(rhs[lo:hi])
+        full[lo:hi] = x.reshape(hi - lo, -1)
+        rows[lo:hi] = torch.as_tensor(its, device=rhs.device).to(torch.float64).reshape(-1)
+    shards.sum_many_([full, rows])
+    return full, rows.to(torch.int32)
 
 
 class PointShards:

@@ -595,12 +595,8 @@ def efgpnd_gradient_batched(
         lap("6_monte_carlo_trace")
 
         # 7) batched CG -----------------------------------------------------------------------------
-        res_t = cg_solve_async(top, ws, sig, 0, B_all, None, cg_tol, early_stop=early_stopping,
-                               diag=diag if use_trace_cg_preconditioner else None, batched=True)
-        if res_t is None:
-            res_t = cg_solve(top, ws, sig, 0, B_all, None, cg_tol, early_stop=early_stopping,
-                             diag=diag if use_trace_cg_preconditioner else None, batched=True)[:2]
-        Beta_all, trace_iters = res_t
+        Beta_all, trace_iters = _solve_batched(shards, top, ws, sig, 0, B_all, cg_tol, early_stop=early_stopping,
+                                               diag=diag if use_trace_cg_preconditioner else None)
         lap("7_batch_cg_solve")
 
         # 7.5) term 1 -------------------------------------------------------------------------------
@@ -721,12 +717,8 @@ def _gradient_tail_native(kernel, grid, top, Fy, v, sig, N, N_local, cg_tol, ear
     lap("6_monte_carlo_trace")
 
     # 7) batched CG from zero (reference :205-236)
-    res_t = cg_solve_async(top, ws, sig, 0, B_all, None, cg_tol, early_stop=early_stopping, diag=diag if use_trace_pc else None,
-                           batched=True)
-    if res_t is None:
-        res_t = cg_solve(top, ws, sig, 0, B_all, None, cg_tol, early_stop=early_stopping, diag=diag if use_trace_pc else None,
-                         batched=True)[:2]
-    Beta_all, trace_iters = res_t
+    Beta_all, trace_iters = _solve_batched(shards, top, ws, sig, 0, B_all, cg_tol, early_stop=early_stopping,
+                                           diag=diag if use_trace_pc else None)
     lap("7_batch_cg_solve")
 
     # 7.5 / 8) every inner product of terms 1 and 2 and the final algebra: two launches, nothing read back
@@ -743,6 +735,47 @@ def _gradient_tail_native(kernel, grid, top, Fy, v, sig, N, N_local, cg_tol, ear
     return out, out[:nh], out[nh:2 * nh], out[2 * nh:3 * nh], out[3 * nh], beta, mean_iters, trace_iters, (K + 1) * T, warm
 
 
+def _rows_over_ranks(shards, top, R):
+    """Should the R independent systems of a batched solve be split over the ranks?  On the 64 x 64 grid every system is ONE
+    workgroup on one CU and up to num_CU of them run side by side on a GPU: splitting pays from more rows than CUs on.  Larger
+    grids take many CUs per system (cooperative launch, multi-kernel 3-D iteration) and go through the rows in slabs:
+    splitting pays as soon as every rank gets a row.  opts / env EFGP_SHARD_ROWS=0 keeps every solve replicated."""
+    import os
+    if shards is None or not shards.active or R < shards.world_size or os.environ.get("EFGP_SHARD_ROWS", "1") == "0":
+        return False
+    if top.size <= 4096:
+        return R > torch.cuda.get_device_properties(top.dev).multi_processor_count
+    return True
+
+
+def _solve_batched(shards, top, ws, sig, variant, B_all, tol, *, early_stop, diag, max_iter=None, hermitian=False):
+    """The batched solves of the gradient and of the variance: asynchronous persistent / cooperative kernels where the grid
+    allows, the multi-launch solver otherwise; rows split over the ranks when that pays (`_rows_over_ranks`).  Returns
+    (X (R, M), iteration count: int-like)."""
+    from efgp_hip.ops import LazyIterations
+    from efgp_hip.dist import solve_rows_sharded
+
+    def solve(block):
+        res = cg_solve_async(top, ws, sig, variant, block, None, tol, max_iter=max_iter, early_stop=early_stop, diag=diag,
+                             batched=True, hermitian=hermitian)
+        if res is not None:
+            return res[0], res[1]._rows_dev
+        x, _, rows = cg_solve(top, ws, sig, variant, block, None, tol, max_iter=max_iter, early_stop=early_stop, diag=diag,
+                              batched=True, hermitian=hermitian)
+        return x, rows
+
+    R = B_all.shape[0]
+    mi = int(max_iter) if max_iter is not None else 2 * top.size
+    if _rows_over_ranks(shards, top, R):
+        X, rows = solve_rows_sharded(shards, B_all.reshape(R, -1), solve)
+        return X.reshape(B_all.shape), LazyIterations(rows, True, mi)
+    X, rows = solve(B_all)
+    if torch.is_tensor(rows):
+        return X, LazyIterations(rows, True, mi)
+    mx = max(rows)
+    return X, (mx + 1 if mx < mi else mx)
+
+
 def vdot_m(a, b):
     """Re<a,b> for M-length device vectors, kept on the device (glue on tiny vectors)."""
     return (a.conj() * b).sum().real
@@ -757,10 +790,11 @@ def _unwrap_operator(A_apply):
     raise TypeError("expected an operator made by create_A_mean / create_A_var")
 
 
-def diag_sums_nd(A_apply, J, xis_flat, max_cg_iter, cg_tol, ws, probes: Optional[torch.Tensor] = None):
+def diag_sums_nd(A_apply, J, xis_flat, max_cg_iter, cg_tol, ws, probes: Optional[torch.Tensor] = None, shards=None):
     """Hutchinson estimate of the lag sums c[r] = sum_{k-l=r} (A^-1)_{kl}-weighted products used by the
     stochastic variance (reference: efgpnd.py:1634-1664).  ``probes`` (J,M) of +-1 may be injected;
-    otherwise they are drawn with torch.randint as in the reference (:1644)."""
+    otherwise they are drawn with torch.randint as in the reference (:1644).  ``shards`` (a PointShards of a multi-GPU
+    model; the probes must then be identical on all ranks): the J systems are split by rows over the ranks."""
     Mtot, d_loc = xis_flat.shape
     m_loc = round(Mtot ** (1 / d_loc))
     assert m_loc ** d_loc == Mtot, "xis must lie on tensor grid"
@@ -772,8 +806,8 @@ def diag_sums_nd(A_apply, J, xis_flat, max_cg_iter, cg_tol, ws, probes: Optional
         etas = probes.detach().to(device=dev, dtype=torch.float64)
     wsd = ws.to(device=dev, dtype=torch.complex128)
     rhs = wsd[None, :] * etas
-    us, _, _ = cg_solve(op.toeplitz._op, wsd, op.sigmasq, op.variant, rhs, None, cg_tol,
-                        max_iter=max_cg_iter, early_stop=True, diag=None, batched=True)
+    us, _ = _solve_batched(shards, op.toeplitz._op, wsd, op.sigmasq, op.variant, rhs, cg_tol, early_stop=True, diag=None,
+                           max_iter=max_cg_iter)
     # zero-padded correlation of every probe pair and the mean over probes (:1660-1664): hipFFT + three small kernels
     return lag_sums(wsd[None, :] * us, etas, m_loc, d_loc)
 
@@ -850,7 +884,7 @@ def logdet_slq(ws, sigma2, toeplitz, *, probes=1000, steps=100, dtype=torch.floa
 
 
 def compute_prediction_variance(x_new, xis, ws, A_var, cg_tol, max_cg_iter, variance_method, h, xcen,
-                                hutchinson_probes, nufft_eps, device, rdtype, cdtype, probes=None):
+                                hutchinson_probes, nufft_eps, device, rdtype, cdtype, probes=None, shards=None):
     """Latent posterior variance at x_new: 'regular' (one CG solve per point, microbatched) or
     'stochastic' (Hutchinson lag sums + FFT-ordered type-2).  Reference: efgpnd.py:1761-1841."""
     method = variance_method.lower()
@@ -873,7 +907,7 @@ def compute_prediction_variance(x_new, xis, ws, A_var, cg_tol, max_cg_iter, vari
         return torch.cat(out, dim=0).to(device=device, dtype=rdtype)
     if method == "stochastic":
         t1 = time.time()
-        est = diag_sums_nd(A_var, hutchinson_probes, xis, max_cg_iter, cg_tol, ws, probes=probes)
+        est = diag_sums_nd(A_var, hutchinson_probes, xis, max_cg_iter, cg_tol, ws, probes=probes, shards=shards)
         print(f"Time to compute diag sums: {time.time() - t1:.4f} seconds")
         return nufft_var_est_nd(est, h, xcen, x_new, nufft_eps).to(device=device, dtype=rdtype)
     raise ValueError(f"Variance method '{variance_method}' not implemented. Choose 'regular' or 'stochastic'.")
@@ -1210,7 +1244,7 @@ class EFGPND(nn.Module):
                 cg_tol=self.opts.get("cg_tolerance", 1e-4), max_cg_iter=self.opts.get("max_cg_iterations", 1000),
                 variance_method=variance_method, h=st["h"], xcen=torch.zeros(d, dtype=torch.float64),
                 hutchinson_probes=hutchinson_probes, nufft_eps=nufft_eps, device=self.device, rdtype=rdtype,
-                cdtype=cdtype, probes=variance_probes)
+                cdtype=cdtype, probes=variance_probes, shards=self._shards if self._shards.active else None)
         else:
             # the reference fills a (B,) tensor with NaN (efgpnd.py:947): same values as a stride-0 view of ONE NaN, without
             # writing 8 B bytes per call (16 us and 80 MB of traffic per predict at N = 1e7)
