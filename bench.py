@@ -97,6 +97,33 @@ def cpu_baseline(seed):
     }
 
 
+def model_costs(dev, x, y):
+    """What a model costs beyond the steady step (N = the headline's points, warm process): `one_shot_fit_ms` -- a NEW EFGPND +
+    fit + posterior mean at the N points, the unit of the legacy efgp_nd() call (efgpnd_variance_shootout.py:129-137), which
+    never builds the sorted point layout; `one_shot_fit_with_layout_ms` -- the same with the layout forced from the first fit;
+    `layout_once_ms` -- their difference: bounding box, band keys, radix sort, two gathers, max|y|, paid once by a model at its
+    second pass over the points."""
+    from efgpnd import EFGPND
+    from kernels.squared_exponential import SquaredExponential
+
+    def one(layout):
+        ts = []
+        for _ in range(7):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            kern = SquaredExponential(dimension=DIM, init_lengthscale=LS, init_variance=VAR)
+            m = EFGPND(x, y, kern, sigmasq=SIG2, eps=EPS, nufft_eps=NUFFT_TOL, estimate_params=False,
+                       opts={"cg_tolerance": CG_TOL, "mean_cg_warm_start": False, "point_layout": layout})
+            m._compute_common_parameters()
+            m.predict(x, return_variance=False)
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+            del m
+        return 1e3 * sorted(ts)[len(ts) // 2]
+    plain, forced = one("auto"), one(True)
+    return {"one_shot_fit_ms": plain, "one_shot_fit_with_layout_ms": forced, "layout_once_ms": forced - plain}
+
+
 def north_star(dev, rank, world, distributed, barrier):
     """The north_star configuration (N = 1e7, d = 2, SE): microseconds per launch of the N-scale kernels of one
     fit + mean step, HIP events inside the library.  `ordering_us` = per-step ordering passes (none: the point layout
@@ -115,13 +142,18 @@ def north_star(dev, rank, world, distributed, barrier):
     model._compute_common_parameters(force_recompute=True)
     model.predict(x, return_variance=False)
     torch.cuda.synchronize(dev)
-    first_ms = 1e3 * (time.perf_counter() - t0)
+    first_ms = 1e3 * (time.perf_counter() - t0)      # a model's first fit + mean: no sorted layout yet (built at its second pass)
 
     def step():
         model._compute_common_parameters(force_recompute=True)
         return model.predict(x, return_variance=False)[0]
-    for _ in range(2):
+    early = []
+    for _ in range(3):                               # step 1 of these builds the layout; the later ones are steady
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
         step()
+        torch.cuda.synchronize(dev)
+        early.append(1e3 * (time.perf_counter() - t0))
     barrier()
     kernel_timing(True)
     reps = 10
@@ -147,7 +179,7 @@ def north_star(dev, rank, world, distributed, barrier):
     del model
     return {"global_n": NG, "n_per_gpu": n_loc, "ms_per_step": 1e3 * el / reps, "fits_per_s": reps / el,
             "spread_us": spread_us, "gather_us": gather_us, "ordering_us": order_us, "sum_us": total_us,
-            "first_fit_and_layout_ms": first_ms,
+            "first_fit_ms": first_ms, "layout_once_ms": early[0] - min(early[1:]),
             "frac_hbm_survey_bytes": survey_bytes / (total_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "frac_hbm_actual_bytes": actual_bytes / (total_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "survey_bytes": survey_bytes, "actual_bytes": actual_bytes}
@@ -335,6 +367,7 @@ def main():
             cg_mid[f"{opm.fft_shape[0]}x{opm.fft_shape[1]}"] = 1e6 * dtm / itm
             del opm
 
+    costs = model_costs(dev, x, y) if (world == 1 and rank == 0 and not args.no_extras) else None
     # extra legs (every rank takes part: they contain collectives)
     weak = None
     star = None
@@ -402,6 +435,8 @@ def main():
                                              "point layout, MFMA register tiles)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_source": "profiles/" + os.path.basename(tpath) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                           "bench.py --main-only, committed; not measured in this run)" if traffic is not None else None,
                          "bytes_per_launch": spread_bytes, "avg_launch_us": spread_avg_s * 1e6, "launches": spread_n,
                          "achieved_vs_unfused_survey_figure": unfused_bytes / spread_avg_s / 1e9 if spread_n else None},
             "interp": {"avg_launch_us": 1e3 * interp_ms / max(interp_n, 1),
@@ -421,6 +456,8 @@ def main():
             rec["north_star_n1e7"] = star
         if cg_mid is not None:
             rec["cg_mid_us_per_iter"] = cg_mid
+        if world == 1 and not args.no_extras:
+            rec["model_costs"] = costs
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(1000)
         print(json.dumps(rec))

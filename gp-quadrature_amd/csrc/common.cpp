@@ -3,6 +3,7 @@
 #include "common.hpp"
 
 #include <chrono>
+#include <map>
 #include <cstdlib>
 
 #include <algorithm>
@@ -190,7 +191,9 @@ void release_ctx(int device) {
 }
 
 // ---- CG residual history hook ----------------------------------------------------------------
-static CgHistory g_cg_history;
+// per host thread: the hook is set and consumed by the thread that runs the solve (two models solving on different threads must
+// not write into each other's buffer)
+static thread_local CgHistory g_cg_history;
 CgHistory cg_history() { return g_cg_history; }
 
 }  // namespace efgp
@@ -207,17 +210,28 @@ namespace efgp {
 struct TimingRec {
     std::string name;
     hipEvent_t start, stop;
+    int device;
+    bool valid;          // both records succeeded
 };
 static bool g_timing = false;
 static std::string g_timing_only;            // non-empty: only timers of this name record (efgp_kernel_timing_only)
 static std::vector<TimingRec> g_recs;
-static std::vector<hipEvent_t> g_free_events;   // recycled: hipEventCreate per launch cost the host ~10 us per timed kernel
+// recycled events, per device (an event belongs to the device that was current when it was created; recording it on another
+// device's stream fails): hipEventCreate per launch cost the host ~10 us per timed kernel
+static std::map<int, std::vector<hipEvent_t>> g_free_events;
 constexpr size_t kMaxTimingRecs = 1 << 16;
 
-static bool take_event(hipEvent_t* e) {
-    if (!g_free_events.empty()) {
-        *e = g_free_events.back();
-        g_free_events.pop_back();
+static int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) (void)hipGetLastError();
+    return d;
+}
+
+static bool take_event(int dev, hipEvent_t* e) {
+    auto& pool = g_free_events[dev];
+    if (!pool.empty()) {
+        *e = pool.back();
+        pool.pop_back();
         return true;
     }
     return hipEventCreate(e) == hipSuccess;
@@ -243,24 +257,31 @@ KernelTimer::KernelTimer(const char* name, hipStream_t s) : stream(s) {
     if (!g_timing_only.empty() && g_timing_only != name) return;
     TimingRec r;
     r.name = name;
-    if (!take_event(&r.start)) return;
-    if (!take_event(&r.stop)) {
-        g_free_events.push_back(r.start);
+    r.device = current_device();          // the library's entry points set the plan's / operator's device before they launch
+    if (!take_event(r.device, &r.start)) return;
+    if (!take_event(r.device, &r.stop)) {
+        g_free_events[r.device].push_back(r.start);
         return;
     }
-    (void)hipEventRecord(r.start, s);
+    r.valid = hipEventRecord(r.start, s) == hipSuccess;
+    if (!r.valid) (void)hipGetLastError();
     g_recs.push_back(r);
     slot = (int)g_recs.size() - 1;
 }
 
 KernelTimer::~KernelTimer() {
-    if (slot >= 0) (void)hipEventRecord(g_recs[(size_t)slot].stop, stream);
+    if (slot < 0) return;
+    TimingRec& r = g_recs[(size_t)slot];
+    if (r.valid && hipEventRecord(r.stop, stream) != hipSuccess) {
+        (void)hipGetLastError();
+        r.valid = false;                  // a record that failed must not be read as a duration
+    }
 }
 
 static void clear_timing() {
     for (auto& r : g_recs) {
-        g_free_events.push_back(r.start);
-        g_free_events.push_back(r.stop);
+        g_free_events[r.device].push_back(r.start);
+        g_free_events[r.device].push_back(r.stop);
     }
     g_recs.clear();
 }
@@ -298,7 +319,7 @@ int efgp_kernel_timing_read(const char* name, double* total_ms_out, int64_t* lau
     double tot = 0.0;
     int64_t cnt = 0;
     for (auto& r : g_recs) {
-        if (r.name != name) continue;
+        if (r.name != name || !r.valid) continue;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
             tot += ms;

@@ -1494,6 +1494,185 @@ __global__ __launch_bounds__(kG2MThreads) void grid_to_modes_kernel(G2MArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 3: the same accumulator -> modes step as TWO launches that use the whole chip.
+// grid_to_modes_kernel gives every workgroup four mode rows k0 and makes it pull the WHOLE accumulator through one CU
+// (12 workgroups for the 45-mode box): 20 us on the 96 x 96 pair grid, 47-60 us on the 180 x 180 grid of a dense point set.
+// A one-launch variant with the x1 transform spread over the rows and the whole x0 transform done by the last workgroup to
+// arrive measured 30 / 51 us: 45 x 45 x nf0 complex multiply-adds are 5-10 us of ONE CU's fp64 pipe, and data freshly written
+// by other XCDs costs a microsecond per dependent round trip.  So:
+//   grid_rows_kernel    (workgroup = kG2RRows rows x0 of the accumulator): C[x0][k1] = sum_x1 G[x0][x1] w1^(k1 x1) for
+//                       k1 in [-h1, h1]; only its own rows are loaded (converted from the int64 fixed point, and cleared for
+//                       the next pass: no arrival counter); the sums for +k1 and -k1 share their four real products;
+//   rows_modes_kernel   (workgroup = the column pair +-k1): H[k0][+-k1] = sum_x0 C[x0][+-k1] w0^(k0 x0) for all k0 out of LDS
+//                       (two columns of C = 2 nf0 values, every load in flight at once), then the epilogue of
+//                       grid_to_modes_kernel (parts 0 | 3 | 4): the modes k and -k it pairs are both in this workgroup.
+// Sums of <= 256 terms with exact table twiddles, fixed order: equal to the FFT sequence to rounding, reproducible.
+constexpr int kG2RRows = 4;
+constexpr int kG2RThreads = 1024;
+constexpr int kR2MThreads = 256;
+
+struct G2RArgs {
+    long long* gacc;          // [nbatch][channels][nf0 * nf1]   (null: `fine`)
+    const double2* fine;      // [nbatch][nf0 * nf1] complex grid already reduced (other spreaders); nothing is cleared
+    const double* scale;
+    int channels, nf0, nf1, h0, h1;
+    int part, rows_limit, sign;
+    ModeGeom ma, mb;
+    double2* out_a;
+    double2* out_b;
+    double2* cbuf;            // [nbatch][nf0][2 h1 + 1]
+};
+
+template <bool FINE>
+__global__ __launch_bounds__(kG2RThreads) void grid_rows_kernel(G2RArgs a) {
+    extern __shared__ double2 g2r_lds[];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int nf0 = a.nf0, nf1 = a.nf1, h1 = a.h1;
+    const int nk1 = 2 * h1 + 1;
+    const int64_t cells = (int64_t)nf0 * nf1;
+    double2* const T = g2r_lds;                         // w1^q, q < nf1 <= 256
+    double2* const Row = T + 256;                       // [kG2RRows][nf1] (re, im) of the owned rows
+    for (int q = tid; q < nf1; q += kG2RThreads) {
+        double sn, cs;
+        sincospi((double)a.sign * 2.0 * (double)q / (double)nf1, &sn, &cs);
+        T[q] = make_double2(cs, sn);
+    }
+    const int x0_lo = (int)blockIdx.x * kG2RRows;
+    {
+        const double s0 = FINE ? 1.0 : a.scale[1], s1 = FINE ? 1.0 : a.scale[3];
+        for (int o = tid; o < kG2RRows * nf1; o += kG2RThreads) {
+            const int r = o / nf1, x1 = o - r * nf1, x0 = x0_lo + r;
+            double2 v = make_double2(0.0, 0.0);
+            if (x0 < nf0) {
+                if (FINE) {
+                    v = a.fine[(int64_t)b * cells + (int64_t)x0 * nf1 + x1];
+                } else {
+                    long long* g = a.gacc + (int64_t)b * a.channels * cells + (int64_t)x0 * nf1 + x1;
+                    const long long ire = g[0];
+                    g[0] = 0;                                       // the next pass finds a zeroed accumulator
+                    long long iim = 0;
+                    if (a.channels == 2) {
+                        iim = g[cells];
+                        g[cells] = 0;
+                    }
+                    v = make_double2((double)ire * s0, (double)iim * s1);
+                }
+            }
+            Row[o] = v;
+        }
+    }
+    __syncthreads();
+    // task = (row r, k1 >= 0, segment of x1): eight segments per (r, k1) in neighbouring lanes, combined by shuffles
+    constexpr int SEG = 8;
+    const int seg = tid & (SEG - 1), pair = tid >> 3;            // pair < 128
+    const int npairs = kG2RRows * (h1 + 1);
+    for (int pr = pair; pr < ((npairs + 127) / 128) * 128; pr += 128) {
+        const bool on = pr < npairs;
+        const int r = on ? pr / (h1 + 1) : 0, k1 = on ? pr - r * (h1 + 1) : 0;
+        const int xa = (nf1 * seg) / SEG, xe = (nf1 * (seg + 1)) / SEG;
+        int idx = (int)(((long long)k1 * xa) % nf1);
+        double P = 0.0, Q = 0.0, R = 0.0, S = 0.0;
+        if (on) {
+            const double2* row = Row + r * nf1;
+            for (int x = xa; x < xe; ++x) {
+                const double2 g = row[x], tw = T[idx];
+                P = fma(g.x, tw.x, P);
+                Q = fma(g.x, tw.y, Q);
+                R = fma(g.y, tw.x, R);
+                S = fma(g.y, tw.y, S);
+                idx += k1;
+                if (idx >= nf1) idx -= nf1;
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < SEG; m <<= 1) {
+            P += __shfl_xor(P, m, 64);
+            Q += __shfl_xor(Q, m, 64);
+            R += __shfl_xor(R, m, 64);
+            S += __shfl_xor(S, m, 64);
+        }
+        const int x0 = x0_lo + r;
+        if (on && seg == 0 && x0 < nf0) {
+            double2* c = a.cbuf + ((int64_t)b * nf0 + x0) * nk1;
+            c[h1 + k1] = make_double2(P - S, Q + R);                       // sum (re + i im)(c + i s)
+            if (k1 > 0) c[h1 - k1] = make_double2(P + S, R - Q);           // ... (c - i s)
+        }
+    }
+}
+
+__global__ __launch_bounds__(kR2MThreads) void rows_modes_kernel(G2RArgs a) {
+    __shared__ double2 T[256], Cc[2][256], Hs[2][2 * kG2MMaxH + 2], part[2][4][2 * kG2MMaxH + 2];
+    const int tid = threadIdx.x, b = blockIdx.y, k1 = (int)blockIdx.x;             // column pair +-k1, k1 = 0..h1
+    const int nf0 = a.nf0, h0 = a.h0, h1 = a.h1;
+    const int nk0 = 2 * h0 + 1, nk1 = 2 * h1 + 1;
+    const double2* C = a.cbuf + (int64_t)b * nf0 * nk1;
+    for (int o = tid; o < 2 * nf0; o += kR2MThreads) {                           // every load issued before any is used
+        const int col = o >= nf0 ? 1 : 0, x0 = o - col * nf0;
+        Cc[col][x0] = C[(int64_t)x0 * nk1 + (col ? h1 - k1 : h1 + k1)];
+    }
+    for (int q = tid; q < nf0; q += kR2MThreads) {
+        double sn, cs;
+        sincospi((double)a.sign * 2.0 * (double)q / (double)nf0, &sn, &cs);
+        T[q] = make_double2(cs, sn);
+    }
+    __syncthreads();
+    // H[k0][col] = sum_x0 Cc[col][x0] w0^(k0 x0): task = (col, k0, quarter of x0)
+    for (int o = tid; o < 8 * nk0; o += kR2MThreads) {
+        const int qtr = o / (2 * nk0), rc = o - qtr * 2 * nk0;
+        const int col = rc / nk0, r = rc - col * nk0;
+        int st = (r - h0) % nf0;
+        if (st < 0) st += nf0;
+        const int xa = (nf0 * qtr) / 4, xe = (nf0 * (qtr + 1)) / 4;
+        int idx = (int)(((long long)st * xa) % nf0);
+        double sx = 0.0, sy = 0.0;
+        for (int x = xa; x < xe; ++x) {
+            const double2 cv = Cc[col][x], tw = T[idx];
+            sx = fma(cv.x, tw.x, fma(-cv.y, tw.y, sx));
+            sy = fma(cv.x, tw.y, fma(cv.y, tw.x, sy));
+            idx += st;
+            if (idx >= nf0) idx -= nf0;
+        }
+        part[col][qtr][r] = make_double2(sx, sy);
+    }
+    __syncthreads();
+    for (int o = tid; o < 2 * nk0; o += kR2MThreads) {
+        const int col = o / nk0, r = o - col * nk0;
+        Hs[col][r] = make_double2((part[col][0][r].x + part[col][1][r].x) + (part[col][2][r].x + part[col][3][r].x),
+                                  (part[col][0][r].y + part[col][1][r].y) + (part[col][2][r].y + part[col][3][r].y));
+    }
+    __syncthreads();
+    // epilogue (as grid_to_modes_kernel): mode (k0, +-k1) with its partner (-k0, -+k1) in the other column
+    for (int o = tid; o < 2 * nk0; o += kR2MThreads) {
+        const int col = o / nk0, r = o - col * nk0;
+        if (col == 1 && k1 == 0) continue;                                       // -0 duplicates +0
+        const int k0 = r - h0, kk1 = col ? -k1 : k1;
+        const double2 H = Hs[col][r], G = Hs[k1 == 0 ? 0 : 1 - col][nk0 - 1 - r];
+        int64_t t;
+        double f;
+        if (a.part == 0) {
+            if (g2m_slot(a.ma, k0, kk1, &t, &f)) a.out_a[(int64_t)b * a.ma.total + t] = make_double2(H.x * f, H.y * f);
+            continue;
+        }
+        if (g2m_slot(a.ma, k0, kk1, &t, &f)) {
+            double2 r1 = make_double2(0.5 * (H.x + G.x) * f, 0.5 * (H.y - G.y) * f);
+            if (a.part == 3) {
+                a.out_a[(int64_t)(2 * b) * a.ma.total + t] = r1;
+                if (2 * b + 1 < a.rows_limit)
+                    a.out_a[(int64_t)(2 * b + 1) * a.ma.total + t] = make_double2(0.5 * (H.y + G.y) * f, 0.5 * (G.x - H.x) * f);
+            } else {
+                const double norm0 = a.scale ? a.scale[4] : 1.0;  // channel 0 was carried normalised (fixed_scale_kernel)
+                if (norm0 != 1.0) {
+                    r1.x *= norm0;
+                    r1.y *= norm0;
+                }
+                a.out_a[t] = r1;
+            }
+        }
+        if (a.part == 4 && g2m_slot(a.mb, k0, kk1, &t, &f)) a.out_b[t] = make_double2(0.5 * (H.y + G.y) * f, 0.5 * (G.x - H.x) * f);
+    }
+}
+
 // type 2: fine[b][k mod nf] = fac * f[b][slot] (* mul[slot] when given), zero outside the mode box: every
 // fine cell is written, so the grid needs no memset.  herm != 0 stores the Hermitian part
 // (f[k] + conj f[-k])/2, whose transform is the real part of the full one (real_only outputs).
@@ -1803,7 +1982,7 @@ struct WindowSet {          // device copies of the window data for one (toleran
     int64_t nf[3] = {0, 0, 0};
 };
 
-constexpr int64_t kDensePoints = 8000000;
+constexpr int64_t kDensePoints = 4000000;
 
 struct ClassOrder {         // see class_order_kernel
     int64_t nf[3];
@@ -1856,9 +2035,9 @@ static void free_window(WindowSet* w) {
 // only on (tolerance, dimension, mode box), not on the points, so they are cached per device.
 static int get_window(efgp_nufft_s* plan, const int64_t* n_modes, hipStream_t stream, WindowSet** out) {
     const int d = plan->dim;
-    // from 8e6 points on a 2-D plan takes the finer grid / narrower window (N = 1e7, mtot = 23: spread + gather 316 -> 283 us on
-    // the same box; the accumulator -> modes launch behind them grows from 20 to 47 us with the grid, which is why the rule
-    // waits for 8e6 points: at 4e6 the step as a whole was 13 us slower with it)
+    // from 4e6 points on a 2-D plan takes the finer grid / narrower window (N = 1e7, mtot = 23: spread + gather 316 -> 276 us on
+    // the same box).  The accumulator -> modes step behind them grows with the grid: as ONE launch it went from 20 to 47-60 us
+    // (180 x 180 cells) and ate the gain -- the two-launch form (grid_rows_kernel + rows_modes_kernel) takes 12 / 17 us.
     const bool dense = d == 2 && plan->npts >= kDensePoints && std::getenv("EFGP_NO_DENSE_SIGMA") == nullptr;
     for (void* vp : plan->ctx->window_cache) {
         WindowSet* w = (WindowSet*)vp;
@@ -2510,6 +2689,38 @@ static int g2m_launch(DeviceCtx* ctx, const GridGeom& g, G2MRequest* req, long l
     ga.out_a = (double2*)req->out_a;
     ga.out_b = (double2*)req->out_b;
     ga.ticket = ticket;
+    if (std::getenv("EFGP_G2M_V1") == nullptr) {
+        // round 3: two launches -- rows of the accumulator over the chip, then one workgroup per column pair of the mode box
+        G2RArgs ra;
+        ra.gacc = gacc;
+        ra.fine = fine;
+        ra.scale = scale;
+        ra.channels = channels;
+        ra.nf0 = ga.nf0;
+        ra.nf1 = ga.nf1;
+        ra.h0 = ga.h0;
+        ra.h1 = ga.h1;
+        ra.part = ga.part;
+        ra.rows_limit = ga.rows_limit;
+        ra.sign = ga.sign;
+        ra.ma = ga.ma;
+        ra.mb = ga.mb;
+        ra.out_a = ga.out_a;
+        ra.out_b = ga.out_b;
+        const int nk1 = 2 * ga.h1 + 1;
+        ra.cbuf = (double2*)scratch(ctx, SLOT_G2M, (size_t)nbatch * ga.nf0 * nk1 * sizeof(double2));
+        if (!ra.cbuf) return EFGP_ENOMEM;
+        ctx->g2m_zeroed_for = nullptr;                   // (the one-launch kernel's counters share this slot)
+        const size_t lds = (256 + (size_t)kG2RRows * ga.nf1) * sizeof(double2);
+        const dim3 grid((ga.nf0 + kG2RRows - 1) / kG2RRows, nbatch);
+        if (gacc) hipLaunchKernelGGL((grid_rows_kernel<false>), grid, dim3(kG2RThreads), lds, stream, ra);
+        else hipLaunchKernelGGL((grid_rows_kernel<true>), grid, dim3(kG2RThreads), lds, stream, ra);
+        EFGP_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(rows_modes_kernel, dim3(ga.h1 + 1, nbatch), dim3(kR2MThreads), 0, stream, ra);
+        EFGP_HIP_CHECK(hipGetLastError());
+        req->done = true;
+        return EFGP_OK;
+    }
     const unsigned tiles = (unsigned)(ga.h0 / 2 + 1);
     const bool small = ga.nf0 <= 128 && ga.nf1 <= 128;
     // stage-1 split, measured (rocprofv3, launch average): 96 x 96 grid 20.0 / 27.7 / 32.4 / 45.7 us at 1 / 2 / 4 / 8 workgroups

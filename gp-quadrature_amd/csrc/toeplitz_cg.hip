@@ -913,6 +913,7 @@ struct CoopArgs {
     unsigned* bar;            // [systems] arrival counters, 64 bytes apart, zero at launch
     int* iters;               // [systems]
     int* status;              // [0] != 0: a barrier timed out
+    int nan_on_dead;          // asynchronous entries: a system whose barrier died gets NaN in x (nobody may mistake x0 for a solution)
     double* hist;
     int hist_cap;
     int G;                    // workgroups per system
@@ -1181,6 +1182,14 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
     };
     auto dead = [&]() {
         if (wg == 0 && tid == 0) a.iters[sys] = -3;
+        // The asynchronous entries have no host that reads the iteration counts before the result is used (EFGPND keeps them as
+        // lazy device values): the unsolved system must show in the DATA, as the Hermitian kernel's refusal does.  The synchronous
+        // entry keeps x0 in place and re-solves the system through the multi-launch iteration.
+        if (a.nan_on_dead) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                if (ok[s]) a.x[base + tid + s * kLineThreads] = make_double2(__builtin_nan(""), __builtin_nan(""));
+        }
     };
 
     double2 Ap[KS];
@@ -1789,7 +1798,7 @@ struct CoopInfo {
 };
 static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int variant, const double* precond_diag, const void* b,
                         void* x, int nbatch, double tol, int max_iter, int early_stop, int batched_semantics, int* d_iters,
-                        hipStream_t stream, CoopInfo* info) {
+                        hipStream_t stream, CoopInfo* info, int nan_on_dead) {
     DeviceCtx* ctx = op->ctx;
     const ToepGeom g = op->g;
     const int F0 = (int)g.F[0], F1 = (int)g.F[1], n0 = (int)g.n[0], n1 = (int)g.n[1];
@@ -1847,6 +1856,7 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     ca.bar = (unsigned*)(scb + off_bar);
     ca.status = (int*)(scb + off_status);
     ca.hist_cap = cg_history().capacity;
+    ca.nan_on_dead = nan_on_dead;
     ca.G = G;
     ca.rows_wg = rows_wg;
     ca.cols_wg = cols_wg;
@@ -1855,10 +1865,15 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     ca.dbg = std::getenv("EFGP_COOP_DBG") ? std::atoi(std::getenv("EFGP_COOP_DBG")) : 0;
     ca.stamps = (double*)(scb + off_status + 64);
     if (ca.dbg == 2) EFGP_HIP_CHECK(hipMemsetAsync(ca.stamps, 0, 128, stream));
-    EFGP_HIP_CHECK(hipMemsetAsync(scb + off_status, 0, 64, stream));
     auto launch = [&](auto kern, int nsys) -> hipError_t {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        // the hand-rolled grid barrier needs every workgroup of a launch resident: at most one workgroup per CU is asked for
+        // (G * nsys <= num_cu above), so it is enough that ONE fits a CU with these registers and this much LDS
+        int fit = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, kern, kLineThreads, lds);
+        if (e != hipSuccess) return e;
+        if (fit < 1) return hipErrorLaunchOutOfResources;
         hipLaunchKernelGGL(kern, dim3(G, nsys), dim3(kLineThreads), lds, stream, ca);
         return hipGetLastError();
     };
@@ -1871,6 +1886,9 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
             ca.iters = d_iters + s0;
             ca.hist = s0 == 0 ? cg_history().buf : nullptr;
             EFGP_HIP_CHECK(hipMemsetAsync(scb + off_bar, 0, (size_t)per * 64, stream));
+            // the status word is cleared before EVERY launch: a dead barrier in one slab of systems must not make the later
+            // slabs give up at their first poll (the per-system iteration counts carry the -3 of the slab that died)
+            EFGP_HIP_CHECK(hipMemsetAsync(scb + off_status, 0, 64, stream));
             hipError_t e;
             if (G == 1 && ks == 8) e = launch(cg_coop2d_kernel<8, true>, nsys);
             else if (G == 1) e = launch(cg_coop2d_kernel<4, true>, nsys);
@@ -1946,7 +1964,7 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         if (!d_iters || !host) return EFGP_ENOMEM;
         CoopInfo ci;
         const int rcq = coop_enqueue(op, ws, sigmasq, variant, precond_diag, b, x, nbatch, tol, max_iter, early_stop, batched_semantics,
-                                     d_iters, stream, &ci);
+                                     d_iters, stream, &ci, /*nan_on_dead: this entry re-solves dead systems from x0*/ 0);
         if (rcq != EFGP_OK && rcq != EFGP_EUNSUPPORTED) return rcq;
         if (rcq == EFGP_OK) {
             EFGP_HIP_CHECK(hipMemcpyAsync(host, ci.d_status, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -2315,7 +2333,7 @@ static int cg_solve_async_impl(efgp_toeplitz_t* op, const void* ws, double sigma
             DeviceGuard guard_c(op->device);
             if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * op->g.M, 2000000000);
             return coop_enqueue(op, ws, sigmasq, variant, precond_diag, b, x, nbatch, tol, max_iter, early_stop, batched_semantics,
-                                row_iters_dev, stream_c, nullptr);
+                                row_iters_dev, stream_c, nullptr, /*nan_on_dead*/ 1);
         }
         set_error("efgp_cg_solve_async: grid does not fit the persistent kernel");
         return EFGP_EUNSUPPORTED;

@@ -308,7 +308,13 @@ def cg_solve(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=Tru
         res = cg_solve_async(op, ws, sigmasq, variant, b, x0, tol, max_iter=max_iter, early_stop=early_stop, diag=diag,
                              batched=batched, hermitian=True)
         if res is not None:
-            return res[0], int(res[1]), list(res[1].rows)
+            try:
+                return res[0], int(res[1]), list(res[1].rows)
+            except RuntimeError as err:
+                # a cooperative launch whose grid barrier died (-3: its systems hold NaN): this entry is the one that retries --
+                # fall through to the synchronous solver, which re-solves dead systems through the multi-launch iteration
+                if "cooperative CG" not in str(err):
+                    raise
     bb = b.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous()
     x = _start_vector(x0, bb, op, dev)
     wsd = ws.to(device=dev, dtype=_CD).contiguous()
@@ -339,8 +345,8 @@ class LazyIterations:
             self._rows = [int(v) for v in self._rows_dev.tolist()]
             if any(v == -3 for v in self._rows):
                 raise RuntimeError("efgp_hip: a cooperative CG launch could not get its workgroups resident together (another "
-                                   "kernel held the CUs); the affected systems were not solved -- call cg_solve (it retries "
-                                   "them through the multi-launch iteration) or set EFGP_NO_CG_COOP=1")
+                                   "kernel held the CUs); the affected systems were not solved and hold NaN -- efgp_hip.cg_solve "
+                                   "retries them through the multi-launch iteration; EFGP_NO_CG_COOP=1 avoids the cooperative path")
             if any(v == -2 for v in self._rows):
                 raise RuntimeError("efgp_hip: a system given to the Hermitian CG kernel is not the transform of real data "
                                    "(right-hand side not conjugate-even, or ws not real and even); its solution is NaN")

@@ -743,7 +743,10 @@ def _rows_over_ranks(shards, top, R):
     import os
     if shards is None or not shards.active or R < shards.world_size or os.environ.get("EFGP_SHARD_ROWS", "1") == "0":
         return False
-    if top.size <= 4096:
+    cells = 1
+    for f in top.fft_shape:
+        cells *= int(f)
+    if cells <= 4096:                                   # circulant grid of one workgroup (64 x 64, short 1-D lines)
         return R > torch.cuda.get_device_properties(top.dev).multi_processor_count
     return True
 
@@ -925,7 +928,8 @@ class EFGPND(nn.Module):
     mean_cg_preconditioner (True), trace_cg_preconditioner (True), mean_cg_warm_start (True),
     noise_floor, log_marginal_probes (100), log_marginal_steps (25); additionally
     ``shard_points`` (bool): x, y hold THIS rank's block of the observations and gridded partial
-    sums are all-reduced over the default process group (one process per GPU).
+    sums are all-reduced over the default process group (one process per GPU); ``point_layout``
+    ("auto" | True | False): when the model builds its sorted point layout (see ``_layout``).
     """
 
     def __init__(self, x, y, kernel, sigmasq: float = None, eps: float = 1e-2, nufft_eps: float = 1e-4,
@@ -1078,11 +1082,23 @@ class EFGPND(nn.Module):
                 L = 1.0
             n_glob = int(self._shards.sum_scalars([xd.shape[0]], dev)[0]) if self._shards.active else xd.shape[0]
             yy = self._shards.sum_scalars([vdot_real(yd, yd)], dev)[0]          # global sum of y^2 (gradient, once)
-            # the model's point layout: every plan of this model is made on it (grid-independent sorted copies for
-            # the type-1 pass, max|y| once per model)
-            pts = PointSet(xd, values=yd) if xd.shape[0] > 0 else None
-            self._devdata = dict(dev=dev, x=xd, y=yd, L=L, N=n_glob, yy=yy, points=pts)
+            self._devdata = dict(dev=dev, x=xd, y=yd, L=L, N=n_glob, yy=yy, points=None, passes=0)
         return self._devdata
+
+    def _layout(self):
+        """The model's point layout (grid-independent sorted copies for the type-1 pass, bounding box, max|y| once per model), or
+        None while it is not worth building.  opts["point_layout"]: "auto" (default) -- from the SECOND pass over the points
+        on: a model that is fitted once (efgp_nd, predict-only use; efgpnd_variance_shootout.py:129-137) never pays the sort
+        (bounding box + key + radix sort + two gathers: 0.5 ms at N = 1e6, 8-13 ms at 1e7), a training loop pays it at its second
+        step and streams the sorted copies from then on; True -- from the first pass; False -- never."""
+        dd = self._device_data()
+        want = self.opts.get("point_layout", "auto")
+        dd["passes"] += 1
+        if want is False or dd["x"].shape[0] == 0 or (want == "auto" and dd["passes"] < 2):
+            return None
+        if dd["points"] is None:
+            dd["points"] = PointSet(dd["x"], values=dd["y"])
+        return dd["points"]
 
     # -- gradient -----------------------------------------------------------------------------------
     def compute_gradients(self, *, trace_samples: int = 10, do_profiling: bool = False,
@@ -1111,7 +1127,7 @@ class EFGPND(nn.Module):
             use_trace_cg_preconditioner=self.opts.get("trace_cg_preconditioner", True),
             compute_log_marginal=compute_log_marginal, log_marginal_probes=log_marginal_probes,
             log_marginal_steps=log_marginal_steps, shards=self._shards, domain_length=dd["L"], y_norm_sq=dd["yy"],
-            points=dd["points"], **kwargs)
+            points=self._layout(), **kwargs)
         self._last_gradient_beta = stats.pop("mean_beta", None)
         grad_host = stats.pop("grad_host", None)       # the native tail reads grad | term1 | term2 back in one copy
         self._last_gradient_stats = stats
@@ -1144,7 +1160,7 @@ class EFGPND(nn.Module):
         cdtype = _cmplx(rdtype)
 
         grid = _Grid(self.kernel, self.eps, dd["L"], d, dev)
-        plan = NufftPlan(xd, grid.h, min(float(nufft_eps), _CONV_TOL), points=dd["points"])
+        plan = NufftPlan(xd, grid.h, min(float(nufft_eps), _CONV_TOL), points=self._layout())
         Fy, v = _normal_equations(plan, yd, grid, self._shards)
         toeplitz = ToeplitzND(v, force_pow2=True)
         use_precond = self.opts.get("mean_cg_preconditioner", True)

@@ -22,8 +22,9 @@ import torch
 
 from efgpnd import NUFFT, ToeplitzND
 
-__all__ = ["weighted_toeplitz", "wrap_to_circulant_kernel", "circulant_eigenvalues", "make_circulant_inverse",
-           "scalar_circulant_preconditioner", "sandwich_circulant_preconditioner"]
+__all__ = ["weighted_toeplitz", "weighted_feature_operator", "wrap_to_circulant_kernel", "circulant_eigenvalues",
+           "make_circulant_inverse", "scalar_circulant_preconditioner", "sandwich_circulant_preconditioner",
+           "reference_preconditioners"]
 
 
 def weighted_toeplitz(nufft_op: NUFFT, weights: torch.Tensor, out_shape: Sequence[int], cdtype=None) -> ToeplitzND:
@@ -34,6 +35,27 @@ def weighted_toeplitz(nufft_op: NUFFT, weights: torch.Tensor, out_shape: Sequenc
     if cdtype is not None:
         v_w = v_w.to(cdtype)
     return ToeplitzND(v_w, force_pow2=True)
+
+
+def weighted_feature_operator(nufft_op: NUFFT, weights: torch.Tensor, ws: torch.Tensor, out_shape: Sequence[int]):
+    """u -> u + ws T_w (ws u), the feature-space operator of the Polya-Gamma classifier's solves (pg_classifier.py:398-416 with
+    the exact weighted Toeplitz operator).  It is A_var with sigma^2 = 1 on the weighted Toeplitz operator, so
+    ``ConjugateGradients(weighted_feature_operator(...), rhs, x0, ...)`` runs inside the fused HIP solver (efgp_cg_solve:
+    one-launch persistent / cooperative kernels), not in a Python loop of transforms as the reference's does."""
+    from efgpnd import create_A_var
+    return create_A_var(ws, weighted_toeplitz(nufft_op, weights, out_shape, cdtype=torch.complex128), 1.0, torch.complex128)
+
+
+def reference_preconditioners(v_kernel: torch.Tensor, ws: torch.Tensor, sigmasq: float):
+    """The six preconditioners of the reference's study, by its names (benchmark_prism_mean_preconditioners.py:158-191)."""
+    from efgpnd import create_jacobi_precond
+    center = tuple((s - 1) // 2 for s in v_kernel.shape)
+    return {"none": None,
+            "jacobi_Nws2": create_jacobi_precond(ws, sigmasq, diag_scale=v_kernel[center].real),
+            "circ_scalar_meanws2": scalar_circulant_preconditioner(v_kernel, ws, sigmasq, "mean"),
+            "circ_scalar_maxws2": scalar_circulant_preconditioner(v_kernel, ws, sigmasq, "max"),
+            "circ_sandwich_med": sandwich_circulant_preconditioner(v_kernel, ws, sigmasq, "median"),
+            "circ_sandwich_geom": sandwich_circulant_preconditioner(v_kernel, ws, sigmasq, "geom")}
 
 
 def wrap_to_circulant_kernel(v_kernel: torch.Tensor) -> torch.Tensor:

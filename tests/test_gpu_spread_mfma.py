@@ -118,7 +118,7 @@ def test_model_fit_uses_layout_and_matches_plain(monkeypatch):
     def run():
         k = SquaredExponential(dimension=2, init_lengthscale=0.2, init_variance=2.0)
         m = EFGPND(x.cuda(), y.cuda(), k, sigmasq=0.2, eps=1e-4, nufft_eps=1e-7, estimate_params=False,
-                   opts={"cg_tolerance": 1e-10})
+                   opts={"cg_tolerance": 1e-10, "point_layout": True})     # layout from the first fit on ("auto": from the second pass)
         mean, _ = m.predict(xn.cuda(), return_variance=False)
         V = torch.ones(3, m.last_fit_stats["feature_count"], dtype=torch.float64)
         V[1, ::2] = -1
@@ -127,6 +127,14 @@ def test_model_fit_uses_layout_and_matches_plain(monkeypatch):
         return mean.cpu(), grad.detach().cpu(), m
     mean_a, grad_a, m = run()
     assert m._devdata["points"] is not None
+    # "auto": a model that is fitted once never builds the layout; its second pass over the points does
+    k = SquaredExponential(dimension=2, init_lengthscale=0.2, init_variance=2.0)
+    lazy = EFGPND(x.cuda(), y.cuda(), k, sigmasq=0.2, eps=1e-4, nufft_eps=1e-7, estimate_params=False, opts={"cg_tolerance": 1e-10})
+    mean_l, _ = lazy.predict(xn.cuda(), return_variance=False)
+    assert lazy._devdata["points"] is None
+    assert float((mean_l.cpu() - mean_a).abs().max() / mean_a.abs().max()) < 1e-5
+    lazy.fit()
+    assert lazy._devdata["points"] is not None
     monkeypatch.setenv("EFGP_NO_MFMA_SPREAD", "1")
     mean_b, grad_b, _ = run()
     assert float((mean_a - mean_b).abs().max() / mean_b.abs().max()) < 1e-5
