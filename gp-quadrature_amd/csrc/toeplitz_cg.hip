@@ -219,44 +219,6 @@ __device__ __forceinline__ double2 apply_A(const CgArgs& a, double2 wst, double2
     return make_double2(g.x / a.sigmasq + u.x, g.y / a.sigmasq + u.y);
 }
 
-// r = b - A x0, z = r/diag, p = z, rz = <r,z>, den = |b| (cg.py:94-111 / :164-186).  grid = rows.
-__global__ __launch_bounds__(kCgThreads) void cg_init_kernel(CgArgs a) {
-    __shared__ double red[kCgThreads / 64];
-    const int row = blockIdx.x;
-    const int64_t M = a.g.M;
-    const double2* P = a.pad + (int64_t)row * a.g.Ftot;
-    double rz = 0.0, bb = 0.0;
-    for (int64_t t = threadIdx.x; t < M; t += kCgThreads) {
-        const int64_t o = (int64_t)row * M + t;
-        double2 x0 = a.x[o];
-        double2 Ax = apply_A(a, a.ws[t], P[pad_index(a.g, t, 1)], x0);
-        double2 bv = a.b[o];
-        double2 rv = make_double2(bv.x - Ax.x, bv.y - Ax.y);
-        double2 zv = rv;
-        if (a.diag) {
-            zv.x = rv.x / a.diag[t];
-            zv.y = rv.y / a.diag[t];
-        }
-        a.r[o] = rv;
-        a.p[o] = zv;
-        rz += rv.x * zv.x + rv.y * zv.y;
-        bb += bv.x * bv.x + bv.y * bv.y;
-    }
-    rz = block_sum(rz, red);
-    bb = block_sum(bb, red);
-    if (threadIdx.x == 0) {
-        double bn = sqrt(bb);
-        a.sc[row].rz = rz;
-        a.sc[row].den = bn > 0.0 ? bn : 1.0;
-        a.sc[row].active = 1;
-        a.sc[row].iters = 0;
-        a.sc[row].pAp = 1.0;
-        a.sc[row].beta = 0.0;
-        a.sc[row].do_p = 0;
-        a.sc[row].pad_ = 0;
-    }
-}
-
 // ---- one CG iteration (cg.py:116-150 / :193-241), spread over nblk workgroups per system ----------------
 // A system with M up to ~2e5 unknowns is far too long for one workgroup (measured: 60 us per iteration at
 // M = 12167), so the iteration is three launches over (nblk, slots) grids; dot products are reduced in two
@@ -284,6 +246,67 @@ __device__ __forceinline__ void block_range(const CgArgs& a, int64_t& lo, int64_
     const int64_t per = (a.g.M + a.nblk - 1) / a.nblk;
     lo = (int64_t)blockIdx.x * per;
     hi = lo + per < a.g.M ? lo + per : a.g.M;
+}
+
+// r = b - A x0, z = r/diag, p = z, rz = <r,z>, den = |b| (cg.py:94-111 / :164-186).  grid = (nblk, rows): round 3 -- with ONE
+// workgroup per system (as before) a 3-D system of 185 k unknowns (BASELINE configs[4] at eps 1e-3) spent 630 us here, 11 % of
+// a hyper-gradient step; the two sums are reduced like the iteration's (fixed order inside a workgroup, partials added in index
+// order by the last workgroup to arrive).
+__global__ __launch_bounds__(kVecThreads) void cg_init_kernel(CgArgs a) {
+    __shared__ double red[kVecThreads / 64];
+    __shared__ int flag;
+    const int row = blockIdx.y;
+    const double2* P = a.pad + (int64_t)row * a.g.Ftot;
+    const int64_t base = (int64_t)row * a.g.M;
+    int64_t lo, hi;
+    block_range(a, lo, hi);
+    double rz = 0.0, bb = 0.0;
+    for (int64_t t = lo + threadIdx.x; t < hi; t += kVecThreads) {
+        const int64_t o = base + t;
+        double2 x0 = a.x[o];
+        double2 Ax = apply_A(a, a.ws[t], P[pad_index(a.g, t, 1)], x0);
+        double2 bv = a.b[o];
+        double2 rv = make_double2(bv.x - Ax.x, bv.y - Ax.y);
+        double2 zv = rv;
+        if (a.diag) {
+            zv.x = rv.x / a.diag[t];
+            zv.y = rv.y / a.diag[t];
+        }
+        a.r[o] = rv;
+        a.p[o] = zv;
+        rz += rv.x * zv.x + rv.y * zv.y;
+        bb += bv.x * bv.x + bv.y * bv.y;
+    }
+    rz = block_sum(rz, red);
+    bb = block_sum(bb, red);
+    double* part = a.partial + (int64_t)row * 3 * kCgBlocksMax;
+    if (threadIdx.x == 0) {
+        part[kCgBlocksMax + blockIdx.x] = rz;
+        part[2 * kCgBlocksMax + blockIdx.x] = bb;
+    }
+    if (!arrive_last(a, row, 1, &flag)) return;
+    __shared__ double fin[2 * kCgBlocksMax];
+    if (threadIdx.x < a.nblk) {
+        fin[threadIdx.x] = load_agent(&part[kCgBlocksMax + threadIdx.x]);
+        fin[kCgBlocksMax + threadIdx.x] = load_agent(&part[2 * kCgBlocksMax + threadIdx.x]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double srz = 0.0, sbb = 0.0;
+        for (int i = 0; i < a.nblk; ++i) {
+            srz += fin[i];
+            sbb += fin[kCgBlocksMax + i];
+        }
+        const double bn = sqrt(sbb);
+        a.sc[row].rz = srz;
+        a.sc[row].den = bn > 0.0 ? bn : 1.0;
+        a.sc[row].active = 1;
+        a.sc[row].iters = 0;
+        a.sc[row].pAp = 1.0;
+        a.sc[row].beta = 0.0;
+        a.sc[row].do_p = 0;
+        a.sc[row].pad_ = 0;
+    }
 }
 
 // pad[slot] = zero-padded ws .* p, after the deferred direction update p <- r/diag + beta p
@@ -2083,7 +2106,7 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         EFGP_HIP_CHECK(hipGetLastError());
         int rc = circulant(op, pad, rows, stream);
         if (rc != EFGP_OK) return rc;
-        hipLaunchKernelGGL(cg_init_kernel, dim3(rows), dim3(kCgThreads), 0, stream, a);
+        hipLaunchKernelGGL(cg_init_kernel, dim3(a.nblk, rows), dim3(kVecThreads), 0, stream, a);
         EFGP_HIP_CHECK(hipGetLastError());
 
         // iteration loop; active rows are compacted on the host whenever the status is polled

@@ -95,7 +95,7 @@ def test_fit_residual_and_mean_at_full_size():
     k = SquaredExponential(dimension=2, init_lengthscale=0.2, init_variance=2.0)
     tol = 1e-6
     m = EFGPND(x, y, k, sigmasq=0.2, eps=1e-4, nufft_eps=TOL, estimate_params=False,
-               opts={"cg_tolerance": tol, "mean_cg_warm_start": False})
+               opts={"cg_tolerance": tol, "mean_cg_warm_start": False, "point_layout": True})   # same spreader in both fits below
     mean, _ = m.predict(x, return_variance=False)
     st = m._fit_state
     assert st["mtot"] == MTOT
