@@ -344,27 +344,35 @@ def main():
     grad_step_ms = 1e3 * sorted(gts)[len(gts) // 2]
 
     # CG iteration time on the circulant grids beyond one CU (BASELINE configs[2], [3] solve on 128^2..512^2): one cooperative
-    # launch per solve (cg_coop2d_kernel); synthetic Hermitian Toeplitz vector, 160 forced iterations, rank 0's GPU only
+    # launch per solve; synthetic Hermitian Toeplitz vector, 160 forced iterations, rank 0's GPU only.  The systems are what a
+    # model's are -- right-hand side conjugate-even (the transform of real data), ws real and even -- and go through the
+    # Hermitian kernel (cg_coop2d_herm_kernel, round 3); `cg_mid_general_us_per_iter`: the same systems through the general
+    # complex kernel (cg_coop2d_kernel), which arbitrary right-hand sides (feature-space probes) take.
     cg_mid = None
+    cg_mid_general = None
     if rank == 0 and not args.no_extras:
         from efgp_hip import ToeplitzOp
-        cg_mid = {}
+        cg_mid, cg_mid_general = {}, {}
         gm = torch.Generator().manual_seed(0)
         for mt in (41, 71, 131):
             L = 2 * mt - 1
             vv = torch.complex(torch.randn(L, L, generator=gm, dtype=torch.float64), torch.randn(L, L, generator=gm, dtype=torch.float64))
             vv = ((vv + vv.flip(0, 1).conj()) / 2).to(dev)
-            wsm = torch.rand(mt * mt, generator=gm, dtype=torch.float64).to(torch.complex128).to(dev)
-            bm = torch.randn(mt * mt, generator=gm, dtype=torch.float64).to(torch.complex128).to(dev)
+            wr = torch.rand(mt, mt, generator=gm, dtype=torch.float64)
+            wsm = ((wr + wr.flip(0, 1)) / 2).reshape(-1).to(torch.complex128).to(dev)
+            br = torch.complex(torch.randn(mt, mt, generator=gm, dtype=torch.float64), torch.randn(mt, mt, generator=gm, dtype=torch.float64))
+            bm = ((br + br.flip(0, 1).conj()) / 2).reshape(-1).to(dev)
             dgm = (wsm.abs() ** 2 + 0.1).real
             opm = ToeplitzOp(vv)
-            for _ in range(2):
-                torch.cuda.synchronize(dev)
-                tm = time.perf_counter()
-                _, itm, _ = cg_solve(opm, wsm, 0.1, 0, bm, torch.zeros_like(bm), 1e-300, max_iter=160, early_stop=False, diag=dgm, batched=False)
-                torch.cuda.synchronize(dev)
-                dtm = time.perf_counter() - tm
-            cg_mid[f"{opm.fft_shape[0]}x{opm.fft_shape[1]}"] = 1e6 * dtm / itm
+            for herm, dst in ((True, cg_mid), (False, cg_mid_general)):
+                for _ in range(2):
+                    torch.cuda.synchronize(dev)
+                    tm = time.perf_counter()
+                    _, itm, _ = cg_solve(opm, wsm, 0.1, 0, bm, torch.zeros_like(bm), 1e-300, max_iter=160, early_stop=False, diag=dgm,
+                                         batched=False, hermitian=herm)
+                    torch.cuda.synchronize(dev)
+                    dtm = time.perf_counter() - tm
+                dst[f"{opm.fft_shape[0]}x{opm.fft_shape[1]}"] = 1e6 * dtm / itm
             del opm
 
     costs = model_costs(dev, x, y) if (world == 1 and rank == 0 and not args.no_extras) else None
@@ -456,6 +464,7 @@ def main():
             rec["north_star_n1e7"] = star
         if cg_mid is not None:
             rec["cg_mid_us_per_iter"] = cg_mid
+            rec["cg_mid_general_us_per_iter"] = cg_mid_general
         if world == 1 and not args.no_extras:
             rec["model_costs"] = costs
         if world == 1 and not args.no_cpu_baseline:

@@ -586,12 +586,16 @@ __device__ __forceinline__ void wave_sync_lds() {
 
 // forward transform of nl lines (line l at src + l * ld, natural order) into dst + l * ld (natural order); src is destroyed.
 // tw = exp(-2 pi i q / F), q < F, in LDS.  Ends with a workgroup barrier.
-// MUL: the outputs are multiplied by mul[k * mul_stride + l] (entry k of line l) and conjugated on the way out -- the
+// MUL = 1: the outputs are multiplied by mul[k * mul_stride + l] (entry k of line l) and conjugated on the way out -- the
 // spectrum multiply and the conjugation in front of the inverse transform, done on the registers that hold the result;
 // the return value is the thread's share of sum Re(mul) |X|^2 (with the centred spectrum: <w, T w> by Parseval).
-template <int R, bool MUL = false>
+// MUL = 2 (round 3, Hermitian cooperative solve): line l carries TWO real columns as real and imaginary part; they are
+// multiplied by the REAL spectra Re mul[k * mul_stride + l] and Re mul[k * mul_stride + l + mul_pair], halved (the unpacking
+// behind the inverse transform adds two terms) and conjugated; the return value is sum S_a re^2 + S_b im^2.
+template <int R, int MUL = 0>
 __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, int ld, int nl, const double2* tw,
-                                                  const double2* __restrict__ mul = nullptr, int64_t mul_stride = 0) {
+                                                  const double2* __restrict__ mul = nullptr, int64_t mul_stride = 0,
+                                                  int64_t mul_pair = 0) {
     constexpr int LPL = 8 * R, LINES = kLineThreads / LPL, U = R > 1 ? 8 / R : 1;
     double psum = 0.0;          // MUL: this thread's share of sum_k Re(mul_k) |X_k|^2 over its lines (Parseval: <w, T w>)
     const int li = threadIdx.x & (LPL - 1), lsub = threadIdx.x / LPL;
@@ -620,12 +624,20 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
                 double2 mv[8];
                 const int lq = act ? l0 + lsub : l0;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) mv[t] = mul[(int64_t)(j + 8 * t) * mul_stride + lq];
+                for (int t = 0; t < 8; ++t) {
+                    mv[t] = mul[(int64_t)(j + 8 * t) * mul_stride + lq];
+                    if (MUL == 2) mv[t].y = mul[(int64_t)(j + 8 * t) * mul_stride + lq + mul_pair].x;
+                }
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    if (act) psum += mv[t].x * (v[t].x * v[t].x + v[t].y * v[t].y);
-                    const double2 m = cmul(v[t], mv[t]);
-                    v[t] = make_double2(m.x, -m.y);
+                    if (MUL == 2) {
+                        if (act) psum += mv[t].x * v[t].x * v[t].x + mv[t].y * v[t].y * v[t].y;
+                        v[t] = make_double2(0.5 * mv[t].x * v[t].x, -0.5 * mv[t].y * v[t].y);
+                    } else {
+                        if (act) psum += mv[t].x * (v[t].x * v[t].x + v[t].y * v[t].y);
+                        const double2 m = cmul(v[t], mv[t]);
+                        v[t] = make_double2(m.x, -m.y);
+                    }
                 }
             }
             wave_sync_lds();
@@ -650,7 +662,10 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int q = 0; q < R; ++q) mv[u * R + q] = mul[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq];
+                for (int q = 0; q < R; ++q) {
+                    mv[u * R + q] = mul[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq];
+                    if (MUL == 2) mv[u * R + q].y = mul[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq + mul_pair].x;
+                }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -680,9 +695,14 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
         if (MUL) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (act) psum += mv[i].x * (v[i].x * v[i].x + v[i].y * v[i].y);
-                const double2 m = cmul(v[i], mv[i]);
-                v[i] = make_double2(m.x, -m.y);
+                if (MUL == 2) {
+                    if (act) psum += mv[i].x * v[i].x * v[i].x + mv[i].y * v[i].y * v[i].y;
+                    v[i] = make_double2(0.5 * mv[i].x * v[i].x, -0.5 * mv[i].y * v[i].y);
+                } else {
+                    if (act) psum += mv[i].x * (v[i].x * v[i].x + v[i].y * v[i].y);
+                    const double2 m = cmul(v[i], mv[i]);
+                    v[i] = make_double2(m.x, -m.y);
+                }
             }
         }
         wave_sync_lds();
@@ -702,27 +722,37 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
 // with every unrelated code change).  Operands are passed as offsets into the kernel's dynamic LDS so that the accesses
 // stay LDS instructions.
 extern __shared__ double2 efgp_line_lds[];
-template <int R, bool MUL>
+template <int R, int MUL>
 __device__ __noinline__ double line_fft_inwave_call(int src_off, int dst_off, int ld, int nl, int tw_off, const double2* mul,
-                                                    int64_t mul_stride) {
-    return line_fft_inwave<R, MUL>(efgp_line_lds + src_off, efgp_line_lds + dst_off, ld, nl, efgp_line_lds + tw_off, mul, mul_stride);
+                                                    int64_t mul_stride, int64_t mul_pair = 0) {
+    return line_fft_inwave<R, MUL>(efgp_line_lds + src_off, efgp_line_lds + dst_off, ld, nl, efgp_line_lds + tw_off, mul, mul_stride,
+                                   mul_pair);
 }
 // result buffer is always `dst`
 __device__ __forceinline__ double2* line_fft_fast(double2* src, double2* dst, int F, int ld, int nl, const double2* tw) {
     const int so = (int)(src - efgp_line_lds), dn = (int)(dst - efgp_line_lds), to = (int)(tw - efgp_line_lds);
-    if (F == 64) line_fft_inwave_call<1, false>(so, dn, ld, nl, to, nullptr, 0);
-    else if (F == 128) line_fft_inwave_call<2, false>(so, dn, ld, nl, to, nullptr, 0);
-    else if (F == 256) line_fft_inwave_call<4, false>(so, dn, ld, nl, to, nullptr, 0);
-    else line_fft_inwave_call<8, false>(so, dn, ld, nl, to, nullptr, 0);
+    if (F == 64) line_fft_inwave_call<1, 0>(so, dn, ld, nl, to, nullptr, 0);
+    else if (F == 128) line_fft_inwave_call<2, 0>(so, dn, ld, nl, to, nullptr, 0);
+    else if (F == 256) line_fft_inwave_call<4, 0>(so, dn, ld, nl, to, nullptr, 0);
+    else line_fft_inwave_call<8, 0>(so, dn, ld, nl, to, nullptr, 0);
     return dst;
 }
 // forward transform, spectrum multiply (mul[k * mul_stride + l]) and conjugation in one pass (F = 128, 256, 512)
 __device__ __forceinline__ double2* line_fft_fast_mul(double2* src, double2* dst, int F, int ld, int nl, const double2* tw,
                                                       const double2* mul, int64_t mul_stride, double& psum) {
     const int so = (int)(src - efgp_line_lds), dn = (int)(dst - efgp_line_lds), to = (int)(tw - efgp_line_lds);
-    if (F == 128) psum += line_fft_inwave_call<2, true>(so, dn, ld, nl, to, mul, mul_stride);
-    else if (F == 256) psum += line_fft_inwave_call<4, true>(so, dn, ld, nl, to, mul, mul_stride);
-    else psum += line_fft_inwave_call<8, true>(so, dn, ld, nl, to, mul, mul_stride);
+    if (F == 128) psum += line_fft_inwave_call<2, 1>(so, dn, ld, nl, to, mul, mul_stride);
+    else if (F == 256) psum += line_fft_inwave_call<4, 1>(so, dn, ld, nl, to, mul, mul_stride);
+    else psum += line_fft_inwave_call<8, 1>(so, dn, ld, nl, to, mul, mul_stride);
+    return dst;
+}
+// the same for lines that carry two real columns (MUL = 2)
+__device__ __forceinline__ double2* line_fft_fast_mul2(double2* src, double2* dst, int F, int ld, int nl, const double2* tw,
+                                                       const double2* mul, int64_t mul_stride, int64_t mul_pair, double& psum) {
+    const int so = (int)(src - efgp_line_lds), dn = (int)(dst - efgp_line_lds), to = (int)(tw - efgp_line_lds);
+    if (F == 128) psum += line_fft_inwave_call<2, 2>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
+    else if (F == 256) psum += line_fft_inwave_call<4, 2>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
+    else psum += line_fft_inwave_call<8, 2>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
     return dst;
 }
 // in-wave transform for the lengths it covers, the generic Stockham stages otherwise; the result buffer is returned
@@ -1269,6 +1299,313 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
         if (ok[s]) a.x[base + tid + s * kLineThreads] = xv[s];
     if (wg == 0 && tid == 0) a.iters[sys] = it;
 #undef COOP_STAMP
+}
+
+// ==========================================================================================================
+// Hermitian specialisation of the cooperative solve (round 3; the mid-size counterpart of cg_herm64_kernel).
+// Every CG system of an EFGP model has vectors that are coefficient arrays of REAL functions (u[-k] = conj u[k] on the
+// centred modes k in [-h, h]^2), a real even ws and a real centred spectrum S = vhat_c.  With the modes placed CENTRED
+// on the torus (mode k at position k mod F) the operator is
+//     coefficients -> real function r(f) -> S r -> coefficients,
+// and only half of every phase is needed:
+//   R : rows k0 = 0..h0 of ws .* u, forward transform along dim 1              -> B1[k0][f1]      (h0 + 1 of n0 rows)
+//   C : the column of a real function is the transform of a Hermitian sequence z[k0] = G[k0][c], z[-k0] = conj G[k0][c]:
+//       REAL, so two columns c = q, q + F1/2 ride through one complex transform as real and imaginary part (F1/2 column
+//       lines); .* the two real spectra (halved), conjugate, transform again; unpack T_q[k0] = T[k0] + conj T[-k0],
+//       T_q'[k0] = (T[k0] - conj T[-k0]) / i for k0 >= 0                       -> B2[k0][f1]
+//   Ri: rows k0 >= 0, inverse transform along dim 1, crop to |k1| <= h1, A u = ws .* (.) + sigma^2 u
+// Row k0 = 0 stores BOTH +k1 and -k1; its line G[0][.] is real only up to the anti-Hermitian rounding noise of the iterates,
+// so phase C keeps its real part only (the projection the 64 x 64 kernel needed, see cg_persistent.hip).  Dot products weigh
+// the rows k0 > 0 twice.  Same recurrences, stopping rule, barrier / all-reduce machinery as cg_coop2d_kernel; a right-hand
+// side that is not conjugate-even (or a ws that is not real and even) is refused: -2 iterations, NaN in x.
+// Launch geometry in CoopArgs: rows_wg = rows k0 per workgroup (of h0 + 1), cols_wg = column PAIRS per workgroup (of F1 / 2),
+// lpbc = pairs per LDS pass.
+// ==========================================================================================================
+template <int KS, bool SOLO>
+__global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a) {
+    extern __shared__ double2 lsm[];
+    __shared__ double red[kLineThreads / 64];
+    __shared__ double fin[3 * kCoopMaxG];
+    __shared__ int sflag;
+    const int tid = threadIdx.x, wg = blockIdx.x, sys = blockIdx.y, G = a.G;
+    const int n0 = (int)a.g.n[0], n1 = (int)a.g.n[1], F0 = (int)a.g.F[0], F1 = (int)a.g.F[1];
+    const int h0 = (n0 - 1) / 2, h1 = (n1 - 1) / 2, nh = h0 + 1, halfF1 = F1 >> 1;
+    const int ldr = F1 + 1, ldc = F0 + 1;
+    const int lgF1 = ilog2(F1), lgC = ilog2(a.lpbc);
+    const int bufsz = max(a.lines * ldr, a.lpbc * ldc);
+    double2* A = lsm;
+    double2* B = lsm + bufsz;
+    double2* tw1s = B + bufsz;
+    double2* tw0s = F0 == F1 ? tw1s : tw1s + F1;
+    load_twiddles(tw1s, a.tw1, F1);
+    if (F0 != F1) load_twiddles(tw0s, a.tw0, F0);
+    __syncthreads();
+    const int64_t M = a.g.M;
+    const int r0 = wg * a.rows_wg;                            // first owned row k0
+    const int nrows = max(0, min(a.rows_wg, nh - r0));
+    const int cnt = nrows * n1;
+    const int64_t base = (int64_t)sys * M;
+    const int p_lo = wg * a.cols_wg;                          // first owned column pair
+    double2* b1 = a.b1 + (int64_t)sys * n0 * F1;
+    double2* b2 = a.b2 + (int64_t)sys * n0 * F1;
+    double* part = a.partial + (int64_t)sys * 3 * kCoopMaxG;
+    unsigned* bar = a.bar + (int64_t)sys * 16;
+    unsigned epoch = 0;
+
+    double2 xv[KS], rv[KS], pv[KS];
+    double wsr[KS], dg[KS], wgt[KS];
+    int lrow[KS], pos1[KS], tix[KS];                          // owned element s: row k0 = r0 + lrow, torus position of k1, flat index
+    bool ok[KS];
+    double ws_bad = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int e = tid + s * kLineThreads;
+        ok[s] = e < cnt;
+        lrow[s] = ok[s] ? e / n1 : 0;
+        const int lcol = ok[s] ? e - lrow[s] * n1 : 0;
+        const int k0 = r0 + lrow[s];
+        pos1[s] = (lcol - h1) & (F1 - 1);
+        tix[s] = (h0 + k0) * n1 + lcol;
+        wgt[s] = k0 == 0 ? 1.0 : 2.0;
+        if (ok[s]) {
+            xv[s] = a.x[base + tix[s]];
+            const double2 w = a.ws[tix[s]], wm = a.ws[M - 1 - tix[s]];
+            wsr[s] = w.x;
+            ws_bad += w.y * w.y + (w.x - wm.x) * (w.x - wm.x) + wm.y * wm.y;
+            dg[s] = a.diag ? a.diag[tix[s]] : 1.0;
+        } else {
+            xv[s] = make_double2(0.0, 0.0);
+            wsr[s] = 0.0;
+            dg[s] = 1.0;
+            wgt[s] = 0.0;
+        }
+        rv[s] = pv[s] = make_double2(0.0, 0.0);
+    }
+    auto sync_grid = [&]() __attribute__((always_inline)) -> bool {
+        if (SOLO) {
+            __syncthreads();
+            return true;
+        }
+        return coop_barrier(bar, epoch, G, a.status, &sflag);
+    };
+    auto all_sum = [&](double (&v)[3], int K, int slot0) __attribute__((always_inline)) -> bool {
+        double a0 = v[0], a1 = K > 1 ? v[1] : 0.0;
+        for (int off = 32; off > 0; off >>= 1) {
+            a0 += __shfl_down(a0, off, 64);
+            a1 += __shfl_down(a1, off, 64);
+        }
+        const int lane = tid & 63, wid = tid >> 6;
+        __syncthreads();
+        if (lane == 0) {
+            red[wid] = a0;
+            fin[wid] = a1;
+        }
+        __syncthreads();
+        a0 = ((red[0] + red[1]) + red[2]) + red[3];
+        a1 = ((fin[0] + fin[1]) + fin[2]) + fin[3];
+        if (SOLO) {
+            v[0] = a0;
+            v[1] = a1;
+            __syncthreads();
+            return true;
+        }
+        if (tid == 0) {
+            __hip_atomic_store(&part[slot0 * kCoopMaxG + wg], a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (K > 1) __hip_atomic_store(&part[(slot0 + 1) * kCoopMaxG + wg], a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!coop_barrier(bar, epoch, G, a.status, &sflag)) return false;
+        double b0 = lane < G ? __hip_atomic_load(&part[slot0 * kCoopMaxG + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        double b1v = (K > 1 && lane < G) ? __hip_atomic_load(&part[(slot0 + 1) * kCoopMaxG + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        for (int off = 32; off > 0; off >>= 1) {
+            b0 += __shfl_xor(b0, off, 64);
+            b1v += __shfl_xor(b1v, off, 64);
+        }
+        v[0] = b0;
+        v[1] = b1v;
+        return true;
+    };
+    auto apply = [&](const double2 (&u)[KS], double2 (&Au)[KS], double& uAu) __attribute__((always_inline)) -> bool {
+        double pp = 0.0, cs = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pp += wgt[s] * (u[s].x * u[s].x + u[s].y * u[s].y);
+        // R: owned rows k0 in passes of a.lines; mode k1 sits at position k1 mod F1
+        for (int p0 = 0; p0 < nrows; p0 += a.lines) {
+            const int nl = min(a.lines, nrows - p0);
+            for (int l = 0; l < nl; ++l)                                      // zeros between the two ends of the mode range
+                for (int i1 = h1 + 1 + tid; i1 < F1 - h1; i1 += kLineThreads) A[l * ldr + i1] = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                if (ok[s] && lrow[s] >= p0 && lrow[s] < p0 + nl) A[(lrow[s] - p0) * ldr + pos1[s]] = make_double2(wsr[s] * u[s].x, wsr[s] * u[s].y);
+            __syncthreads();
+            const double2* X = line_fft_fast(A, B, F1, ldr, nl, tw1s);
+            for (int w = tid; w < (nl << lgF1); w += kLineThreads) {
+                const int l = w >> lgF1, i1 = w & (F1 - 1);
+                store_x2<SOLO>(b1 + (int64_t)(r0 + p0 + l) * F1 + i1, X[l * ldr + i1]);
+            }
+            __syncthreads();
+        }
+        if (!sync_grid()) return false;
+        // C: owned column pairs (q, q + F1/2) in passes of a.lpbc lines
+        for (int c0 = p_lo; c0 < p_lo + a.cols_wg; c0 += a.lpbc) {
+            double2 ta[kCoopLoads / 2], tb[kCoopLoads / 2];
+#pragma unroll
+            for (int q = 0; q < kCoopLoads / 2; ++q) {                        // every load is issued before the first is used
+                const int w = tid + q * kLineThreads, l = w & (a.lpbc - 1), k0 = w >> lgC;
+                const bool in = k0 < nh;
+                ta[q] = in ? load_x2<SOLO>(b1 + (int64_t)k0 * F1 + c0 + l) : make_double2(0.0, 0.0);
+                tb[q] = in ? load_x2<SOLO>(b1 + (int64_t)k0 * F1 + c0 + l + halfF1) : make_double2(0.0, 0.0);
+            }
+            for (int w = tid; w < a.lpbc * (F0 - 2 * h0 - 1); w += kLineThreads) {          // zeros between the two ends
+                const int l = w & (a.lpbc - 1), i0 = h0 + 1 + (w >> lgC);
+                A[l * ldc + i0] = make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int q = 0; q < kCoopLoads / 2; ++q) {
+                const int w = tid + q * kLineThreads, l = w & (a.lpbc - 1), k0 = w >> lgC;
+                if (k0 < nh) {
+                    const double2 ga = ta[q], gb = tb[q];
+                    if (k0 == 0) {
+                        A[l * ldc] = make_double2(ga.x, gb.x);                                    // real part of line k0 = 0
+                    } else {
+                        A[l * ldc + k0] = make_double2(ga.x - gb.y, ga.y + gb.x);                 // G_a + i G_b
+                        A[l * ldc + F0 - k0] = make_double2(ga.x + gb.y, gb.x - ga.y);            // conj G_a + i conj G_b
+                    }
+                }
+            }
+            __syncthreads();
+            double2* X = line_fft_fast_mul2(A, B, F0, ldc, a.lpbc, tw0s, a.vhat + c0, F1, halfF1, cs);
+            double2* Y = X == A ? B : A;
+            const double2* Z = line_fft_fast(X, Y, F0, ldc, a.lpbc, tw0s);    // Z = conj T (T = packed, halved result)
+            for (int w = tid; w < (nh << lgC); w += kLineThreads) {
+                const int l = w & (a.lpbc - 1), k0 = w >> lgC;
+                const double2 zp = Z[l * ldc + k0], zm = Z[l * ldc + ((F0 - k0) & (F0 - 1))];
+                const double px = zp.x, py = -zp.y, mx = zm.x, my = -zm.y;       // T[k0], T[-k0]
+                store_x2<SOLO>(b2 + (int64_t)k0 * F1 + c0 + l, make_double2(px + mx, py - my));            // T + conj T(-)
+                store_x2<SOLO>(b2 + (int64_t)k0 * F1 + c0 + l + halfF1, make_double2(py + my, mx - px));   // (T - conj T(-)) / i
+            }
+            __syncthreads();
+        }
+        {
+            double t3[3] = {a.variant == 0 ? a.sigmasq * pp + cs : pp + cs / a.sigmasq, 0.0, 0.0};
+            if (!all_sum(t3, 1, 2)) return false;
+            uAu = t3[0];
+        }
+        // Ri: owned rows k0
+#pragma unroll
+        for (int s = 0; s < KS; ++s) Au[s] = make_double2(0.0, 0.0);
+        for (int p0 = 0; p0 < nrows; p0 += a.lines) {
+            const int nl = min(a.lines, nrows - p0);
+            double2 tmp[kCoopLoads];
+#pragma unroll
+            for (int q = 0; q < kCoopLoads; ++q) {
+                const int w = tid + q * kLineThreads;
+                tmp[q] = w < (nl << lgF1) ? load_x2<SOLO>(b2 + (int64_t)(r0 + p0) * F1 + w) : make_double2(0.0, 0.0);   // rows are contiguous
+            }
+#pragma unroll
+            for (int q = 0; q < kCoopLoads; ++q) {
+                const int w = tid + q * kLineThreads;
+                if (w < (nl << lgF1)) A[(w >> lgF1) * ldr + (w & (F1 - 1))] = make_double2(tmp[q].x, -tmp[q].y);
+            }
+            __syncthreads();
+            const double2* X = line_fft_fast(A, B, F1, ldr, nl, tw1s);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (ok[s] && lrow[s] >= p0 && lrow[s] < p0 + nl) {
+                    const double2 z = X[(lrow[s] - p0) * ldr + pos1[s]];
+                    const double2 gq = make_double2(wsr[s] * z.x, -wsr[s] * z.y);
+                    if (a.variant == 0) Au[s] = make_double2(gq.x + a.sigmasq * u[s].x, gq.y + a.sigmasq * u[s].y);
+                    else Au[s] = make_double2(gq.x / a.sigmasq + u[s].x, gq.y / a.sigmasq + u[s].y);
+                }
+            }
+            __syncthreads();
+        }
+        return true;
+    };
+    auto fill_nan = [&]() {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            if (ok[s]) {
+                a.x[base + tix[s]] = make_double2(__builtin_nan(""), __builtin_nan(""));
+                a.x[base + M - 1 - tix[s]] = make_double2(__builtin_nan(""), __builtin_nan(""));
+            }
+    };
+    auto dead = [&]() {
+        if (wg == 0 && tid == 0) a.iters[sys] = -3;
+        if (a.nan_on_dead) fill_nan();
+    };
+
+    // the contract: b conjugate-even, ws real and even (rounding leaves ~1e-32 |b|^2)
+    double2 bv[KS];
+    double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        bv[s] = make_double2(0.0, 0.0);
+        if (ok[s]) {
+            bv[s] = a.b[base + tix[s]];
+            const double2 bm = a.b[base + M - 1 - tix[s]];
+            acc[0] += (bv[s].x - bm.x) * (bv[s].x - bm.x) + (bv[s].y + bm.y) * (bv[s].y + bm.y);
+            acc[1] += wgt[s] * (bv[s].x * bv[s].x + bv[s].y * bv[s].y);
+        }
+    }
+    acc[0] += ws_bad > 0.0 ? 1e300 : 0.0;
+    if (!all_sum(acc, 2, 0)) return dead();
+    const double bb = acc[1];
+    if (!(acc[0] <= 1e-16 * bb)) {
+        fill_nan();
+        if (wg == 0 && tid == 0) a.iters[sys] = -2;
+        return;
+    }
+    double2 Ap[KS];
+    double uAu = 0.0;
+    if (!apply(xv, Ap, uAu)) return dead();
+    acc[0] = acc[1] = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (ok[s]) {
+            rv[s] = make_double2(bv[s].x - Ap[s].x, bv[s].y - Ap[s].y);
+            pv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            acc[0] += wgt[s] * (rv[s].x * pv[s].x + rv[s].y * pv[s].y);
+        }
+    }
+    if (!all_sum(acc, 1, 0)) return dead();
+    double rz = acc[0];
+    const double bn = sqrt(bb);
+    const double den = bn > 0.0 ? bn : 1.0;
+    int it = 0;
+    for (; it < a.max_iter;) {
+        if (!apply(pv, Ap, uAu)) return dead();
+        const double alpha = rz / (uAu + kDivEps);
+        acc[0] = acc[1] = 0.0;
+        double2 zv[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            xv[s].x += alpha * pv[s].x;
+            xv[s].y += alpha * pv[s].y;
+            rv[s].x -= alpha * Ap[s].x;
+            rv[s].y -= alpha * Ap[s].y;
+            zv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            acc[0] += wgt[s] * (rv[s].x * rv[s].x + rv[s].y * rv[s].y);
+            acc[1] += wgt[s] * (rv[s].x * zv[s].x + rv[s].y * zv[s].y);
+        }
+        if (!all_sum(acc, 2, 0)) return dead();
+        ++it;
+        const double rnorm = sqrt(acc[0]), rzn = acc[1];
+        if (a.hist && sys == 0 && wg == 0 && tid == 0 && it <= a.hist_cap) a.hist[it - 1] = rnorm / (den + kDivEps);
+        const bool conv = a.early_stop && ((rnorm / (den + kDivEps) < a.tol) || (a.batched && rnorm < 1e-12));
+        if (!a.batched && conv) break;                            // cg.py:132
+        const double beta = rzn / (rz + kDivEps);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pv[s] = make_double2(zv[s].x + beta * pv[s].x, zv[s].y + beta * pv[s].y);
+        rz = rzn;
+        if (conv) break;                                          // cg.py:229-241
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        if (ok[s]) {
+            a.x[base + tix[s]] = xv[s];
+            if (r0 + lrow[s] > 0) a.x[base + M - 1 - tix[s]] = make_double2(xv[s].x, -xv[s].y);        // mode -k
+        }
+    if (wg == 0 && tid == 0) a.iters[sys] = it;
 }
 
 // ==========================================================================================================
@@ -1821,26 +2158,32 @@ struct CoopInfo {
 };
 static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int variant, const double* precond_diag, const void* b,
                         void* x, int nbatch, double tol, int max_iter, int early_stop, int batched_semantics, int* d_iters,
-                        hipStream_t stream, CoopInfo* info, int nan_on_dead) {
+                        hipStream_t stream, CoopInfo* info, int nan_on_dead, int hermitian = 0) {
     DeviceCtx* ctx = op->ctx;
     const ToepGeom g = op->g;
     const int F0 = (int)g.F[0], F1 = (int)g.F[1], n0 = (int)g.n[0], n1 = (int)g.n[1];
+    // Hermitian systems (the caller's promise, checked by the kernel): rows k0 >= 0 only, column pairs (cg_coop2d_herm_kernel)
+    const bool herm = hermitian && (n0 & 1) && (n1 & 1) && n0 >= 3 && std::getenv("EFGP_NO_CG_COOP_HERM") == nullptr;
+    const int nrow = herm ? (n0 + 1) / 2 : n0;            // rows of the mode block the workgroups share out
+    const int ncol = herm ? F1 / 2 : F1;                  // column lines (pairs) they share out
     // workgroups per system: as many as the latency shape uses (16 / 32 / 64) while the whole batch stays resident (one
     // workgroup per CU), never fewer than the registers need (8 vector entries per thread)
     int G_lat = F1 / 8;      // 16 / 32 / 64 (measured at 128^2: 19.9 us per iteration with 16 workgroups, 22.7 with 32, 20.6 with 8)
     if (const char* eg = std::getenv("EFGP_COOP_G")) G_lat = std::max(1, std::min(G_lat, std::atoi(eg)));   // experiments
     int G_min = 1;
-    while (G_min < G_lat && ((n0 + G_min - 1) / G_min) * n1 > 8 * kLineThreads) G_min <<= 1;
+    while (G_min < G_lat && ((nrow + G_min - 1) / G_min) * n1 > 8 * kLineThreads) G_min <<= 1;
     int G = G_lat;
     while (G > G_min && (int64_t)G * nbatch > ctx->num_cu) G >>= 1;
-    const int ks = ((n0 + G - 1) / G) * n1 <= 4 * kLineThreads ? 4 : 8;
+    const int ks = ((nrow + G - 1) / G) * n1 <= 4 * kLineThreads ? 4 : 8;
     // columns per LDS pass: as many as the workgroup owns, the per-thread load registers (16) and the LDS allow -- a pass of
     // 8 columns leaves one work item per thread and stage (latency bound: 134 us per iteration of a 128^2 system on one CU
-    // with 8, 4 items with 32)
-    int lpbc = std::min(F1 / G, kCoopLoads * kLineThreads / F0);
+    // with 8, 4 items with 32).  Hermitian: a line is a column PAIR and a thread loads two values per (k0, line) slot.
+    const int load_cap = herm ? (kCoopLoads / 2) * kLineThreads / nrow : kCoopLoads * kLineThreads / F0;
+    int lpbc = 1;
+    while (lpbc * 2 <= std::min(ncol / G, load_cap)) lpbc <<= 1;
     while (lpbc > 4 && ((size_t)4 * lpbc * (F0 + 1) + (size_t)F0 + (size_t)F1) * sizeof(double2) + 2048 > (size_t)ctx->max_lds) lpbc >>= 1;
-    bool shape_ok = G <= kCoopMaxG && ((n0 + G - 1) / G) * n1 <= ks * kLineThreads && F1 % (G * lpbc) == 0;
-    const int rows_wg = (n0 + G - 1) / G, cols_wg = F1 / G;
+    bool shape_ok = G <= kCoopMaxG && ((nrow + G - 1) / G) * n1 <= ks * kLineThreads && ncol % (G * lpbc) == 0;
+    const int rows_wg = (nrow + G - 1) / G, cols_wg = ncol / G;
     int lines = std::min(rows_wg, kCoopLoads * kLineThreads / F1);
     auto lds_for = [&](int ln) {
         const size_t bufsz = (size_t)std::max(ln * (F1 + 1), lpbc * (F0 + 1));
@@ -1848,7 +2191,8 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     };
     while (lines > 1 && lds_for(lines) + 2048 > (size_t)ctx->max_lds) --lines;
     const size_t lds = lds_for(lines);
-    shape_ok = shape_ok && lpbc * F0 <= kCoopLoads * kLineThreads && lds + 2048 <= (size_t)ctx->max_lds && G <= ctx->num_cu;
+    shape_ok = shape_ok && lds + 2048 <= (size_t)ctx->max_lds && G <= ctx->num_cu &&
+               (herm ? lpbc * nrow <= (kCoopLoads / 2) * kLineThreads : lpbc * F0 <= kCoopLoads * kLineThreads);
     if (!shape_ok) return EFGP_EUNSUPPORTED;
     const int cap = std::max(1, ctx->num_cu / G);                      // systems resident at once (one workgroup per CU)
     const int per = std::min(cap, nbatch);
@@ -1913,7 +2257,12 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
             // slabs give up at their first poll (the per-system iteration counts carry the -3 of the slab that died)
             EFGP_HIP_CHECK(hipMemsetAsync(scb + off_status, 0, 64, stream));
             hipError_t e;
-            if (G == 1 && ks == 8) e = launch(cg_coop2d_kernel<8, true>, nsys);
+            if (herm) {
+                if (G == 1 && ks == 8) e = launch(cg_coop2d_herm_kernel<8, true>, nsys);
+                else if (G == 1) e = launch(cg_coop2d_herm_kernel<4, true>, nsys);
+                else if (ks == 8) e = launch(cg_coop2d_herm_kernel<8, false>, nsys);
+                else e = launch(cg_coop2d_herm_kernel<4, false>, nsys);
+            } else if (G == 1 && ks == 8) e = launch(cg_coop2d_kernel<8, true>, nsys);
             else if (G == 1) e = launch(cg_coop2d_kernel<4, true>, nsys);
             else if (ks == 8) e = launch(cg_coop2d_kernel<8, false>, nsys);
             else e = launch(cg_coop2d_kernel<4, false>, nsys);
@@ -2356,7 +2705,7 @@ static int cg_solve_async_impl(efgp_toeplitz_t* op, const void* ws, double sigma
             DeviceGuard guard_c(op->device);
             if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * op->g.M, 2000000000);
             return coop_enqueue(op, ws, sigmasq, variant, precond_diag, b, x, nbatch, tol, max_iter, early_stop, batched_semantics,
-                                row_iters_dev, stream_c, nullptr, /*nan_on_dead*/ 1);
+                                row_iters_dev, stream_c, nullptr, /*nan_on_dead*/ 1, hermitian);
         }
         set_error("efgp_cg_solve_async: grid does not fit the persistent kernel");
         return EFGP_EUNSUPPORTED;

@@ -309,5 +309,17 @@ def test_async_solve_on_mid_size_grids():
     xs, its, rows = cg_solve(op, ws.cuda(), 0.5, 0, b.cuda(), torch.zeros_like(b).cuda(), 1e-9, diag=diag.cuda(), batched=True)
     assert int(lazy) == its and list(lazy.rows) == rows
     assert torch.equal(xa, xs)
+    # hermitian=True is a CONTRACT on these grids too since round 3 (cg_coop2d_herm_kernel): data that are not the transform of a
+    # real function are refused in the result (NaN, -2); conjugate-even data give the general solver's answer
     one = cg_solve_async(op, ws.cuda(), 0.5, 0, b[1].cuda(), torch.zeros_like(b[1]).cuda(), 1e-9, diag=diag.cuda(), batched=False, hermitian=True)
-    assert one is not None and _rel(one[0], xs[1]) < 1e-8           # hermitian is only a hint on these grids
+    assert one is not None and bool(torch.isnan(one[0].real).all())
+    with pytest.raises(RuntimeError, match="not the transform of real data"):
+        int(one[1])
+    wsq = ws.reshape(mtot, mtot)
+    ws_e = ((wsq + wsq.flip(0, 1)) / 2).reshape(-1)
+    bh = b[1].reshape(mtot, mtot)
+    bh = ((bh + bh.flip(0, 1).conj()) / 2).reshape(-1)
+    dg_e = 3.0 * L * ws_e.abs().pow(2).real + 0.5
+    xg, itg, _ = cg_solve(op, ws_e.cuda(), 0.5, 0, bh.cuda(), torch.zeros_like(bh).cuda(), 1e-9, diag=dg_e.cuda(), batched=False)
+    xh, lz = cg_solve_async(op, ws_e.cuda(), 0.5, 0, bh.cuda(), torch.zeros_like(bh).cuda(), 1e-9, diag=dg_e.cuda(), batched=False, hermitian=True)
+    assert abs(int(lz) - itg) <= 1 and _rel(xh, xg) < 1e-7
