@@ -962,6 +962,7 @@ struct CoopArgs {
     const double2* tw1;
     double2* b1;              // [systems][n0][F1]
     double2* b2;              // [systems][n0][F1]
+    double2* b3;              // [systems][n0][F1]  (Hermitian kernel: row transforms of the current direction)
     double* partial;          // [systems][3][kCoopMaxG]
     unsigned* bar;            // [systems] arrival counters, 64 bytes apart, zero at launch
     int* iters;               // [systems]
@@ -1323,6 +1324,15 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
 // ==========================================================================================================
 template <int KS, bool SOLO>
 __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a) {
+    long long st_prev = (long long)__builtin_readcyclecounter();   // EFGP_COOP_DBG=2: shader clock ticks per phase (workgroup 0, system 0)
+#define COOP_STAMP(slot_)                                                                     \
+    do {                                                                                      \
+        if (a.dbg == 2 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {           \
+            const long long now_ = (long long)__builtin_readcyclecounter();                   \
+            a.stamps[slot_] += (double)(now_ - st_prev);                                      \
+            st_prev = now_;                                                                   \
+        }                                                                                     \
+    } while (0)
     extern __shared__ double2 lsm[];
     __shared__ double red[kLineThreads / 64];
     __shared__ double fin[3 * kCoopMaxG];
@@ -1346,8 +1356,9 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
     const int cnt = nrows * n1;
     const int64_t base = (int64_t)sys * M;
     const int p_lo = wg * a.cols_wg;                          // first owned column pair
-    double2* b1 = a.b1 + (int64_t)sys * n0 * F1;
-    double2* b2 = a.b2 + (int64_t)sys * n0 * F1;
+    double2* b1 = a.b1 + (int64_t)sys * n0 * F1;              // row transforms of the vector just handed to phase R
+    double2* b2 = a.b2 + (int64_t)sys * n0 * F1;              // column phase output
+    double2* b3 = a.b3 + (int64_t)sys * n0 * F1;              // row transforms of ws .* p, carried from iteration to iteration
     double* part = a.partial + (int64_t)sys * 3 * kCoopMaxG;
     unsigned* bar = a.bar + (int64_t)sys * 16;
     unsigned epoch = 0;
@@ -1424,11 +1435,8 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
         v[1] = b1v;
         return true;
     };
-    auto apply = [&](const double2 (&u)[KS], double2 (&Au)[KS], double& uAu) __attribute__((always_inline)) -> bool {
-        double pp = 0.0, cs = 0.0;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) pp += wgt[s] * (u[s].x * u[s].x + u[s].y * u[s].y);
-        // R: owned rows k0 in passes of a.lines; mode k1 sits at position k1 mod F1
+    // R: row transforms of ws .* u for the owned rows k0 (mode k1 at position k1 mod F1) -> b1
+    auto phase_rows = [&](const double2 (&u)[KS]) __attribute__((always_inline)) {
         for (int p0 = 0; p0 < nrows; p0 += a.lines) {
             const int nl = min(a.lines, nrows - p0);
             for (int l = 0; l < nl; ++l)                                      // zeros between the two ends of the mode range
@@ -1444,16 +1452,22 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
             }
             __syncthreads();
         }
-        if (!sync_grid()) return false;
-        // C: owned column pairs (q, q + F1/2) in passes of a.lpbc lines
+    };
+    // C: owned column pairs (q, q + F1/2) in passes of a.lpbc lines.  mode 0: the columns of b1 as they are (operator on a given
+    // vector); 1: the same and b3 <- b1 (first direction); 2: b3 <- b1 + beta b3 first -- the row transform of ws .* p follows the
+    // direction's own recurrence p = z + beta p, so phase R could run on z BEFORE beta was known (see the iteration below).
+    auto phase_cols = [&](int mode, double beta, double& cs) __attribute__((always_inline)) {
         for (int c0 = p_lo; c0 < p_lo + a.cols_wg; c0 += a.lpbc) {
-            double2 ta[kCoopLoads / 2], tb[kCoopLoads / 2];
+            double2 ta[kCoopLoads / 2], tb[kCoopLoads / 2], tc[kCoopLoads / 2], td[kCoopLoads / 2];
 #pragma unroll
             for (int q = 0; q < kCoopLoads / 2; ++q) {                        // every load is issued before the first is used
                 const int w = tid + q * kLineThreads, l = w & (a.lpbc - 1), k0 = w >> lgC;
                 const bool in = k0 < nh;
-                ta[q] = in ? load_x2<SOLO>(b1 + (int64_t)k0 * F1 + c0 + l) : make_double2(0.0, 0.0);
-                tb[q] = in ? load_x2<SOLO>(b1 + (int64_t)k0 * F1 + c0 + l + halfF1) : make_double2(0.0, 0.0);
+                const int64_t o = (int64_t)k0 * F1 + c0 + l;
+                ta[q] = in ? load_x2<SOLO>(b1 + o) : make_double2(0.0, 0.0);
+                tb[q] = in ? load_x2<SOLO>(b1 + o + halfF1) : make_double2(0.0, 0.0);
+                tc[q] = (in && mode == 2) ? load_x2<SOLO>(b3 + o) : make_double2(0.0, 0.0);
+                td[q] = (in && mode == 2) ? load_x2<SOLO>(b3 + o + halfF1) : make_double2(0.0, 0.0);
             }
             for (int w = tid; w < a.lpbc * (F0 - 2 * h0 - 1); w += kLineThreads) {          // zeros between the two ends
                 const int l = w & (a.lpbc - 1), i0 = h0 + 1 + (w >> lgC);
@@ -1463,7 +1477,16 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
             for (int q = 0; q < kCoopLoads / 2; ++q) {
                 const int w = tid + q * kLineThreads, l = w & (a.lpbc - 1), k0 = w >> lgC;
                 if (k0 < nh) {
-                    const double2 ga = ta[q], gb = tb[q];
+                    double2 ga = ta[q], gb = tb[q];
+                    if (mode == 2) {
+                        ga = make_double2(ga.x + beta * tc[q].x, ga.y + beta * tc[q].y);
+                        gb = make_double2(gb.x + beta * td[q].x, gb.y + beta * td[q].y);
+                    }
+                    if (mode != 0) {
+                        const int64_t o = (int64_t)k0 * F1 + c0 + l;
+                        store_x2<SOLO>(b3 + o, ga);
+                        store_x2<SOLO>(b3 + o + halfF1, gb);
+                    }
                     if (k0 == 0) {
                         A[l * ldc] = make_double2(ga.x, gb.x);                                    // real part of line k0 = 0
                     } else {
@@ -1473,9 +1496,11 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
                 }
             }
             __syncthreads();
+            COOP_STAMP(4);
             double2* X = line_fft_fast_mul2(A, B, F0, ldc, a.lpbc, tw0s, a.vhat + c0, F1, halfF1, cs);
             double2* Y = X == A ? B : A;
             const double2* Z = line_fft_fast(X, Y, F0, ldc, a.lpbc, tw0s);    // Z = conj T (T = packed, halved result)
+            COOP_STAMP(5);
             for (int w = tid; w < (nh << lgC); w += kLineThreads) {
                 const int l = w & (a.lpbc - 1), k0 = w >> lgC;
                 const double2 zp = Z[l * ldc + k0], zm = Z[l * ldc + ((F0 - k0) & (F0 - 1))];
@@ -1484,13 +1509,11 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
                 store_x2<SOLO>(b2 + (int64_t)k0 * F1 + c0 + l + halfF1, make_double2(py + my, mx - px));   // (T - conj T(-)) / i
             }
             __syncthreads();
+            COOP_STAMP(6);
         }
-        {
-            double t3[3] = {a.variant == 0 ? a.sigmasq * pp + cs : pp + cs / a.sigmasq, 0.0, 0.0};
-            if (!all_sum(t3, 1, 2)) return false;
-            uAu = t3[0];
-        }
-        // Ri: owned rows k0
+    };
+    // Ri: inverse row transforms of b2 for the owned rows, crop, A u = ws .* (.) + sigma^2 u (or / sigma^2 + u)
+    auto phase_rows_inv = [&](const double2 (&u)[KS], double2 (&Au)[KS]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) Au[s] = make_double2(0.0, 0.0);
         for (int p0 = 0; p0 < nrows; p0 += a.lines) {
@@ -1507,6 +1530,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
                 if (w < (nl << lgF1)) A[(w >> lgF1) * ldr + (w & (F1 - 1))] = make_double2(tmp[q].x, -tmp[q].y);
             }
             __syncthreads();
+            COOP_STAMP(8);
             const double2* X = line_fft_fast(A, B, F1, ldr, nl, tw1s);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -1519,7 +1543,6 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
             }
             __syncthreads();
         }
-        return true;
     };
     auto fill_nan = [&]() {
 #pragma unroll
@@ -1555,28 +1578,69 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
         if (wg == 0 && tid == 0) a.iters[sys] = -2;
         return;
     }
+    // r_0 = b - A x_0: one plain operator application (R | barrier | C | barrier | Ri)
     double2 Ap[KS];
-    double uAu = 0.0;
-    if (!apply(xv, Ap, uAu)) return dead();
-    acc[0] = acc[1] = 0.0;
+    {
+        double cs = 0.0;
+        phase_rows(xv);
+        if (!sync_grid()) return dead();
+        phase_cols(0, 0.0, cs);
+        if (!sync_grid()) return dead();
+        phase_rows_inv(xv, Ap);
+    }
+    double2 zv[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        if (ok[s]) {
-            rv[s] = make_double2(bv[s].x - Ap[s].x, bv[s].y - Ap[s].y);
-            pv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
-            acc[0] += wgt[s] * (rv[s].x * pv[s].x + rv[s].y * pv[s].y);
-        }
+        rv[s] = ok[s] ? make_double2(bv[s].x - Ap[s].x, bv[s].y - Ap[s].y) : make_double2(0.0, 0.0);
+        zv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
     }
-    if (!all_sum(acc, 1, 0)) return dead();
-    double rz = acc[0];
     const double bn = sqrt(bb);
     const double den = bn > 0.0 ? bn : 1.0;
+    // Iteration with TWO grid barriers (the complex kernel needs three): the all-reduce of <r,r>, <r,z> rides on the barrier
+    // between the row and the column phase of the NEXT operator application.  That application needs p = z + beta p, and beta
+    // needs <r,z> -- but the row transform is linear: phase R transforms ws .* z while beta is unknown, and the column phase
+    // forms  rows(ws p) = rows(ws z) + beta rows(ws p_prev)  from the copy b3 it keeps of the previous direction's row
+    // transforms.  Same recurrences as cg.py:116-150, the direction's transform updated by the direction's own recurrence.
+    //   top of trip i: r_i, z_i local; p_{i-1}, <r,z>_{i-1} known; b3 = rows(ws p_{i-1})
+    double rz = 0.0;
     int it = 0;
-    for (; it < a.max_iter;) {
-        if (!apply(pv, Ap, uAu)) return dead();
-        const double alpha = rz / (uAu + kDivEps);
+    st_prev = (long long)__builtin_readcyclecounter();
+    for (;;) {
         acc[0] = acc[1] = 0.0;
-        double2 zv[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            acc[0] += wgt[s] * (rv[s].x * rv[s].x + rv[s].y * rv[s].y);
+            acc[1] += wgt[s] * (rv[s].x * zv[s].x + rv[s].y * zv[s].y);
+        }
+        COOP_STAMP(0);
+        phase_rows(zv);
+        COOP_STAMP(1);
+        if (!all_sum(acc, 2, 0)) return dead();                               // barrier 1: <r,r>, <r,z> of r_i
+        COOP_STAMP(2);
+        const double rnorm = sqrt(acc[0]), rzn = acc[1];
+        bool conv = false;
+        if (it > 0) {
+            if (a.hist && sys == 0 && wg == 0 && tid == 0 && it <= a.hist_cap) a.hist[it - 1] = rnorm / (den + kDivEps);
+            conv = a.early_stop && ((rnorm / (den + kDivEps) < a.tol) || (a.batched && rnorm < 1e-12));
+            if (conv) break;                                                  // cg.py:132 / :229-241 (p is not an output)
+        }
+        if (it >= a.max_iter) break;
+        const double beta = it > 0 ? rzn / (rz + kDivEps) : 0.0;
+        double pp = 0.0, cs = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            pv[s] = make_double2(zv[s].x + beta * pv[s].x, zv[s].y + beta * pv[s].y);
+            pp += wgt[s] * (pv[s].x * pv[s].x + pv[s].y * pv[s].y);
+        }
+        rz = rzn;
+        COOP_STAMP(3);
+        phase_cols(it > 0 ? 2 : 1, beta, cs);
+        double t3[3] = {a.variant == 0 ? a.sigmasq * pp + cs : pp + cs / a.sigmasq, 0.0, 0.0};
+        if (!all_sum(t3, 1, 2)) return dead();                                // barrier 2: <p, A p>
+        COOP_STAMP(7);
+        phase_rows_inv(pv, Ap);
+        COOP_STAMP(9);
+        const double alpha = rz / (t3[0] + kDivEps);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             xv[s].x += alpha * pv[s].x;
@@ -1584,20 +1648,8 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
             rv[s].x -= alpha * Ap[s].x;
             rv[s].y -= alpha * Ap[s].y;
             zv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
-            acc[0] += wgt[s] * (rv[s].x * rv[s].x + rv[s].y * rv[s].y);
-            acc[1] += wgt[s] * (rv[s].x * zv[s].x + rv[s].y * zv[s].y);
         }
-        if (!all_sum(acc, 2, 0)) return dead();
         ++it;
-        const double rnorm = sqrt(acc[0]), rzn = acc[1];
-        if (a.hist && sys == 0 && wg == 0 && tid == 0 && it <= a.hist_cap) a.hist[it - 1] = rnorm / (den + kDivEps);
-        const bool conv = a.early_stop && ((rnorm / (den + kDivEps) < a.tol) || (a.batched && rnorm < 1e-12));
-        if (!a.batched && conv) break;                            // cg.py:132
-        const double beta = rzn / (rz + kDivEps);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) pv[s] = make_double2(zv[s].x + beta * pv[s].x, zv[s].y + beta * pv[s].y);
-        rz = rzn;
-        if (conv) break;                                          // cg.py:229-241
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s)
@@ -1606,6 +1658,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
             if (r0 + lrow[s] > 0) a.x[base + M - 1 - tix[s]] = make_double2(xv[s].x, -xv[s].y);        // mode -k
         }
     if (wg == 0 && tid == 0) a.iters[sys] = it;
+#undef COOP_STAMP
 }
 
 // ==========================================================================================================
@@ -2155,6 +2208,7 @@ struct CoopInfo {
     int G = 0, rows_wg = 0, lines = 0, cols_wg = 0, per = 0;
     double* stamps = nullptr;
     int dbg = 0;
+    bool herm = false;
 };
 static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int variant, const double* precond_diag, const void* b,
                         void* x, int nbatch, double tol, int max_iter, int early_stop, int batched_semantics, int* d_iters,
@@ -2169,6 +2223,7 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     // workgroups per system: as many as the latency shape uses (16 / 32 / 64) while the whole batch stays resident (one
     // workgroup per CU), never fewer than the registers need (8 vector entries per thread)
     int G_lat = F1 / 8;      // 16 / 32 / 64 (measured at 128^2: 19.9 us per iteration with 16 workgroups, 22.7 with 32, 20.6 with 8)
+    if (herm && F1 <= 256) G_lat = F1 / 16;   // half the work per system: 8 / 16 workgroups measured best at 128^2 / 256^2, 64 at 512^2
     if (const char* eg = std::getenv("EFGP_COOP_G")) G_lat = std::max(1, std::min(G_lat, std::atoi(eg)));   // experiments
     int G_min = 1;
     while (G_min < G_lat && ((nrow + G_min - 1) / G_min) * n1 > 8 * kLineThreads) G_min <<= 1;
@@ -2197,7 +2252,7 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     const int cap = std::max(1, ctx->num_cu / G);                      // systems resident at once (one workgroup per CU)
     const int per = std::min(cap, nbatch);
     const size_t grid_elems = (size_t)per * (size_t)n0 * (size_t)F1;
-    double2* pad = (double2*)scratch(ctx, SLOT_TOEP_PAD, 2 * grid_elems * sizeof(double2));
+    double2* pad = (double2*)scratch(ctx, SLOT_TOEP_PAD, 3 * grid_elems * sizeof(double2));
     // partial sums | arrival counters (64 B apart) | status
     const size_t off_bar = (size_t)per * 3 * kCoopMaxG * sizeof(double);
     const size_t off_status = off_bar + (size_t)per * 64;
@@ -2219,6 +2274,7 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     ca.tw1 = op->tw[1];
     ca.b1 = pad;
     ca.b2 = pad + grid_elems;
+    ca.b3 = pad + 2 * grid_elems;
     ca.partial = (double*)scb;
     ca.bar = (unsigned*)(scb + off_bar);
     ca.status = (int*)(scb + off_status);
@@ -2277,7 +2333,21 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
         info->cols_wg = cols_wg;
         info->per = per;
         info->stamps = ca.stamps;
+        info->herm = herm;
         info->dbg = ca.dbg;
+    }
+    if (herm && ca.dbg == 2) {          // diagnostic run (EFGP_COOP_DBG=2): wait and print the phase shares of workgroup 0, system 0
+        double hs[12];
+        int it0 = 0;
+        EFGP_HIP_CHECK(stream_wait(stream));
+        EFGP_HIP_CHECK(hipMemcpy(hs, ca.stamps, sizeof(hs), hipMemcpyDeviceToHost));
+        EFGP_HIP_CHECK(hipMemcpy(&it0, d_iters, sizeof(int), hipMemcpyDeviceToHost));
+        const char* nm[10] = {"partial <r,r>, <r,z>", "R: rows of ws z -> b1", "barrier 1 + all-reduce", "beta, p update", "C: loads b1/b3, assemble",
+                              "C: transform, spectrum, transform", "C: unpack, stores to b2", "barrier 2 + all-reduce", "Ri: loads of b2", "Ri: transform, A p, x r z"};
+        double tot = 0;
+        for (int q = 0; q < 10; ++q) tot += hs[q];
+        std::fprintf(stderr, "[coop-herm] G = %d, rows/wg %d, lines/pass %d, column pairs/wg %d, systems/launch %d, %d iterations\n", G, rows_wg, lines, cols_wg, per, it0);
+        for (int q = 0; q < 10; ++q) std::fprintf(stderr, "[coop-herm] %-36s %9.0f ticks/iter %5.1f%%\n", nm[q], hs[q] / std::max(1, it0), 100.0 * hs[q] / tot);
     }
     return EFGP_OK;
 }
