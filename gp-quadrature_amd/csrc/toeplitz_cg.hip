@@ -197,6 +197,10 @@ struct CgArgs {
     int nblk;                 // workgroups per system
     double* hist;             // diagnostic: row 0's |r_i| / |b| per iteration (efgp_cg_record_history) or null
     int hist_cap;
+    // the part of every vector the update kernels walk: [v_off, v_off + v_len) of the M entries; entries below v_off + v_w1
+    // count once in the dot products, the others twice.  General systems: (0, M, M).  Hermitian 3-D systems (round 3): the
+    // planes k0 >= 0 -- (h0 n1 n2, (h0 + 1) n1 n2, n1 n2): plane k0 = 0 once, every other plane for itself and its mirror image.
+    int64_t v_off, v_len, v_w1;
 };
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -228,24 +232,32 @@ __device__ __forceinline__ double2 apply_A(const CgArgs& a, double2 wst, double2
 __device__ __forceinline__ double load_agent(const double* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // bypasses this CU's L1
 }
-// returns true in every thread of the LAST workgroup of `row` to arrive at counter `which`
-__device__ __forceinline__ bool arrive_last(const CgArgs& a, int row, int which, int* flag) {
-    __threadfence();
-    __syncthreads();
+__device__ __forceinline__ void store_agent(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // write-through, leaves no dirty L2 line behind
+}
+// Arrival at a reduction: returns true in every thread of the LAST of `nblk` workgroups to arrive at `counter`.
+// Thread 0 has stored this workgroup's partial sums with store_agent; it drains them (s_waitcnt vmcnt(0)) before its arrival,
+// and the last arriver reads all partials with load_agent (L1-bypassing): the hand-off form R1 of MI355X_MICROARCH.md, no
+// fence.  Round 3: the __threadfence() pair that stood here cost EVERY workgroup an L2 write-back, serialised per XCD --
+// 15-18 of cg3_inv2_kernel's 23 us at 207 workgroups, ~9 of cg_axpy_kernel's 14 us at 64.  Everything else these kernels write
+// is read by later launches only (kernel boundary).
+__device__ __forceinline__ bool arrive_count(int* counter, int nblk, int* flag) {
     if (threadIdx.x == 0) {
-        const int prev = atomicAdd(&a.counter[2 * row + which], 1);
-        *flag = prev == a.nblk - 1;
-        if (*flag) a.counter[2 * row + which] = 0;       // all arrivals of this iteration are in
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = prev == nblk - 1;
+        if (*flag) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // all arrivals of this launch are in
     }
     __syncthreads();
-    const bool last = *flag != 0;
-    if (last) __threadfence();
-    return last;
+    return *flag != 0;
+}
+__device__ __forceinline__ bool arrive_last(const CgArgs& a, int row, int which, int* flag) {
+    return arrive_count(&a.counter[2 * row + which], a.nblk, flag);
 }
 __device__ __forceinline__ void block_range(const CgArgs& a, int64_t& lo, int64_t& hi) {
-    const int64_t per = (a.g.M + a.nblk - 1) / a.nblk;
-    lo = (int64_t)blockIdx.x * per;
-    hi = lo + per < a.g.M ? lo + per : a.g.M;
+    const int64_t per = (a.v_len + a.nblk - 1) / a.nblk, end = a.v_off + a.v_len;
+    lo = a.v_off + (int64_t)blockIdx.x * per;
+    hi = lo + per < end ? lo + per : end;
 }
 
 // r = b - A x0, z = r/diag, p = z, rz = <r,z>, den = |b| (cg.py:94-111 / :164-186).  grid = (nblk, rows): round 3 -- with ONE
@@ -281,8 +293,8 @@ __global__ __launch_bounds__(kVecThreads) void cg_init_kernel(CgArgs a) {
     bb = block_sum(bb, red);
     double* part = a.partial + (int64_t)row * 3 * kCgBlocksMax;
     if (threadIdx.x == 0) {
-        part[kCgBlocksMax + blockIdx.x] = rz;
-        part[2 * kCgBlocksMax + blockIdx.x] = bb;
+        store_agent(&part[kCgBlocksMax + blockIdx.x], rz);
+        store_agent(&part[2 * kCgBlocksMax + blockIdx.x], bb);
     }
     if (!arrive_last(a, row, 1, &flag)) return;
     __shared__ double fin[2 * kCgBlocksMax];
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(kVecThreads) void cg_dot_kernel(CgArgs a) {
     }
     pAp = block_sum(pAp, red);
     double* part = a.partial + (int64_t)row * 3 * kCgBlocksMax;
-    if (threadIdx.x == 0) part[blockIdx.x] = pAp;
+    if (threadIdx.x == 0) store_agent(&part[blockIdx.x], pAp);
     if (arrive_last(a, row, 0, &flag)) {
         __shared__ double fin[kCgBlocksMax];
         if (threadIdx.x < a.nblk) fin[threadIdx.x] = load_agent(&part[threadIdx.x]);     // loads in parallel
@@ -406,7 +418,7 @@ __global__ __launch_bounds__(kVecThreads) void cg_axpy_kernel(CgArgs a) {
         rv.y -= alpha * Ap.y;
         a.x[base + t] = xv;
         a.r[base + t] = rv;
-        const double q = rv.x * rv.x + rv.y * rv.y;
+        const double q = (t - a.v_off < a.v_w1 ? 1.0 : 2.0) * (rv.x * rv.x + rv.y * rv.y);
         rr += q;
         rz_new += a.diag ? q / a.diag[t] : q;
     }
@@ -414,8 +426,8 @@ __global__ __launch_bounds__(kVecThreads) void cg_axpy_kernel(CgArgs a) {
     rz_new = block_sum(rz_new, red);
     double* part = a.partial + (int64_t)row * 3 * kCgBlocksMax;
     if (threadIdx.x == 0) {
-        part[kCgBlocksMax + blockIdx.x] = rr;
-        part[2 * kCgBlocksMax + blockIdx.x] = rz_new;
+        store_agent(&part[kCgBlocksMax + blockIdx.x], rr);
+        store_agent(&part[2 * kCgBlocksMax + blockIdx.x], rz_new);
     }
     if (!arrive_last(a, row, 1, &flag)) return;
     __shared__ double fin[2 * kCgBlocksMax];
@@ -592,6 +604,7 @@ __device__ __forceinline__ void wave_sync_lds() {
 // MUL = 2 (round 3, Hermitian cooperative solve): line l carries TWO real columns as real and imaginary part; they are
 // multiplied by the REAL spectra Re mul[k * mul_stride + l] and Re mul[k * mul_stride + l + mul_pair], halved (the unpacking
 // behind the inverse transform adds two terms) and conjugated; the return value is sum S_a re^2 + S_b im^2.
+// MUL = 3: the same with `mul` pointing at an array of REAL spectrum values (3-D Hermitian iteration: half the bytes).
 template <int R, int MUL = 0>
 __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, int ld, int nl, const double2* tw,
                                                   const double2* __restrict__ mul = nullptr, int64_t mul_stride = 0,
@@ -625,12 +638,17 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
                 const int lq = act ? l0 + lsub : l0;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    mv[t] = mul[(int64_t)(j + 8 * t) * mul_stride + lq];
-                    if (MUL == 2) mv[t].y = mul[(int64_t)(j + 8 * t) * mul_stride + lq + mul_pair].x;
+                    if (MUL == 3) {
+                        const double* rs = reinterpret_cast<const double*>(mul);
+                        mv[t] = make_double2(rs[(int64_t)(j + 8 * t) * mul_stride + lq], rs[(int64_t)(j + 8 * t) * mul_stride + lq + mul_pair]);
+                    } else {
+                        mv[t] = mul[(int64_t)(j + 8 * t) * mul_stride + lq];
+                        if (MUL == 2) mv[t].y = mul[(int64_t)(j + 8 * t) * mul_stride + lq + mul_pair].x;
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    if (MUL == 2) {
+                    if (MUL >= 2) {
                         if (act) psum += mv[t].x * v[t].x * v[t].x + mv[t].y * v[t].y * v[t].y;
                         v[t] = make_double2(0.5 * mv[t].x * v[t].x, -0.5 * mv[t].y * v[t].y);
                     } else {
@@ -663,8 +681,14 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int q = 0; q < R; ++q) {
-                    mv[u * R + q] = mul[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq];
-                    if (MUL == 2) mv[u * R + q].y = mul[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq + mul_pair].x;
+                    if (MUL == 3) {
+                        const double* rs = reinterpret_cast<const double*>(mul);
+                        mv[u * R + q] = make_double2(rs[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq],
+                                                     rs[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq + mul_pair]);
+                    } else {
+                        mv[u * R + q] = mul[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq];
+                        if (MUL == 2) mv[u * R + q].y = mul[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq + mul_pair].x;
+                    }
                 }
         }
 #pragma unroll
@@ -695,7 +719,7 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
         if (MUL) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (MUL == 2) {
+                if (MUL >= 2) {
                     if (act) psum += mv[i].x * v[i].x * v[i].x + mv[i].y * v[i].y * v[i].y;
                     v[i] = make_double2(0.5 * mv[i].x * v[i].x, -0.5 * mv[i].y * v[i].y);
                 } else {
@@ -753,6 +777,17 @@ __device__ __forceinline__ double2* line_fft_fast_mul2(double2* src, double2* ds
     if (F == 128) psum += line_fft_inwave_call<2, 2>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
     else if (F == 256) psum += line_fft_inwave_call<4, 2>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
     else psum += line_fft_inwave_call<8, 2>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
+    return dst;
+}
+// two real columns per line, spectra given as a REAL array (MUL = 3)
+__device__ __forceinline__ double2* line_fft_fast_mul3(double2* src, double2* dst, int F, int ld, int nl, const double2* tw,
+                                                       const double* spec, int64_t stride, int64_t pair) {
+    const int so = (int)(src - efgp_line_lds), dn = (int)(dst - efgp_line_lds), to = (int)(tw - efgp_line_lds);
+    const double2* mul = reinterpret_cast<const double2*>(spec);
+    if (F == 64) line_fft_inwave_call<1, 3>(so, dn, ld, nl, to, mul, stride, pair);
+    else if (F == 128) line_fft_inwave_call<2, 3>(so, dn, ld, nl, to, mul, stride, pair);
+    else if (F == 256) line_fft_inwave_call<4, 3>(so, dn, ld, nl, to, mul, stride, pair);
+    else line_fft_inwave_call<8, 3>(so, dn, ld, nl, to, mul, stride, pair);
     return dst;
 }
 // in-wave transform for the lengths it covers, the generic Stockham stages otherwise; the result buffer is returned
@@ -896,18 +931,8 @@ __global__ __launch_bounds__(kLineThreads) void cg_rows_inv_kernel(LineArgs a) {
     }
     pAp = block_sum(pAp, red);
     double* part = c.partial + (int64_t)row * 3 * kCgBlocksMax;
-    if (threadIdx.x == 0) part[blockIdx.x] = pAp;
-    // arrival counter 0 with this kernel's own block count
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int prev = atomicAdd(&c.counter[2 * row], 1);
-        flag = prev == a.nblk_rows - 1;
-        if (flag) c.counter[2 * row] = 0;
-    }
-    __syncthreads();
-    if (!flag) return;
-    __threadfence();
+    if (threadIdx.x == 0) store_agent(&part[blockIdx.x], pAp);
+    if (!arrive_count(&c.counter[2 * row], a.nblk_rows, &flag)) return;      // arrival counter 0 with this kernel's own block count
     __shared__ double fin[kCgBlocksMax];
     if (threadIdx.x < a.nblk_rows) fin[threadIdx.x] = load_agent(&part[threadIdx.x]);
     __syncthreads();
@@ -1851,17 +1876,8 @@ __global__ __launch_bounds__(kLineThreads) void cg3_inv2_kernel(Line3Args a) {
     }
     pAp = block_sum(pAp, red);
     double* part = c.partial + (int64_t)row * 3 * kCgBlocksMax;
-    if (threadIdx.x == 0) part[blockIdx.x] = pAp;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int prev = atomicAdd(&c.counter[2 * row], 1);
-        flag = prev == a.nblk_lines - 1;
-        if (flag) c.counter[2 * row] = 0;
-    }
-    __syncthreads();
-    if (!flag) return;
-    __threadfence();
+    if (threadIdx.x == 0) store_agent(&part[blockIdx.x], pAp);
+    if (!arrive_count(&c.counter[2 * row], a.nblk_lines, &flag)) return;
     __shared__ double fin[kCgBlocksMax];
     if (threadIdx.x < a.nblk_lines) fin[threadIdx.x] = load_agent(&part[threadIdx.x]);
     __syncthreads();
@@ -1870,6 +1886,291 @@ __global__ __launch_bounds__(kLineThreads) void cg3_inv2_kernel(Line3Args a) {
         for (int i = 0; i < a.nblk_lines; ++i) t += fin[i];
         c.sc[row].pAp = t + kDivEps;
     }
+}
+
+// ==========================================================================================================
+// Round 3: the 3-D line iteration for HERMITIAN systems (vectors = Fourier coefficients of real functions on the symmetric mode
+// box, ws real and even, Toeplitz vector Hermitian -- every system EFGP solves: efgpnd.py:119-141, 192-206, 926-941).
+//   u[-k] = conj u[k]: only the planes k0 = 0..h0 are carried ((h0 + 1) n1 n2 of the M entries, the upper half of the flat
+//   vector).  Modes sit CENTRED on the torus (k at k mod F), which makes the spectrum of the (Hermitian) Toeplitz vector real:
+//   vc = Re(vhat e^(2 pi i sum f_a (n_a - 1) / F_a)), stored as doubles.
+//     fwd2 / dim1<0> : as above on the (h0 + 1) planes: half the lines
+//     mid0           : the k0-sequence of a column (t1, t2) is Hermitian, its transform real: TWO columns (t2, t2 + F2/2) ride
+//                      through one complex transform as real and imaginary part (line_fft_inwave<R, 3>), are multiplied by
+//                      their real spectra and come back through the second transform; unpacked as T + conj T(-) and
+//                      (T - conj T(-)) / i.  Plane k0 = 0 keeps its real part only (projection on the Hermitian subspace:
+//                      without it rounding noise in that plane is fed back, cf. cg_herm64_kernel).
+//     dim1<1> / inv2 : back on the (h0 + 1) planes; <p, A p> counts plane 0 once and the others twice
+//   Per operator application at mtot = 57 (F = 128): 66 MB through HBM/L2 instead of 150 MB (the spectrum alone 33.5 -> 16.8 MB).
+// ==========================================================================================================
+struct Line3HArgs {
+    CgArgs c;
+    const double* vc;         // [F0][F1][F2] real centred spectrum, already divided by F0*F1*F2
+    const double2* tw[3];
+    double2* b1;              // [slots][(h0+1) n1][F2]
+    double2* b2;              // [slots][h0+1][F1][F2]
+    int lpb_c;                // lines per workgroup, contiguous kernels (fwd2, inv2)
+    int lpb_s;                // adjacent t2 columns per workgroup, dim-1 kernels
+    int lpb_m;                // column pairs per workgroup, mid0
+    int nblk_lines;           // workgroups of inv2 per system
+};
+// torus position -> index into the centred mode range of n = 2h+1 (or -1)
+__device__ __forceinline__ int centred_index(int pos, int h, int F) { return pos <= h ? pos + h : (pos >= F - h ? pos - (F - h) : -1); }
+
+__global__ __launch_bounds__(kLineThreads) void cg3h_fwd2_kernel(Line3HArgs a) {
+    extern __shared__ double2 lsm[];
+    const CgArgs& c = a.c;
+    const int slot = blockIdx.y;
+    const int row = c.rows ? c.rows[slot] : slot;
+    if (row < 0) return;
+    const CgRowScalars sc = c.sc[row];
+    if (!sc.active) return;
+    const int n0 = (int)c.g.n[0], n1 = (int)c.g.n[1], n2 = (int)c.g.n[2], F2 = (int)c.g.F[2], ld = F2 + 1;
+    const int h2 = (n2 - 1) / 2, lgF2 = ilog2(F2);
+    const int nlines = ((n0 + 1) / 2) * n1;
+    const int l0 = blockIdx.x * a.lpb_c;
+    const int nl = min(a.lpb_c, nlines - l0);
+    double2* A = lsm;
+    double2* B = lsm + a.lpb_c * ld;
+    double2* tws = B + a.lpb_c * ld;
+    load_twiddles(tws, a.tw[2], F2);
+    const int64_t base = (int64_t)row * c.g.M;
+    for (int w = threadIdx.x; w < (nl << lgF2); w += kLineThreads) {
+        const int l = w >> lgF2, pos = w & (F2 - 1);
+        const int i2 = centred_index(pos, h2, F2);
+        double2 v = make_double2(0.0, 0.0);
+        if (i2 >= 0) {
+            const int64_t t = c.v_off + (int64_t)(l0 + l) * n2 + i2;
+            double2 pv = c.p[base + t];
+            if (sc.do_p) {                                       // deferred p <- r/diag + beta p
+                double2 zv = c.r[base + t];
+                if (c.diag) {
+                    zv.x /= c.diag[t];
+                    zv.y /= c.diag[t];
+                }
+                pv = make_double2(zv.x + sc.beta * pv.x, zv.y + sc.beta * pv.y);
+                c.p[base + t] = pv;
+            }
+            const double wr = c.ws[t].x;
+            v = make_double2(wr * pv.x, wr * pv.y);
+        }
+        A[l * ld + pos] = v;
+    }
+    __syncthreads();
+    const double2* X = line_fft_any(A, B, F2, ld, nl, tws);
+    double2* out = a.b1 + ((int64_t)slot * nlines + l0) * F2;
+    for (int w = threadIdx.x; w < (nl << lgF2); w += kLineThreads) {
+        const int l = w >> lgF2, i2 = w & (F2 - 1);
+        out[(int64_t)l * F2 + i2] = X[l * ld + i2];
+    }
+}
+
+// MODE 0: forward along dim 1 (b1 -> b2);  MODE 1: inverse along dim 1 with crop (b2 -> b1); planes k0 = 0..h0
+template <int MODE>
+__global__ __launch_bounds__(kLineThreads) void cg3h_dim1_kernel(Line3HArgs a) {
+    extern __shared__ double2 lsm[];
+    const CgArgs& c = a.c;
+    const int slot = blockIdx.y;
+    const int row = c.rows ? c.rows[slot] : slot;
+    if (row < 0) return;
+    if (!c.sc[row].active) return;
+    const int n0 = (int)c.g.n[0], n1 = (int)c.g.n[1], F1 = (int)c.g.F[1], F2 = (int)c.g.F[2], ld = F1 + 1;
+    const int nh = (n0 + 1) / 2, h1 = (n1 - 1) / 2;
+    const int L = a.lpb_s, lgL = ilog2(L);
+    const int groups = F2 / L;
+    const int k0 = blockIdx.x / groups, c0 = (blockIdx.x - k0 * groups) * L;
+    double2* A = lsm;
+    double2* B = lsm + L * ld;
+    double2* tws = B + L * ld;
+    load_twiddles(tws, a.tw[1], F1);
+    double2* b1 = a.b1 + (int64_t)slot * nh * n1 * F2;
+    double2* b2 = a.b2 + (int64_t)slot * nh * F1 * F2;
+    if (MODE == 0) {
+        for (int w = threadIdx.x; w < (F1 << lgL); w += kLineThreads) {
+            const int pos = w >> lgL, l = w & (L - 1);
+            const int i1 = centred_index(pos, h1, F1);
+            A[l * ld + pos] = i1 >= 0 ? b1[((int64_t)k0 * n1 + i1) * F2 + c0 + l] : make_double2(0.0, 0.0);
+        }
+    } else {
+        for (int w = threadIdx.x; w < (F1 << lgL); w += kLineThreads) {
+            const int t1 = w >> lgL, l = w & (L - 1);
+            const double2 v = b2[((int64_t)k0 * F1 + t1) * F2 + c0 + l];
+            A[l * ld + t1] = make_double2(v.x, -v.y);
+        }
+    }
+    __syncthreads();
+    const double2* X = line_fft_any(A, B, F1, ld, L, tws);
+    if (MODE == 0) {
+        for (int w = threadIdx.x; w < (F1 << lgL); w += kLineThreads) {
+            const int t1 = w >> lgL, l = w & (L - 1);
+            b2[((int64_t)k0 * F1 + t1) * F2 + c0 + l] = X[l * ld + t1];
+        }
+    } else {
+        for (int w = threadIdx.x; w < (n1 << lgL); w += kLineThreads) {
+            const int i1 = w >> lgL, l = w & (L - 1);
+            const double2 z = X[l * ld + ((i1 - h1) & (F1 - 1))];
+            b1[((int64_t)k0 * n1 + i1) * F2 + c0 + l] = make_double2(z.x, -z.y);
+        }
+    }
+}
+
+// per (t1, group of L column pairs (c, c + F2/2)): packed transform along dim 0, real spectra, back, in place in b2
+__global__ __launch_bounds__(kLineThreads) void cg3h_mid0_kernel(Line3HArgs a) {
+    extern __shared__ double2 lsm[];
+    const CgArgs& c = a.c;
+    const int slot = blockIdx.y;
+    const int row = c.rows ? c.rows[slot] : slot;
+    if (row < 0) return;
+    if (!c.sc[row].active) return;
+    const int n0 = (int)c.g.n[0], F0 = (int)c.g.F[0], F1 = (int)c.g.F[1], F2 = (int)c.g.F[2], ld = F0 + 1;
+    const int nh = (n0 + 1) / 2, h0 = nh - 1, halfF2 = F2 >> 1;
+    const int L = a.lpb_m, lgL = ilog2(L);
+    const int groups = halfF2 / L;
+    const int t1 = blockIdx.x / groups, c0 = (blockIdx.x - t1 * groups) * L;
+    double2* A = lsm;
+    double2* B = lsm + L * ld;
+    double2* tws = B + L * ld;
+    load_twiddles(tws, a.tw[0], F0);
+    double2* b2 = a.b2 + (int64_t)slot * nh * F1 * F2;
+    for (int w = threadIdx.x; w < ((F0 - 2 * h0 - 1) << lgL); w += kLineThreads) {           // zeros between the two ends
+        const int l = w & (L - 1), i0 = h0 + 1 + (w >> lgL);
+        A[l * ld + i0] = make_double2(0.0, 0.0);
+    }
+    for (int w = threadIdx.x; w < (nh << lgL); w += kLineThreads) {
+        const int k0 = w >> lgL, l = w & (L - 1);
+        const int64_t o = ((int64_t)k0 * F1 + t1) * F2 + c0 + l;
+        const double2 ga = b2[o], gb = b2[o + halfF2];
+        if (k0 == 0) {
+            A[l * ld] = make_double2(ga.x, gb.x);                                       // real part of plane k0 = 0
+        } else {
+            A[l * ld + k0] = make_double2(ga.x - gb.y, ga.y + gb.x);                    // G_a + i G_b
+            A[l * ld + F0 - k0] = make_double2(ga.x + gb.y, gb.x - ga.y);               // conj G_a + i conj G_b
+        }
+    }
+    __syncthreads();
+    double2* X;
+    if (F0 == 64 || F0 == 128 || F0 == 256 || F0 == 512) {
+        X = line_fft_fast_mul3(A, B, F0, ld, L, tws, a.vc + (int64_t)t1 * F2 + c0, (int64_t)F1 * F2, halfF2);
+    } else {
+        X = line_fft(A, B, F0, ld, L, tws);
+        for (int w = threadIdx.x; w < (F0 << lgL); w += kLineThreads) {
+            const int t0 = w >> lgL, l = w & (L - 1);
+            const int64_t o = ((int64_t)t0 * F1 + t1) * F2 + c0 + l;
+            const double2 v = X[l * ld + t0];
+            X[l * ld + t0] = make_double2(0.5 * a.vc[o] * v.x, -0.5 * a.vc[o + halfF2] * v.y);
+        }
+        __syncthreads();
+    }
+    double2* Y = X == A ? B : A;
+    const double2* Z = line_fft_any(X, Y, F0, ld, L, tws);                              // Z = conj T (T = packed, halved result)
+    for (int w = threadIdx.x; w < (nh << lgL); w += kLineThreads) {
+        const int k0 = w >> lgL, l = w & (L - 1);
+        const double2 zp = Z[l * ld + k0], zm = Z[l * ld + ((F0 - k0) & (F0 - 1))];
+        const double px = zp.x, py = -zp.y, mx = zm.x, my = -zm.y;                      // T[k0], T[-k0]
+        const int64_t o = ((int64_t)k0 * F1 + t1) * F2 + c0 + l;
+        b2[o] = make_double2(px + mx, py - my);                                         // T + conj T(-)
+        b2[o + halfF2] = make_double2(py + my, mx - px);                                // (T - conj T(-)) / i
+    }
+}
+
+__global__ __launch_bounds__(kLineThreads) void cg3h_inv2_kernel(Line3HArgs a) {
+    extern __shared__ double2 lsm[];
+    __shared__ double red[kLineThreads / 64];
+    __shared__ int flag;
+    const CgArgs& c = a.c;
+    const int slot = blockIdx.y;
+    const int row = c.rows ? c.rows[slot] : slot;
+    if (row < 0) return;
+    if (!c.sc[row].active) return;
+    const int n0 = (int)c.g.n[0], n1 = (int)c.g.n[1], n2 = (int)c.g.n[2], F2 = (int)c.g.F[2], ld = F2 + 1;
+    const int h2 = (n2 - 1) / 2, lgF2 = ilog2(F2);
+    const int nlines = ((n0 + 1) / 2) * n1;
+    const int l0 = blockIdx.x * a.lpb_c;
+    const int nl = min(a.lpb_c, nlines - l0);
+    double2* A = lsm;
+    double2* B = lsm + a.lpb_c * ld;
+    double2* tws = B + a.lpb_c * ld;
+    load_twiddles(tws, a.tw[2], F2);
+    const double2* in = a.b1 + ((int64_t)slot * nlines + l0) * F2;
+    for (int w = threadIdx.x; w < (nl << lgF2); w += kLineThreads) {
+        const int l = w >> lgF2, i2 = w & (F2 - 1);
+        const double2 v = in[(int64_t)l * F2 + i2];
+        A[l * ld + i2] = make_double2(v.x, -v.y);
+    }
+    __syncthreads();
+    const double2* X = line_fft_any(A, B, F2, ld, nl, tws);
+    const int64_t base = (int64_t)row * c.g.M;
+    double pAp = 0.0;
+    for (int w = threadIdx.x; w < nl * n2; w += kLineThreads) {
+        const int l = w / n2, i2 = w - l * n2;
+        const int64_t t = c.v_off + (int64_t)(l0 + l) * n2 + i2;
+        const double2 z = X[l * ld + ((i2 - h2) & (F2 - 1))];
+        const double2 pv = c.p[base + t];
+        const double2 Ap = apply_A(c, make_double2(c.ws[t].x, 0.0), make_double2(z.x, -z.y), pv);
+        c.ap[base + t] = Ap;
+        pAp += (l0 + l < n1 ? 1.0 : 2.0) * (pv.x * Ap.x + pv.y * Ap.y);                 // plane k0 = 0 once, the others twice
+    }
+    pAp = block_sum(pAp, red);
+    double* part = c.partial + (int64_t)row * 3 * kCgBlocksMax;
+    if (threadIdx.x == 0) store_agent(&part[blockIdx.x], pAp);
+    if (!arrive_count(&c.counter[2 * row], a.nblk_lines, &flag)) return;
+    __shared__ double fin[kCgBlocksMax];
+    if (threadIdx.x < a.nblk_lines) fin[threadIdx.x] = load_agent(&part[threadIdx.x]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < a.nblk_lines; ++i) t += fin[i];
+        c.sc[row].pAp = t + kDivEps;
+    }
+}
+
+// x[-k] = conj x[k] for the planes k0 > 0 (the iteration carried k0 >= 0 only)
+__global__ __launch_bounds__(kVecThreads) void cg3h_mirror_kernel(CgArgs a) {
+    const int row = blockIdx.y;
+    double2* x = a.x + (int64_t)row * a.g.M;
+    for (int64_t e = a.v_w1 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < a.v_len; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = a.v_off + e;
+        const double2 v = x[t];
+        x[a.g.M - 1 - t] = make_double2(v.x, -v.y);
+    }
+}
+
+// the contract of the Hermitian iteration, checked on the data: out[0] = sum |b[t] - conj b[M-1-t]|^2 + |x0[t] - conj x0[M-1-t]|^2,
+// out[1] = sum |b|^2 + |x0|^2 over all rows, out[2] = sum over t of (Im ws)^2 + (ws[t] - ws[M-1-t])^2
+__global__ __launch_bounds__(kVecThreads) void cg_herm_check_kernel(const double2* __restrict__ b, const double2* __restrict__ x0,
+                                                                    const double2* __restrict__ ws, int64_t M, int rows, double* out) {
+    __shared__ double red[kVecThreads / 64];
+    double viol = 0.0, bb = 0.0, wbad = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)rows * M; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / M, t = i - r * M;
+        const double2 u = b[i], um = b[r * M + M - 1 - t], y = x0[i], ym = x0[r * M + M - 1 - t];
+        viol += (u.x - um.x) * (u.x - um.x) + (u.y + um.y) * (u.y + um.y) + (y.x - ym.x) * (y.x - ym.x) + (y.y + ym.y) * (y.y + ym.y);
+        bb += u.x * u.x + u.y * u.y + y.x * y.x + y.y * y.y;
+        if (r == 0) {
+            const double2 w = ws[t], wm = ws[M - 1 - t];
+            wbad += w.y * w.y + (w.x - wm.x) * (w.x - wm.x);
+        }
+    }
+    viol = block_sum(viol, red);
+    bb = block_sum(bb, red);
+    wbad = block_sum(wbad, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[0], viol);
+        atomicAdd(&out[1], bb);
+        atomicAdd(&out[2], wbad);
+    }
+}
+
+// vc[f] = Re(vhat[f] e^(2 pi i sum_a f_a (n_a - 1) / F_a)): the real spectrum of the Hermitian Toeplitz vector with its lags centred
+__global__ __launch_bounds__(256) void center_spectrum3_real_kernel(const double2* __restrict__ vhat, const double2* __restrict__ tw0,
+                                                                    const double2* __restrict__ tw1, const double2* __restrict__ tw2,
+                                                                    int n0, int n1, int n2, int F0, int F1, int F2, double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)F0 * F1 * F2) return;
+    const int f2 = (int)(t % F2), f1 = (int)((t / F2) % F1), f0 = (int)(t / ((int64_t)F1 * F2));
+    const double2 a = tw0[((int64_t)(n0 - 1) * f0) & (F0 - 1)], b = tw1[((int64_t)(n1 - 1) * f1) & (F1 - 1)], cc = tw2[((int64_t)(n2 - 1) * f2) & (F2 - 1)];
+    const double2 ab = cmul(a, b), abc = cmul(ab, cc);
+    out[t] = cmul(vhat[t], make_double2(abc.x, -abc.y)).x;
 }
 
 // vhat_c[f] = vhat[f] e^(2 pi i (f0 (n0-1)/F0 + f1 (n1-1)/F1)): the spectrum of the Toeplitz vector circularly shifted so that the
@@ -1931,6 +2232,7 @@ struct efgp_toeplitz_s {
     // the specialised 64 x 64 kernels (any F >= 2 n - 1 embeds the Toeplitz product exactly; measured 3.1 us per iteration
     // against 9-11 us of the generic kernel on the 32 x 32 grid).  fft_shape / efgp_toeplitz_apply keep the reference's grid.
     double2* vhat_c = nullptr;   // lines_ok grids: centred spectrum for the cooperative solve (center_spectrum_kernel)
+    double* vc3 = nullptr;       // lines3_ok grids: REAL centred spectrum of the Hermitian 3-D iteration, built on first use
     ToepGeom g_cg;
     double2* vhat_cg = nullptr;
     double2* tw_cg[3] = {nullptr, nullptr, nullptr};
@@ -2129,6 +2431,7 @@ int efgp_toeplitz_destroy(efgp_toeplitz_t* op) {
     if (op->vhat) pool_free(op->ctx, op->vhat, (size_t)op->g.Ftot * sizeof(double2));
     if (op->vhat_cg) pool_free(op->ctx, op->vhat_cg, (size_t)4096 * sizeof(double2));
     if (op->vhat_c) pool_free(op->ctx, op->vhat_c, (size_t)op->g.Ftot * sizeof(double2));
+    if (op->vc3) pool_free(op->ctx, op->vc3, (size_t)op->g.Ftot * sizeof(double));
     delete op;
     return EFGP_OK;
 }
@@ -2354,9 +2657,27 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
 
 static thread_local bool t_no_coop = false;    // set while the cooperative solve hands systems to the multi-launch path
 
+static int cg_solve_impl(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
+                         const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop,
+                         int batched_semantics, int* iters_out, int* row_iters_out, void* stream_, int hermitian);
+
 int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
                   const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop,
                   int batched_semantics, int* iters_out, int* row_iters_out, void* stream_) {
+    return cg_solve_impl(op, ws, sigmasq, variant, precond_diag, b, x, nbatch, tol, max_iter, early_stop, batched_semantics, iters_out,
+                         row_iters_out, stream_, 0);
+}
+
+int efgp_cg_solve_hermitian(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
+                            const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop,
+                            int batched_semantics, int* iters_out, int* row_iters_out, void* stream_) {
+    return cg_solve_impl(op, ws, sigmasq, variant, precond_diag, b, x, nbatch, tol, max_iter, early_stop, batched_semantics, iters_out,
+                         row_iters_out, stream_, 1);
+}
+
+static int cg_solve_impl(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
+                         const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop,
+                         int batched_semantics, int* iters_out, int* row_iters_out, void* stream_, int hermitian) {
     EFGP_REQUIRE(op && ws && b && x, "efgp_cg_solve: null argument");
     EFGP_REQUIRE(nbatch >= 1, "efgp_cg_solve: nbatch must be >= 1");
     EFGP_REQUIRE(variant == 0 || variant == 1, "efgp_cg_solve: variant must be 0 or 1");
@@ -2515,6 +2836,9 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         int* d_rows = a.status + 16;
         a.counter = (int*)(scb + off_counter);
         a.partial = (double*)(scb + off_partial);
+        a.v_off = 0;
+        a.v_len = g.M;
+        a.v_w1 = g.M;
         a.nblk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(64 /* update kernels: measured optimum */, (g.M + kVecThreads - 1) / kVecThreads),
                                                             std::max<int64_t>(1, 1024 / rows)));
         EFGP_HIP_CHECK(hipMemsetAsync(a.status, 0, off_partial - off_status, stream));      // status, map, counters
@@ -2597,6 +2921,74 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
             EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg3_dim1_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3_s[1]));
             EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg3_mid0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3_s[0]));
         }
+        // Hermitian 3-D systems: the planes k0 >= 0 only (cg3h_* kernels).  The data are checked once per group of rows.
+        bool use_lines3h = use_lines3 && hermitian && (g.n[0] & 1) && (g.n[1] & 1) && (g.n[2] & 1) && g.n[0] >= 3 &&
+                           std::getenv("EFGP_NO_CG_HERM3") == nullptr;
+        Line3HArgs l3h;
+        size_t lds3h_c = 0, lds3h_s[2] = {0, 0};
+        if (use_lines3h) {
+            if (!op->vc3) {
+                op->vc3 = (double*)pool_alloc(ctx, (size_t)g.Ftot * sizeof(double));
+                if (!op->vc3) return EFGP_ENOMEM;
+                hipLaunchKernelGGL(center_spectrum3_real_kernel, dim3((unsigned)((g.Ftot + 255) / 256)), dim3(256), 0, stream, op->vhat, op->tw[0],
+                                   op->tw[1], op->tw[2], (int)g.n[0], (int)g.n[1], (int)g.n[2], (int)g.F[0], (int)g.F[1], (int)g.F[2], op->vc3);
+                EFGP_HIP_CHECK(hipGetLastError());
+            }
+            double* chk_buf = (double*)scratch(ctx, SLOT_MISC, 64);
+            if (!chk_buf) return EFGP_ENOMEM;
+            EFGP_HIP_CHECK(hipMemsetAsync(chk_buf, 0, 64, stream));
+            hipLaunchKernelGGL(cg_herm_check_kernel, dim3(256), dim3(kVecThreads), 0, stream, a.b, (const double2*)a.x, a.ws, g.M, rows, chk_buf);
+            EFGP_HIP_CHECK(hipGetLastError());
+            EFGP_HIP_CHECK(hipMemcpyAsync(host, chk_buf, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
+            EFGP_HIP_CHECK(stream_wait(stream));
+            double hv[3];
+            std::memcpy(hv, host, sizeof(hv));
+            if (!(hv[0] <= 1e-16 * hv[1]) || hv[2] > 0.0) {
+                set_error("efgp_cg_solve_hermitian: right-hand side / start vector not conjugate-even or ws not real and even");
+                return EFGP_EINVAL;
+            }
+            const int64_t nh = (g.n[0] + 1) / 2;
+            a.v_off = (nh - 1) * g.n[1] * g.n[2];
+            a.v_len = nh * g.n[1] * g.n[2];
+            a.v_w1 = g.n[1] * g.n[2];
+            l3h.vc = op->vc3;
+            for (int q = 0; q < 3; ++q) l3h.tw[q] = op->tw[q];
+            l3h.b1 = pad;
+            l3h.b2 = pad + (int64_t)rows * nh * g.n[1] * g.F[2];
+            const int64_t nlines = nh * g.n[1];
+            const int64_t fit = ((int64_t)ctx->max_lds / (int64_t)sizeof(double2) - g.F[2]) / (2 * (g.F[2] + 1));
+            int lpb = 8;
+            while ((nlines + lpb - 1) / lpb > kCgBlocksMax && lpb * 2 <= fit) lpb <<= 1;
+            if (rows >= 3 && lpb < 16 && 32 <= fit) lpb = 16;          // measured at mtot 57: 125 vs 133 us per iteration of 3 systems
+            if (rows > 8) {
+                while (lpb * 2 <= fit && lpb < 64) lpb <<= 1;
+            }
+            auto knob = [](const char* name, int dflt) {
+                const char* e = std::getenv(name);
+                int v = e ? std::atoi(e) : dflt;
+                int p2 = 1;
+                while (p2 * 2 <= v) p2 <<= 1;
+                return std::max(1, p2);
+            };
+            if (std::getenv("EFGP_CG3_LC")) {
+                lpb = knob("EFGP_CG3_LC", lpb);
+                while ((nlines + lpb - 1) / lpb > kCgBlocksMax) lpb <<= 1;
+            }
+            l3h.lpb_c = lpb;
+            l3h.lpb_s = (int)std::min<int64_t>(knob("EFGP_CG3_LS", 16), g.F[2] / 2);
+            l3h.lpb_m = (int)std::min<int64_t>(knob("EFGP_CG3_LM", rows >= 3 ? 32 : 16), g.F[2] / 2);      // 3 systems: 124.6 vs 132.6 us
+            l3h.nblk_lines = (int)((nlines + lpb - 1) / lpb);
+            lds3h_c = ((size_t)2 * lpb * (size_t)(g.F[2] + 1) + (size_t)g.F[2]) * sizeof(double2);
+            lds3h_s[1] = ((size_t)2 * l3h.lpb_s * (size_t)(g.F[1] + 1) + (size_t)g.F[1]) * sizeof(double2);
+            lds3h_s[0] = ((size_t)2 * l3h.lpb_m * (size_t)(g.F[0] + 1) + (size_t)g.F[0]) * sizeof(double2);
+            EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg3h_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3h_c));
+            EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg3h_inv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3h_c));
+            EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg3h_dim1_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3h_s[1]));
+            EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg3h_dim1_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3h_s[1]));
+            EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)cg3h_mid0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3h_s[0]));
+            a.nblk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(std::min(kCgBlocksMax, knob("EFGP_CG_NBLK", 128)), (a.v_len + kVecThreads - 1) / kVecThreads),
+                                                                std::max<int64_t>(1, 1024 / rows)));
+        }
         bool use_graph = !timing_enabled() && std::getenv("EFGP_NO_CG_GRAPH") == nullptr;
         hipGraphExec_t graph_exec = nullptr;
         int graph_slots = -1;
@@ -2614,6 +3006,19 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
             // costs the host ~300 us per iteration (measured, 3-D 64^3), far more than the GPU needs.  A full burst is
             // therefore captured ONCE into a hipGraph per (slots, row map) state and replayed with one launch.
             auto enqueue_iteration = [&]() -> int {
+                if (use_lines3h) {
+                    l3h.c = a;
+                    const unsigned nhp = (unsigned)((g.n[0] + 1) / 2);
+                    const unsigned gs = (unsigned)(g.F[2] / l3h.lpb_s), gp = (unsigned)(g.F[2] / 2 / l3h.lpb_m);
+                    hipLaunchKernelGGL(cg3h_fwd2_kernel, dim3(l3h.nblk_lines, slots), dim3(kLineThreads), lds3h_c, stream, l3h);
+                    hipLaunchKernelGGL((cg3h_dim1_kernel<0>), dim3(nhp * gs, slots), dim3(kLineThreads), lds3h_s[1], stream, l3h);
+                    hipLaunchKernelGGL(cg3h_mid0_kernel, dim3((unsigned)g.F[1] * gp, slots), dim3(kLineThreads), lds3h_s[0], stream, l3h);
+                    hipLaunchKernelGGL((cg3h_dim1_kernel<1>), dim3(nhp * gs, slots), dim3(kLineThreads), lds3h_s[1], stream, l3h);
+                    hipLaunchKernelGGL(cg3h_inv2_kernel, dim3(l3h.nblk_lines, slots), dim3(kLineThreads), lds3h_c, stream, l3h);
+                    hipLaunchKernelGGL(cg_axpy_kernel, dim3(a.nblk, slots), dim3(kVecThreads), 0, stream, a);
+                    EFGP_HIP_CHECK(hipGetLastError());
+                    return EFGP_OK;
+                }
                 if (use_lines3) {
                     l3.c = a;
                     const unsigned gs = (unsigned)(g.F[2] / l3.lpb_s);
@@ -2721,6 +3126,13 @@ int efgp_cg_solve(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varia
         if (graph_exec) {
             TraceSpan span_destroy("hipGraphExecDestroy");
             (void)hipGraphExecDestroy(graph_exec);
+        }
+        if (use_lines3h) {          // the planes k0 < 0 of the solutions
+            CgArgs am = a;
+            am.rows = nullptr;
+            hipLaunchKernelGGL(cg3h_mirror_kernel, dim3(64, rows), dim3(kVecThreads), 0, stream, am);
+            EFGP_HIP_CHECK(hipGetLastError());
+            EFGP_HIP_CHECK(stream_wait(stream));
         }
         // iteration counts (cg.py:152 single; cg.py:193-199,243 batched: +1 for the terminating pass)
         int group_iters;

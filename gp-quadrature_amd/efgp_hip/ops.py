@@ -323,9 +323,11 @@ def cg_solve(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=Tru
     iters = C.c_int(0)
     rows = (C.c_int * B)()
     with torch.cuda.device(dev):
-        check(lib().efgp_cg_solve(op._h, _ptr(wsd), float(sigmasq), int(variant), _ptr(dg) if dg is not None else None,
-                                  _ptr(bb), _ptr(x), B, float(tol), int(max_iter) if max_iter is not None else 0,
-                                  int(bool(early_stop)), int(bool(batched)), C.byref(iters), rows, _stream(dev)),
+        # hermitian: the synchronous entry keeps the promise too (3-D grids carry the planes k0 >= 0 only)
+        fn = lib().efgp_cg_solve_hermitian if hermitian else lib().efgp_cg_solve
+        check(fn(op._h, _ptr(wsd), float(sigmasq), int(variant), _ptr(dg) if dg is not None else None,
+                 _ptr(bb), _ptr(x), B, float(tol), int(max_iter) if max_iter is not None else 0,
+                 int(bool(early_stop)), int(bool(batched)), C.byref(iters), rows, _stream(dev)),
               "efgp_cg_solve")
     return x.reshape(b.shape), int(iters.value), [int(r) for r in rows]
 

@@ -519,7 +519,7 @@ def efgpnd_gradient_batched(
                                diag=diag if use_mean_cg_preconditioner else None, batched=False, hermitian=True)
         if res_m is None:
             res_m = cg_solve(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping,
-                             diag=diag if use_mean_cg_preconditioner else None, batched=False)[:2]
+                             diag=diag if use_mean_cg_preconditioner else None, batched=False, hermitian=True)[:2]
         beta, mean_iters = res_m
         beta_raw = beta.clone()
         beta_s = ws * beta                                        # g = D beta
@@ -686,7 +686,7 @@ def _gradient_tail_native(kernel, grid, top, Fy, v, sig, N, N_local, cg_tol, ear
                            batched=False, hermitian=True)
     if res_m is None:
         res_m = cg_solve(top, ws, sig, 0, rhs, b0, cg_tol, early_stop=early_stopping, diag=diag if use_mean_pc else None,
-                         batched=False)[:2]
+                         batched=False, hermitian=True)[:2]
     beta, mean_iters = res_m
     Tg = top.apply_scaled(beta, pre=ws)                         # T (D beta)
     lap("4_solve_cg")
@@ -1183,7 +1183,8 @@ class EFGPND(nn.Module):
             res = cg_solve_async(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False,
                                  hermitian=True)
             if res is None:
-                res = cg_solve(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False)[:2]
+                res = cg_solve(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False,
+                               hermitian=True)[:2]      # 3-D grids: the planes k0 >= 0 only (efgp_cg_solve_hermitian)
         beta, iters = res
 
         self._beta = beta.to(cdtype) if cdtype != torch.complex128 else beta

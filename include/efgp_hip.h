@@ -247,6 +247,17 @@ int efgp_cg_solve_hermitian_async(efgp_toeplitz_t* op, const void* ws, double si
                                   const double* precond_diag, const void* b, void* x, int nbatch, double tol,
                                   int max_iter, int early_stop, int batched_semantics, int* row_iters_dev, void* stream);
 
+/* efgp_cg_solve (synchronous, every grid) under the same promise as efgp_cg_solve_hermitian_async.  On 3-D circulant grids of
+ * 64..256 per dimension (odd mtot) the multi-launch iteration then carries the planes k0 >= 0 only: half the lines in every
+ * pass, two real columns per complex transform along dim 0, a REAL centred spectrum (cg3h_* kernels; BASELINE configs[4]:
+ * 66 MB per operator application instead of 150 MB); same recurrences, stopping rules and iteration counts (cg.py:86-244).
+ * Every other grid: efgp_cg_solve.  Data that break the promise (right-hand side or start vector not conjugate-even to
+ * 1e-8, ws not real and even) are refused with EFGP_EINVAL before anything is written. */
+int efgp_cg_solve_hermitian(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant,
+                            const double* precond_diag, const void* b, void* x, int nbatch, double tol,
+                            int max_iter, int early_stop, int batched_semantics, int* iters_out,
+                            int* row_iters_out, void* stream);
+
 /* The fit's mean system in one launch, straight from the transform outputs (efgpnd.py:792-803):
  *     (D T D + sigmasq I) beta = D fy,   D = diag(ws),   beta_0 = 0,
  * Jacobi diagonal (*diag_scale_dev) * |ws|^2 + sigmasq when diag_scale_dev is not NULL (device pointer to the

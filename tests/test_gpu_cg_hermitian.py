@@ -227,3 +227,102 @@ def test_residual_history_from_the_hermitian_kernel(monkeypatch):
         print(f"iterations {lo}..{hi}: deviation from the oracle's curve  hermitian {dh:.1e}  complex {dc:.1e}")
         assert dh < 30 * dc + 1e-12, (lo, hi, dh, dc)
     assert abs(its - ito) <= 1 + ito // 100
+
+
+# ---- round 3: the Hermitian 3-D line iteration (cg3h_* kernels, planes k0 >= 0 only) -------------------------------------------
+def _herm3(t):
+    return 0.5 * (t + torch.flip(t, dims=(-3, -2, -1)).conj())
+
+
+def _system3(ns, seed, N=160, rows=None):
+    """Toeplitz vector of N random 3-D points on the (2 n_a - 1) lag box (anisotropic boxes: the central crop of the cubic one), a real
+    even ws, Hermitian right-hand sides."""
+    from oracle import efgp_oracle as O
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(N, 3, generator=g, dtype=torch.float64) * 2 - 1
+    m = (max(ns) - 1) // 2
+    v = O.conv_vector(x, 0.31, m)
+    c = 2 * m
+    v = v[tuple(slice(c - (n - 1), c + n) for n in ns)].contiguous()
+    w = torch.exp(-2.5 * torch.rand(*ns, generator=g, dtype=torch.float64))
+    ws = (0.5 * (w + torch.flip(w, dims=(0, 1, 2)))).reshape(-1).to(torch.complex128)
+    shape = tuple(ns) if rows is None else (rows, *ns)
+    b = _herm3(torch.complex(torch.randn(shape, generator=g, dtype=torch.float64), torch.randn(shape, generator=g, dtype=torch.float64)))
+    b = b.reshape(-1) if rows is None else b.reshape(rows, -1)
+    return v, O.Toeplitz(v), ws, b
+
+
+@pytest.mark.parametrize("ns,precond,variant,tol,sig", [((19, 19, 19), True, 0, 1e-8, 0.3), ((19, 19, 19), False, 1, 1e-6, 0.3),
+                                                        ((17, 19, 21), True, 0, 1e-10, 0.3), ((33, 33, 33), True, 0, 1e-8, 30.0),
+                                                        ((17, 33, 19), True, 1, 1e-8, 0.3)])
+def test_hermitian_3d_iteration_matches_general_iteration_and_oracle(ns, precond, variant, tol, sig, monkeypatch):
+    """Half the planes, packed column pairs along dim 0, real centred spectrum -- against the general 3-D line iteration and the
+    oracle's cg.py restatement: iteration counts, solutions, exact conjugate symmetry of the result, the true residual."""
+    from efgp_hip import ToeplitzOp, cg_solve
+    from oracle import efgp_oracle as O
+    v, T, ws, b = _system3(ns, 11)
+    op = ToeplitzOp(v.cuda())
+    assert len(op.fft_shape) == 3 and min(op.fft_shape) >= 64
+    centre = float(v[tuple((s - 1) // 2 for s in v.shape)].real)
+    diag = (centre * ws.abs().pow(2).real + sig) if precond else None
+    dd = diag.cuda() if diag is not None else None
+    xh, it_h, _ = cg_solve(op, ws.cuda(), sig, variant, b.cuda(), None, tol, diag=dd, batched=False, hermitian=True)
+    xc, it_c, _ = cg_solve(op, ws.cuda(), sig, variant, b.cuda(), None, tol, diag=dd, batched=False)
+    monkeypatch.setenv("EFGP_NO_CG_HERM3", "1")
+    xg, it_g, _ = cg_solve(op, ws.cuda(), sig, variant, b.cuda(), None, tol, diag=dd, batched=False, hermitian=True)
+    monkeypatch.delenv("EFGP_NO_CG_HERM3")
+    assert it_g == it_c and torch.equal(xg, xc)                   # the switch falls back to the general iteration
+    # long solves decorrelate (the reference's own stopping index moves by several per cent under a 1e-13 perturbation)
+    slack = max(1 + it_c // (200 if precond else 50), int(0.03 * it_c)) if it_c < 400 else int(0.06 * it_c)
+    xtol = (100 if precond else 1e4) * tol
+    print(f"\n3-D {ns}: iterations hermitian {it_h}, general {it_c}; solutions differ by {_rel(xh, xc):.2e}")
+    assert abs(it_h - it_c) <= slack, (it_h, it_c)
+    assert _rel(xh, xc) < xtol
+    A = O.make_A_mean(ws, T, sig) if variant == 0 else O.make_A_var(ws, T, sig)
+    xo, ito = O.cg_single(A, b, torch.zeros_like(b), tol, diag=diag)
+    assert abs(it_h - ito) <= slack, (it_h, ito)
+    assert _rel(xh, xo) < xtol
+    true_h = float(torch.linalg.norm(A(xh.cpu()) - b) / torch.linalg.norm(b))
+    true_o = float(torch.linalg.norm(A(xo) - b) / torch.linalg.norm(b))
+    assert true_h < 1.05 * true_o + 0.1 * tol, (true_h, true_o)
+    xq = xh.cpu().reshape(*ns)
+    assert torch.equal(torch.flip(xq, dims=(0, 1, 2)).conj()[: ns[0] // 2], xq[: ns[0] // 2])
+
+
+def test_hermitian_3d_batched_warm_start_and_refusal():
+    """Several systems with per-row stopping and non-zero Hermitian start vectors; data that break the promise are refused
+    (ValueError, nothing written) while the general entry takes them."""
+    from efgp_hip import ToeplitzOp, cg_solve
+    from oracle import efgp_oracle as O
+    ns, rows = (19, 19, 19), 5
+    v, T, ws, B = _system3(ns, 12, rows=rows)
+    op = ToeplitzOp(v.cuda())
+    B = B * torch.logspace(-2, 2, rows, dtype=torch.float64)[:, None]
+    g = torch.Generator().manual_seed(3)
+    X0 = 0.1 * _herm3(torch.complex(torch.randn(rows, *ns, generator=g, dtype=torch.float64),
+                                    torch.randn(rows, *ns, generator=g, dtype=torch.float64))).reshape(rows, -1)
+    xh, it_h, rows_h = cg_solve(op, ws.cuda(), 0.3, 1, B.cuda(), X0.cuda(), 1e-8, batched=True, hermitian=True)
+    xc, it_c, rows_c = cg_solve(op, ws.cuda(), 0.3, 1, B.cuda(), X0.cuda(), 1e-8, batched=True)
+    assert abs(it_h - it_c) <= 1 and all(abs(a - b) <= 1 for a, b in zip(rows_h, rows_c)), (rows_h, rows_c)
+    assert len(set(rows_h)) > 1                                                   # the rows did stop at different iterations
+    A = O.make_A_var(ws, T, 0.3)
+    for r in (0, rows - 1):
+        xo, ito = O.cg_batched(A, B[r:r + 1], X0[r:r + 1], 1e-8)
+        assert abs(rows_h[r] + 1 - ito) <= 2, (r, rows_h[r], ito)
+        assert _rel(xh[r], xo[0]) < 1e-6
+        assert _rel(xh[r], xc[r]) < 1e-7
+    bad = torch.complex(torch.randn(B.shape[1], generator=g, dtype=torch.float64), torch.randn(B.shape[1], generator=g, dtype=torch.float64))
+    with pytest.raises(ValueError, match="conjugate-even"):
+        cg_solve(op, ws.cuda(), 0.3, 0, bad.cuda(), None, 1e-8, batched=False, hermitian=True)
+    ws_bad = ws.clone()
+    ws_bad[7] = ws_bad[7] + 0.1
+    with pytest.raises(ValueError, match="conjugate-even"):
+        cg_solve(op, ws_bad.cuda(), 0.3, 0, B[0].cuda(), None, 1e-8, batched=False, hermitian=True)
+    x, it, _ = cg_solve(op, ws.cuda(), 0.3, 0, bad.cuda(), None, 1e-8, batched=False)
+    assert it > 0 and bool(torch.isfinite(x.real).all())
+    # a grid outside the line kernels' range (16 x 128 x 64): the promise is accepted and the general iteration runs
+    v2, T2, ws2, b2 = _system3((5, 33, 17), 13)
+    op2 = ToeplitzOp(v2.cuda())
+    xa, ia, _ = cg_solve(op2, ws2.cuda(), 0.3, 0, b2.cuda(), None, 1e-8, batched=False, hermitian=True)
+    xb, ib, _ = cg_solve(op2, ws2.cuda(), 0.3, 0, b2.cuda(), None, 1e-8, batched=False)
+    assert ia == ib and torch.equal(xa, xb)
