@@ -56,6 +56,7 @@ enum Slot {
     SLOT_MISC,         // reductions
     SLOT_SCALE,        // fixed-point scale of the spreader
     SLOT_G2M,          // grid_to_modes_kernel: per-tile arrival counters (first 64 KB, zero between launches) + partial sums
+    SLOT_FFT_WORK,     // intermediate arrays of the pruned in-house transforms (line_fft.hip)
     SLOT_COUNT
 };
 

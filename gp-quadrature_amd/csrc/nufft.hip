@@ -24,6 +24,7 @@
 #include "points_layout.hpp"
 #include "spread_mfma.hpp"
 #include "small_dft.hpp"
+#include "line_fft.hpp"
 
 namespace efgp {
 
@@ -2657,7 +2658,19 @@ struct G2MRequest {
     void* out_a = nullptr;
     void* out_b = nullptr;
     bool done = false;
+    // set by transform_fine when the in-house pruned transform ran: the spectrum handed back holds only the crop_nf[a] lowest-|k|
+    // bins per axis (FFT order on that smaller torus) -- the mode extraction indexes it with these extents instead of nf
+    bool cropped = false;
+    int64_t crop_nf[3] = {1, 1, 1};
 };
+static void apply_crop(const G2MRequest* req, ModeGeom& m, int64_t& cells) {
+    if (!req || !req->cropped) return;
+    cells = 1;
+    for (int a = 0; a < 3; ++a) {
+        if (a < m.d) m.nf[a] = req->crop_nf[a];
+        cells *= a < m.d ? req->crop_nf[a] : 1;
+    }
+}
 
 static bool g2m_eligible(const efgp_nufft_s* plan, const GridGeom& g, const G2MRequest* req) {
     if (!req || plan->dim != 2 || std::getenv("EFGP_NO_GRID_TO_MODES")) return false;
@@ -2765,10 +2778,32 @@ static int transform_fine(efgp_nufft_s* plan, const GridGeom& g, double2* fine, 
         *fine_out = nullptr;
         return g2m_launch(plan->ctx, g, req, nullptr, fine, scale, 2, nbatch, isign, nullptr, 0, stream);
     }
-    hipfftHandle fh;
-    int rc = fft_plan(plan->ctx, plan->dim, g.nf, nbatch, stream, &fh);
+    // In-house pruned transform when the caller said which modes it wants: every pass keeps only the bins of the (larger) mode
+    // box, so the strided passes and the extraction behind them run on a fraction of the grid (line_fft.hip).
+    if (req && own_fft_supported(plan->dim, g.nf) && std::getenv("EFGP_NO_PRUNED_FFT") == nullptr) {
+        int64_t nc[3] = {1, 1, 1}, wk = nbatch;
+        bool smaller = false;
+        for (int a = 0; a < plan->dim; ++a) {
+            int64_t hmax = req->ma.nm[a] / 2;
+            if (req->part == 4) hmax = std::max(hmax, req->mb.nm[a] / 2);
+            nc[a] = std::min<int64_t>(2 * hmax + 1, g.nf[a]);
+            smaller = smaller || nc[a] < g.nf[a];
+            wk *= a == plan->dim - 1 ? nc[a] : g.nf[a];
+        }
+        if (smaller) {
+            double2* work = (double2*)scratch(plan->ctx, SLOT_FFT_WORK, (size_t)wk * sizeof(double2));
+            if (!work) return EFGP_ENOMEM;
+            double2* res = nullptr;
+            const int rcp = own_fft_pruned_forward(plan->ctx, plan->dim, g.nf, nc, nbatch, fine, work, isign < 0, &res, stream);
+            if (rcp != EFGP_OK) return rcp;
+            req->cropped = true;
+            for (int a = 0; a < 3; ++a) req->crop_nf[a] = nc[a];
+            *fine_out = res;
+            return EFGP_OK;
+        }
+    }
+    const int rc = fft_c2c(plan->ctx, plan->dim, g.nf, nbatch, fine, isign < 0, stream);      // in-house line kernels, hipFFT beyond their sizes
     if (rc != EFGP_OK) return rc;
-    EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)fine, (hipfftDoubleComplex*)fine, isign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
     *fine_out = fine;
     return EFGP_OK;
 }
@@ -3094,10 +3129,11 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
 }
 
 static int run_deconvolve(efgp_nufft_s* plan, WindowSet* w, const double2* fine, const int64_t* nm, int modeord,
-                          int part, int nbatch, void* out, hipStream_t stream, int rows_limit = 1 << 30) {
+                          int part, int nbatch, void* out, hipStream_t stream, int rows_limit = 1 << 30, const G2MRequest* req = nullptr) {
     ModeGeom m = make_modes(plan, w, nm, modeord);
     int64_t cells = 1;
     for (int a = 0; a < 3; ++a) cells *= w->nf[a];
+    apply_crop(req, m, cells);
     int threads = 256;
     int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((m.total + threads - 1) / threads, 2048));
     hipLaunchKernelGGL(deconvolve_kernel, dim3(blocks, nbatch), dim3(threads), 0, stream, fine, cells, m, part,
@@ -3176,7 +3212,7 @@ static int type1_real_rows(efgp_nufft_s* plan, WindowSet* w, const double* c, bo
         if (rc != EFGP_OK) return rc;
         // for isign = +1 the roles of k and -k swap in the Hermitian split; conjugating H handles both signs:
         // the split below assumes the forward (isign = -1) transform, which is what the reference uses for type 1
-        if (!req.done) rc = run_deconvolve(plan, w, fine, n_modes, modeord, 3, npair, out, stream, nbatch);
+        if (!req.done) rc = run_deconvolve(plan, w, fine, n_modes, modeord, 3, npair, out, stream, nbatch, &req);
         if (rc != EFGP_OK) return rc;
     }
     if ((nbatch & 1) && !pad_odd) {
@@ -3196,7 +3232,7 @@ static int type1_real_rows(efgp_nufft_s* plan, WindowSet* w, const double* c, bo
             rc = spread_and_fft(plan, w, c + (int64_t)last * plan->npts, STR_REAL, 1, isign, stream, &fine, 0, 0, nullptr, &req);
         }
         if (rc != EFGP_OK) return rc;
-        if (!req.done) rc = run_deconvolve(plan, w, fine, n_modes, modeord, 0, 1, (double2*)out + (int64_t)last * total, stream);
+        if (!req.done) rc = run_deconvolve(plan, w, fine, n_modes, modeord, 0, 1, (double2*)out + (int64_t)last * total, stream, 1 << 30, &req);
         if (rc != EFGP_OK) return rc;
     }
     return EFGP_OK;
@@ -3224,7 +3260,7 @@ int efgp_nufft_type1(efgp_nufft_t* plan, const void* c, int c_is_complex, int nb
     rc = spread_and_fft(plan, w, (const double*)c, c_is_complex ? STR_COMPLEX : STR_REAL, nbatch, isign, stream, &fine, 0, 0, nullptr, &req);
     if (rc != EFGP_OK) return rc;
     if (req.done) return EFGP_OK;
-    return run_deconvolve(plan, w, fine, n_modes, modeord, 0, nbatch, out, stream);
+    return run_deconvolve(plan, w, fine, n_modes, modeord, 0, nbatch, out, stream, 1 << 30, &req);
 }
 
 int efgp_nufft_type1_rademacher(efgp_nufft_t* plan, uint64_t seed, int64_t index_offset, int nbatch,
@@ -3323,6 +3359,8 @@ int efgp_nufft_type1_pair(efgp_nufft_t* plan, const double* y, const int64_t* n_
         }
         int64_t cells = 1;
         for (int a = 0; a < 3; ++a) cells *= w->nf[a];
+        apply_crop(reqp, ma, cells);
+        apply_crop(reqp, mb, cells);
         const int64_t most = std::max(ma.total, mb.total);
         const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((most + 255) / 256, 2048));
         hipLaunchKernelGGL(deconvolve_pair_kernel, dim3(blocks, 2), dim3(256), 0, stream, (const double2*)fine, cells, ma,
@@ -3374,15 +3412,35 @@ static int type2_impl(efgp_nufft_t* plan, const void* f, const void* mode_scale,
         if (rc != EFGP_OK) return rc;
     } else {
         int threads = 256;
-        int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((g.cells + threads - 1) / threads, 2048));
-        hipLaunchKernelGGL(precorrect_kernel, dim3(blocks, nbatch), dim3(threads), 0, stream, (const double2*)f,
-                           (const double2*)mode_scale, m, real_only ? 1 : 0, g.cells, fine);
-        EFGP_HIP_CHECK(hipGetLastError());
-        hipfftHandle fh;
-        rc = fft_plan(ctx, plan->dim, g.nf, nbatch, stream, &fh);
-        if (rc != EFGP_OK) return rc;
-        EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)fine, (hipfftDoubleComplex*)fine,
-                                     isign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
+        // In-house pruned transform: the corrected modes go to a compact array (the 2 (nm/2) + 1 lowest bins per axis), the passes
+        // expand it axis by axis, slowest first -- only the last, contiguous pass writes the full grid (line_fft.hip).
+        int64_t nc[3] = {1, 1, 1}, ccells = 1, region = nbatch;
+        bool smaller = false;
+        for (int a = 0; a < plan->dim; ++a) {
+            nc[a] = std::min<int64_t>(2 * (n_modes[a] / 2) + 1, g.nf[a]);
+            smaller = smaller || nc[a] < g.nf[a];
+            ccells *= nc[a];
+            region *= a == plan->dim - 1 ? nc[a] : g.nf[a];
+        }
+        if (smaller && own_fft_supported(plan->dim, g.nf) && std::getenv("EFGP_NO_PRUNED_FFT") == nullptr) {
+            double2* work = (double2*)scratch(ctx, SLOT_FFT_WORK, (size_t)2 * (size_t)region * sizeof(double2));
+            if (!work) return EFGP_ENOMEM;
+            ModeGeom mc = m;
+            for (int a = 0; a < plan->dim; ++a) mc.nf[a] = nc[a];
+            int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((ccells + threads - 1) / threads, 2048));
+            hipLaunchKernelGGL(precorrect_kernel, dim3(blocks, nbatch), dim3(threads), 0, stream, (const double2*)f,
+                               (const double2*)mode_scale, mc, real_only ? 1 : 0, ccells, work);
+            EFGP_HIP_CHECK(hipGetLastError());
+            rc = own_fft_pruned_backward(ctx, plan->dim, nc, g.nf, nbatch, work, fine, work, region, isign < 0, stream);
+            if (rc != EFGP_OK) return rc;
+        } else {
+            int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((g.cells + threads - 1) / threads, 2048));
+            hipLaunchKernelGGL(precorrect_kernel, dim3(blocks, nbatch), dim3(threads), 0, stream, (const double2*)f,
+                               (const double2*)mode_scale, m, real_only ? 1 : 0, g.cells, fine);
+            EFGP_HIP_CHECK(hipGetLastError());
+            rc = fft_c2c(ctx, plan->dim, g.nf, nbatch, fine, isign < 0, stream);
+            if (rc != EFGP_OK) return rc;
+        }
     }
     const bool cplx = !real_only;
     size_t lds_bytes = (size_t)g.cells * (cplx ? sizeof(double2) : sizeof(double));

@@ -21,6 +21,7 @@
 
 #include "common.hpp"
 #include "es_kernel.hpp"
+#include "line_fft.hpp"
 #include "toeplitz_cg.hpp"
 
 namespace efgp {
@@ -2261,15 +2262,21 @@ static dim3 grid_for(int64_t work, int rows, int threads, int cap = 1024) {
 
 // pad = FFT^-1( FFT(pad) .* vhat ) for `slots` rows
 static int circulant(efgp_toeplitz_s* op, double2* pad, int slots, hipStream_t stream) {
-    hipfftHandle fh;
-    int rc = fft_plan(op->ctx, op->g.d, op->g.F, slots, stream, &fh);
+    // in-house transforms know the padding: the input is non-zero on [0, n) per axis, the product is read on [n - 1, 2 n - 1)
+    const bool own = own_fft_supported(op->g.d, op->g.F) && std::getenv("EFGP_NO_PRUNED_FFT") == nullptr;
+    int64_t lo_in[3] = {0, 0, 0}, lo_out[3], cnt[3];
+    for (int a = 0; a < 3; ++a) {
+        cnt[a] = a < op->g.d ? op->g.n[a] : 1;
+        lo_out[a] = a < op->g.d ? std::min(op->g.n[a] - 1, op->g.F[a] - op->g.n[a]) : 0;
+    }
+    int rc = own ? own_fft_exec_windowed(op->ctx, op->g.d, op->g.F, slots, pad, true, lo_in, cnt, false, stream)
+                 : fft_c2c(op->ctx, op->g.d, op->g.F, slots, pad, true, stream);
     if (rc != EFGP_OK) return rc;
-    EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)pad, (hipfftDoubleComplex*)pad, HIPFFT_FORWARD));
     hipLaunchKernelGGL(spectral_mul_kernel, grid_for(op->g.Ftot, slots, kVecThreads), dim3(kVecThreads), 0, stream,
                        op->g.Ftot, (const double2*)op->vhat, pad);
     EFGP_HIP_CHECK(hipGetLastError());
-    EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)pad, (hipfftDoubleComplex*)pad, HIPFFT_BACKWARD));
-    return EFGP_OK;
+    return own ? own_fft_exec_windowed(op->ctx, op->g.d, op->g.F, slots, pad, false, lo_out, cnt, true, stream)
+               : fft_c2c(op->ctx, op->g.d, op->g.F, slots, pad, false, stream);
 }
 
 }  // namespace efgp
@@ -2325,13 +2332,7 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
             set_error("efgp_toeplitz_create: pad launch failed: %s", hipGetErrorString(e));
             return EFGP_EHIP;
         }
-        hipfftHandle fh;
-        rc = fft_plan(ctx, dim, op->g.F, 1, stream, &fh);
-        if (rc == EFGP_OK &&
-            hipfftExecZ2Z(fh, (hipfftDoubleComplex*)op->vhat, (hipfftDoubleComplex*)op->vhat, HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
-            set_error("efgp_toeplitz_create: FFT of the Toeplitz vector failed");
-            rc = EFGP_EHIP;
-        }
+        rc = fft_c2c(ctx, dim, op->g.F, 1, op->vhat, true, stream);
     }
     if (rc != EFGP_OK) {
         pool_free(ctx, op->vhat, (size_t)op->g.Ftot * sizeof(double2));
@@ -3060,8 +3061,12 @@ static int cg_solve_impl(efgp_toeplitz_t* op, const void* ws, double sigmasq, in
                     TraceSpan span_build("graph build (plan + capture + instantiate)");
                     hipGraph_t graph = nullptr;
                     // make sure the FFT plan exists and is bound to the stream before capturing
-                    hipfftHandle fh_unused;
-                    rc = fft_plan(ctx, g.d, g.F, slots, stream, &fh_unused);
+                    if (own_fft_supported(g.d, g.F)) {
+                        rc = own_fft_prepare(ctx, g.d, g.F, stream);
+                    } else {
+                        hipfftHandle fh_unused;
+                        rc = fft_plan(ctx, g.d, g.F, slots, stream, &fh_unused);
+                    }
                     if (rc != EFGP_OK) return rc;
                     bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
                     if (ok) {

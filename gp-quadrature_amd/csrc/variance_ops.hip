@@ -9,6 +9,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "line_fft.hpp"
 #include "toeplitz_cg.hpp"
 
 namespace efgp {
@@ -237,17 +238,13 @@ int efgp_lag_sums(int device, int dim, int64_t mtot, const void* gamma, const do
         const int J = (int)std::min<int64_t>(per, nprobes - j0);
         hipLaunchKernelGGL(lag_pad_kernel, dim3(blocks, J), dim3(256), 0, stream, g, (const double2*)gamma + j0 * g.M, eta + j0 * g.M, pad);
         EFGP_HIP_CHECK(hipGetLastError());
-        hipfftHandle fh;
-        int rc = fft_plan(ctx, dim, sizes, 2 * J, stream, &fh);
+        int rc = fft_c2c(ctx, dim, sizes, 2 * J, pad, true, stream);
         if (rc != EFGP_OK) return rc;
-        EFGP_FFT_CHECK(hipfftExecZ2Z(fh, (hipfftDoubleComplex*)pad, (hipfftDoubleComplex*)pad, HIPFFT_FORWARD));
         hipLaunchKernelGGL(lag_mul_sum_kernel, dim3(blocks), dim3(256), 0, stream, g.P, J, (const double2*)pad, acc, j0 > 0 ? 1 : 0);
         EFGP_HIP_CHECK(hipGetLastError());
     }
-    hipfftHandle fi;
-    int rc = fft_plan(ctx, dim, sizes, 1, stream, &fi);
+    int rc = fft_c2c(ctx, dim, sizes, 1, acc, false, stream);
     if (rc != EFGP_OK) return rc;
-    EFGP_FFT_CHECK(hipfftExecZ2Z(fi, (hipfftDoubleComplex*)acc, (hipfftDoubleComplex*)acc, HIPFFT_BACKWARD));
     const int oblocks = (int)std::max<int64_t>(1, std::min<int64_t>((g.S + 255) / 256, 1024));
     hipLaunchKernelGGL(lag_scale_kernel, dim3(oblocks), dim3(256), 0, stream, g, 1.0 / ((double)g.P * (double)nprobes), (const double2*)acc,
                        (double2*)out);

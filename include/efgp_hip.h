@@ -258,6 +258,13 @@ int efgp_cg_solve_hermitian(efgp_toeplitz_t* op, const void* ws, double sigmasq,
                             int max_iter, int early_stop, int batched_semantics, int* iters_out,
                             int* row_iters_out, void* stream);
 
+/* The complex FFT behind the transforms above, on a caller's device array: `batch` contiguous row-major arrays of extents
+ * n[0..rank), in place, double precision; forward != 0: exp(-i...), else the unnormalised inverse.  use_rocfft = 0: the
+ * in-house line kernels (line_fft.hip: lengths 2^a 3^b 5^c <= 4096 per axis, no run-time compilation; EFGP_EUNSUPPORTED
+ * otherwise), 1: hipFFT.  Replaces torch.fft.fftn / ifftn of ToeplitzND (efgpnd.py:1275-1290, 1331-1393) and the FFT stage of
+ * finufft (efgpnd.py:1395-1421); exported for tests, benchmarks and integrators who want the same transform. */
+int efgp_fft_c2c(int device, int rank, const long long* n, long long batch, void* data, int forward, int use_rocfft, void* stream);
+
 /* The fit's mean system in one launch, straight from the transform outputs (efgpnd.py:792-803):
  *     (D T D + sigmasq I) beta = D fy,   D = diag(ws),   beta_0 = 0,
  * Jacobi diagonal (*diag_scale_dev) * |ws|^2 + sigmasq when diag_scale_dev is not NULL (device pointer to the
