@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Round 3: the 3-D plane-per-wave tile spreader (spread_tile3_planes_kernel) against the lane-per-point one (EFGP_NO_TILE_PLANES=1):
 type-1 outputs must be IDENTICAL (integer sums of the same rounded contributions), and the time per pass.
-usage: tile_planes_ab.py [N] [mtot] [tol]"""
+usage: tile_planes_ab.py [N] [mtot] [tol]
+NOTE: the plane-per-wave kernel measured slower and was removed again (profiles/r3_tile_planes_negative.txt); with the current library
+both legs of this script run the same kernel.  Kept as the record of how the comparison was made."""
 import os
 import sys
 import time
