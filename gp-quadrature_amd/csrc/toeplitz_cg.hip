@@ -606,6 +606,8 @@ __device__ __forceinline__ void wave_sync_lds() {
 // multiplied by the REAL spectra Re mul[k * mul_stride + l] and Re mul[k * mul_stride + l + mul_pair], halved (the unpacking
 // behind the inverse transform adds two terms) and conjugated; the return value is sum S_a re^2 + S_b im^2.
 // MUL = 3: the same with `mul` pointing at an array of REAL spectrum values (3-D Hermitian iteration: half the bytes).
+// MUL = 4: the same with the two real spectra of every line already in LDS as double2 pairs, `mul`[k * mul_stride + l] (the
+// cooperative Hermitian solve keeps its workgroup's slice there: no global round trip inside the transform).
 template <int R, int MUL = 0>
 __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, int ld, int nl, const double2* tw,
                                                   const double2* __restrict__ mul = nullptr, int64_t mul_stride = 0,
@@ -639,7 +641,9 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
                 const int lq = act ? l0 + lsub : l0;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    if (MUL == 3) {
+                    if (MUL == 4) {
+                        mv[t] = mul[(j + 8 * t) * (int)mul_stride + lq];
+                    } else if (MUL == 3) {
                         const double* rs = reinterpret_cast<const double*>(mul);
                         mv[t] = make_double2(rs[(int64_t)(j + 8 * t) * mul_stride + lq], rs[(int64_t)(j + 8 * t) * mul_stride + lq + mul_pair]);
                     } else {
@@ -682,7 +686,9 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int q = 0; q < R; ++q) {
-                    if (MUL == 3) {
+                    if (MUL == 4) {
+                        mv[u * R + q] = mul[(li + LPL * u + 64 * q) * (int)mul_stride + lq];
+                    } else if (MUL == 3) {
                         const double* rs = reinterpret_cast<const double*>(mul);
                         mv[u * R + q] = make_double2(rs[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq],
                                                      rs[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq + mul_pair]);
@@ -778,6 +784,16 @@ __device__ __forceinline__ double2* line_fft_fast_mul2(double2* src, double2* ds
     if (F == 128) psum += line_fft_inwave_call<2, 2>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
     else if (F == 256) psum += line_fft_inwave_call<4, 2>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
     else psum += line_fft_inwave_call<8, 2>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
+    return dst;
+}
+// two real columns per line, spectra resident in LDS at offset spec_off (MUL = 4)
+__device__ __forceinline__ double2* line_fft_fast_mul4(double2* src, double2* dst, int F, int ld, int nl, const double2* tw,
+                                                       const double2* spec_lds, int stride, double& psum) {
+    const int so = (int)(src - efgp_line_lds), dn = (int)(dst - efgp_line_lds), to = (int)(tw - efgp_line_lds);
+    const double2* mul = efgp_line_lds + (int)(spec_lds - efgp_line_lds);
+    if (F == 128) psum += line_fft_inwave_call<2, 4>(so, dn, ld, nl, to, mul, stride);
+    else if (F == 256) psum += line_fft_inwave_call<4, 4>(so, dn, ld, nl, to, mul, stride);
+    else psum += line_fft_inwave_call<8, 4>(so, dn, ld, nl, to, mul, stride);
     return dst;
 }
 // two real columns per line, spectra given as a REAL array (MUL = 3)
@@ -989,6 +1005,7 @@ struct CoopArgs {
     double2* b1;              // [systems][n0][F1]
     double2* b2;              // [systems][n0][F1]
     double2* b3;              // [systems][n0][F1]  (Hermitian kernel: row transforms of the current direction)
+    int spec_lds;             // Hermitian kernel: the workgroup's slice of the spectrum lives in LDS (cols_wg == lpbc)
     double* partial;          // [systems][3][kCoopMaxG]
     unsigned* bar;            // [systems] arrival counters, 64 bytes apart, zero at launch
     int* iters;               // [systems]
@@ -1375,6 +1392,15 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
     double2* tw0s = F0 == F1 ? tw1s : tw1s + F1;
     load_twiddles(tw1s, a.tw1, F1);
     if (F0 != F1) load_twiddles(tw0s, a.tw0, F0);
+    // the real spectra of this workgroup's column pairs, [t0][pair] as (S_a, S_b): read inside every column phase
+    double2* specL = tw0s + F0;
+    if (a.spec_lds) {
+        const int c_first = wg * a.cols_wg;
+        for (int w = tid; w < F0 * a.lpbc; w += kLineThreads) {
+            const int k = w / a.lpbc, l = w - k * a.lpbc;
+            specL[w] = make_double2(a.vhat[(int64_t)k * F1 + c_first + l].x, a.vhat[(int64_t)k * F1 + c_first + l + (F1 >> 1)].x);
+        }
+    }
     __syncthreads();
     const int64_t M = a.g.M;
     const int r0 = wg * a.rows_wg;                            // first owned row k0
@@ -1523,7 +1549,8 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
             }
             __syncthreads();
             COOP_STAMP(4);
-            double2* X = line_fft_fast_mul2(A, B, F0, ldc, a.lpbc, tw0s, a.vhat + c0, F1, halfF1, cs);
+            double2* X = a.spec_lds ? line_fft_fast_mul4(A, B, F0, ldc, a.lpbc, tw0s, specL, a.lpbc, cs)
+                                    : line_fft_fast_mul2(A, B, F0, ldc, a.lpbc, tw0s, a.vhat + c0, F1, halfF1, cs);
             double2* Y = X == A ? B : A;
             const double2* Z = line_fft_fast(X, Y, F0, ldc, a.lpbc, tw0s);    // Z = conj T (T = packed, halved result)
             COOP_STAMP(5);
@@ -2549,7 +2576,12 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
         return (2 * bufsz + (size_t)F1 + (F0 == F1 ? 0 : (size_t)F0)) * sizeof(double2);
     };
     while (lines > 1 && lds_for(lines) + 2048 > (size_t)ctx->max_lds) --lines;
-    const size_t lds = lds_for(lines);
+    size_t lds = lds_for(lines);
+    // Hermitian, one column pass per workgroup: its slice of the spectrum stays in LDS (16-32 KB)
+    const size_t spec_bytes = (size_t)F0 * lpbc * sizeof(double2);
+    const bool spec_lds = herm && cols_wg == lpbc && lds + spec_bytes + 2048 <= (size_t)ctx->max_lds &&
+                          std::getenv("EFGP_NO_COOP_SPEC_LDS") == nullptr;
+    if (spec_lds) lds += spec_bytes;
     shape_ok = shape_ok && lds + 2048 <= (size_t)ctx->max_lds && G <= ctx->num_cu &&
                (herm ? lpbc * nrow <= (kCoopLoads / 2) * kLineThreads : lpbc * F0 <= kCoopLoads * kLineThreads);
     if (!shape_ok) return EFGP_EUNSUPPORTED;
@@ -2579,6 +2611,7 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     ca.b1 = pad;
     ca.b2 = pad + grid_elems;
     ca.b3 = pad + 2 * grid_elems;
+    ca.spec_lds = spec_lds ? 1 : 0;
     ca.partial = (double*)scb;
     ca.bar = (unsigned*)(scb + off_bar);
     ca.status = (int*)(scb + off_status);
