@@ -606,6 +606,8 @@ __device__ __forceinline__ void wave_sync_lds() {
 // multiplied by the REAL spectra Re mul[k * mul_stride + l] and Re mul[k * mul_stride + l + mul_pair], halved (the unpacking
 // behind the inverse transform adds two terms) and conjugated; the return value is sum S_a re^2 + S_b im^2.
 // MUL = 3: the same with `mul` pointing at an array of REAL spectrum values (3-D Hermitian iteration: half the bytes).
+// MUL = 5: the thread's eight spectrum pairs are handed in (`mul` = its register array, filled by spectrum_prefetch<R> before the
+// data of the lines was even loaded: 3-D mid0 kernel, one pass of <= 256 / (8 R) lines).
 // MUL = 4: the same with the two real spectra of every line already in LDS as double2 pairs, `mul`[k * mul_stride + l] (the
 // cooperative Hermitian solve keeps its workgroup's slice there: no global round trip inside the transform).
 template <int R, int MUL = 0>
@@ -641,7 +643,9 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
                 const int lq = act ? l0 + lsub : l0;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    if (MUL == 4) {
+                    if (MUL == 5) {
+                        mv[t] = mul[t];
+                    } else if (MUL == 4) {
                         mv[t] = mul[(j + 8 * t) * (int)mul_stride + lq];
                     } else if (MUL == 3) {
                         const double* rs = reinterpret_cast<const double*>(mul);
@@ -686,7 +690,9 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int q = 0; q < R; ++q) {
-                    if (MUL == 4) {
+                    if (MUL == 5) {
+                        mv[u * R + q] = mul[u * R + q];
+                    } else if (MUL == 4) {
                         mv[u * R + q] = mul[(li + LPL * u + 64 * q) * (int)mul_stride + lq];
                     } else if (MUL == 3) {
                         const double* rs = reinterpret_cast<const double*>(mul);
@@ -806,6 +812,24 @@ __device__ __forceinline__ double2* line_fft_fast_mul3(double2* src, double2* ds
     else if (F == 256) line_fft_inwave_call<4, 3>(so, dn, ld, nl, to, mul, stride, pair);
     else line_fft_inwave_call<8, 3>(so, dn, ld, nl, to, mul, stride, pair);
     return dst;
+}
+// the (S_a, S_b) pairs line_fft_inwave<R, 2..4> would read for this thread in its single pass over nl <= 256 / (8 R) lines
+template <int R>
+__device__ __forceinline__ void spectrum_prefetch(const double* __restrict__ spec, int64_t stride, int64_t pair, int nl, double2 (&pre)[8]) {
+    constexpr int LPL = 8 * R, U = R > 1 ? 8 / R : 1;
+    const int li = threadIdx.x & (LPL - 1), lsub = threadIdx.x / LPL;
+    const int lq = lsub < nl ? lsub : 0;
+    if (R == 1) {
+        const int j = li & 7;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) pre[t] = make_double2(spec[(int64_t)(j + 8 * t) * stride + lq], spec[(int64_t)(j + 8 * t) * stride + lq + pair]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < R; ++q)
+                pre[u * R + q] = make_double2(spec[(int64_t)(li + LPL * u + 64 * q) * stride + lq], spec[(int64_t)(li + LPL * u + 64 * q) * stride + lq + pair]);
+    }
 }
 // in-wave transform for the lengths it covers, the generic Stockham stages otherwise; the result buffer is returned
 __device__ __forceinline__ double2* line_fft_any(double2* A, double2* B, int F, int ld, int nl, const double2* tw) {
@@ -2058,6 +2082,16 @@ __global__ __launch_bounds__(kLineThreads) void cg3h_mid0_kernel(Line3HArgs a) {
     double2* A = lsm;
     double2* B = lsm + L * ld;
     double2* tws = B + L * ld;
+    // the spectrum values this thread multiplies by behind the first transform: requested before anything else, so that their
+    // round trip runs beside the load of the lines and the transform instead of inside it
+    const double* spec = a.vc + (int64_t)t1 * F2 + c0;
+    const bool pre_ok = (F0 == 64 && L <= 32) || (F0 == 128 && L <= 16) || (F0 == 256 && L <= 8);
+    double2 pre[8];
+    if (pre_ok) {
+        if (F0 == 64) spectrum_prefetch<1>(spec, (int64_t)F1 * F2, halfF2, L, pre);
+        else if (F0 == 128) spectrum_prefetch<2>(spec, (int64_t)F1 * F2, halfF2, L, pre);
+        else spectrum_prefetch<4>(spec, (int64_t)F1 * F2, halfF2, L, pre);
+    }
     load_twiddles(tws, a.tw[0], F0);
     double2* b2 = a.b2 + (int64_t)slot * nh * F1 * F2;
     for (int w = threadIdx.x; w < ((F0 - 2 * h0 - 1) << lgL); w += kLineThreads) {           // zeros between the two ends
@@ -2077,8 +2111,13 @@ __global__ __launch_bounds__(kLineThreads) void cg3h_mid0_kernel(Line3HArgs a) {
     }
     __syncthreads();
     double2* X;
-    if (F0 == 64 || F0 == 128 || F0 == 256 || F0 == 512) {
-        X = line_fft_fast_mul3(A, B, F0, ld, L, tws, a.vc + (int64_t)t1 * F2 + c0, (int64_t)F1 * F2, halfF2);
+    if (pre_ok) {
+        if (F0 == 64) line_fft_inwave<1, 5>(A, B, ld, L, tws, pre);
+        else if (F0 == 128) line_fft_inwave<2, 5>(A, B, ld, L, tws, pre);
+        else line_fft_inwave<4, 5>(A, B, ld, L, tws, pre);
+        X = B;
+    } else if (F0 == 64 || F0 == 128 || F0 == 256 || F0 == 512) {
+        X = line_fft_fast_mul3(A, B, F0, ld, L, tws, spec, (int64_t)F1 * F2, halfF2);
     } else {
         X = line_fft(A, B, F0, ld, L, tws);
         for (int w = threadIdx.x; w < (F0 << lgL); w += kLineThreads) {
