@@ -41,6 +41,11 @@ struct OwnFftPass {
     // indices lie in [slow_lo, slow_lo + slow_cnt) are transformed; nouter counts those lines (times the batch)
     int nslow;
     int64_t slow_ext[2], slow_lo[2], slow_cnt[2];
+    // contiguous first pass of a type-1 transform straight from the spreaders' int64 accumulator (FftAccSource), or null
+    long long* acc;
+    int acc_channels, acc_reset;
+    int64_t acc_cells;
+    const double* acc_scale;
 };
 __device__ __forceinline__ int64_t decode_outer(const OwnFftPass& a, int64_t oc) {
     if (a.nslow == 0) return oc;
@@ -124,6 +129,22 @@ __global__ __launch_bounds__(kFftThreads) void own_fft_pass_kernel(OwnFftPass a)
         nl = (int)min((int64_t)L, a.nouter - oc);
         if (tid < nl) lineo[tid] = decode_outer(a, oc + tid);
         __syncthreads();
+        if (a.acc) {                 // fixed-point accumulator -> complex values (reduce_slabs_kernel<true>'s conversion), full lines
+            const int64_t per_batch = a.acc_cells / n;
+            const double s0 = a.acc_scale[1], s1 = a.acc_scale[3];
+            for (int w = tid; w < nl * n; w += kFftThreads) {
+                const int l = w / n, p = w - l * n;
+                const int64_t b = lineo[l] / per_batch, line = lineo[l] - b * per_batch;
+                long long* c0 = a.acc + b * a.acc_channels * a.acc_cells + line * n + p;
+                double2 v = make_double2((double)c0[0] * s0, a.acc_channels == 2 ? (double)c0[a.acc_cells] * s1 : 0.0);
+                if (a.acc_reset) {
+                    c0[0] = 0;
+                    if (a.acc_channels == 2) c0[a.acc_cells] = 0;
+                }
+                if (a.backward) v.y = -v.y;
+                X[l * ld + p] = v;
+            }
+        } else
         for (int w = tid; w < nl * n; w += kFftThreads) {
             const int l = w / n, p = w - l * n;
             const int q = stored_index(p, n, a.n_src);
@@ -251,7 +272,7 @@ struct SlowWindow {
     int64_t ext[2] = {1, 1}, lo[2] = {0, 0}, cnt[2] = {1, 1};
 };
 static int launch_pass(DeviceCtx* ctx, const double2* src, double2* dst, int64_t len, int64_t n_src, int64_t n_dst, int64_t stride, int64_t outer,
-                       bool forward, hipStream_t stream, const SlowWindow* win = nullptr) {
+                       bool forward, hipStream_t stream, const SlowWindow* win = nullptr, const FftAccSource* acc = nullptr) {
     static bool attr_set = false;
     if (!attr_set) {
         EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)own_fft_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (kFftMaxLine + 1) * (int)sizeof(double2)));
@@ -270,6 +291,11 @@ static int launch_pass(DeviceCtx* ctx, const double2* src, double2* dst, int64_t
     p.nouter = outer;
     p.ld = (int)len + 1;
     p.backward = forward ? 0 : 1;
+    p.acc = acc ? acc->acc : nullptr;
+    p.acc_channels = acc ? acc->channels : 0;
+    p.acc_reset = acc ? acc->reset : 0;
+    p.acc_cells = acc ? acc->cells : 0;
+    p.acc_scale = acc ? acc->scale : nullptr;
     p.nslow = win ? win->nslow : 0;
     for (int q = 0; q < 2; ++q) {
         p.slow_ext[q] = win ? win->ext[q] : 1;
@@ -341,8 +367,9 @@ int own_fft_exec_windowed(DeviceCtx* ctx, int rank, const int64_t* n, int64_t ba
 // them reads the small result.  `fine` is destroyed; the result lands in `work` or `fine` (returned through *out).
 // work: >= batch * prod_{a < rank-1} nf[a] * nc[rank-1] elements.
 int own_fft_pruned_forward(DeviceCtx* ctx, int rank, const int64_t* nf, const int64_t* nc, int64_t batch, double2* fine, double2* work,
-                           bool forward, double2** out, hipStream_t stream) {
+                           bool forward, double2** out, hipStream_t stream, const FftAccSource* acc) {
     if (!own_fft_supported(rank, nf)) return EFGP_EUNSUPPORTED;
+    if (acc && nf[rank - 1] == 1) return EFGP_EUNSUPPORTED;       // the accumulator is read by the pass along the contiguous axis
     int64_t cur[3];
     for (int a = 0; a < rank; ++a) cur[a] = nf[a];
     double2* src = fine;
@@ -352,8 +379,10 @@ int own_fft_pruned_forward(DeviceCtx* ctx, int rank, const int64_t* nf, const in
         for (int q = 0; q < ax; ++q) outer *= cur[q];
         const int64_t keep = std::min(nc[ax], nf[ax]);
         if (nf[ax] == 1) continue;
-        double2* dst = keep == nf[ax] ? src : (src == fine ? work : fine);
-        const int rc = launch_pass(ctx, src, dst, nf[ax], nf[ax], keep, stride, outer, forward, stream);
+        const bool from_acc = acc && ax == rank - 1;             // out of place by nature: the complex values go to `fine` / `work`
+        double2* dst = (keep == nf[ax] && !from_acc) ? src : (src == fine && !from_acc ? work : fine);
+        if (from_acc && keep < nf[ax]) dst = work;
+        const int rc = launch_pass(ctx, src, dst, nf[ax], nf[ax], keep, stride, outer, forward, stream, nullptr, from_acc ? acc : nullptr);
         if (rc != EFGP_OK) return rc;
         cur[ax] = keep;
         src = dst;

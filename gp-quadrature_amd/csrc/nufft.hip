@@ -2772,9 +2772,22 @@ static int g2m_launch(DeviceCtx* ctx, const GridGeom& g, G2MRequest* req, long l
 }
 
 // the reduced fine grids of the other spreaders: one-launch pruned DFT when the grid is small, else the FFT in place
+// `acc` != null: the caller's spread left its sums in the int64 accumulator and has NOT converted them to `fine`; the pruned
+// transform's first pass reads (and, if asked, clears) the accumulator itself -- one pass over the grid less per type-1
+// transform (reduce_slabs_kernel: 197 us of a 3-D pair transform at 240^3); every other route converts first.
 static int transform_fine(efgp_nufft_s* plan, const GridGeom& g, double2* fine, int nbatch, int isign, hipStream_t stream,
-                          G2MRequest* req, const double* scale, double2** fine_out) {
+                          G2MRequest* req, const double* scale, double2** fine_out, const FftAccSource* acc = nullptr) {
+    auto convert = [&]() -> int {
+        if (!acc) return EFGP_OK;
+        const int rb = (int)((g.cells + 63) / 64);
+        hipLaunchKernelGGL((reduce_slabs_kernel<true>), dim3(rb, nbatch), dim3(512), 0, stream, (const double*)acc->acc, 1, acc->channels,
+                           g.cells, acc->scale, fine, acc->reset);
+        EFGP_HIP_CHECK(hipGetLastError());
+        return EFGP_OK;
+    };
     if (g2m_eligible(plan, g, req)) {
+        const int rcc = convert();
+        if (rcc != EFGP_OK) return rcc;
         *fine_out = nullptr;
         return g2m_launch(plan->ctx, g, req, nullptr, fine, scale, 2, nbatch, isign, nullptr, 0, stream);
     }
@@ -2794,7 +2807,12 @@ static int transform_fine(efgp_nufft_s* plan, const GridGeom& g, double2* fine, 
             double2* work = (double2*)scratch(plan->ctx, SLOT_FFT_WORK, (size_t)wk * sizeof(double2));
             if (!work) return EFGP_ENOMEM;
             double2* res = nullptr;
-            const int rcp = own_fft_pruned_forward(plan->ctx, plan->dim, g.nf, nc, nbatch, fine, work, isign < 0, &res, stream);
+            const bool fuse = acc && g.nf[plan->dim - 1] > 1 && std::getenv("EFGP_NO_FFT_FROM_ACC") == nullptr;
+            if (!fuse) {
+                const int rcc = convert();
+                if (rcc != EFGP_OK) return rcc;
+            }
+            const int rcp = own_fft_pruned_forward(plan->ctx, plan->dim, g.nf, nc, nbatch, fine, work, isign < 0, &res, stream, fuse ? acc : nullptr);
             if (rcp != EFGP_OK) return rcp;
             req->cropped = true;
             for (int a = 0; a < 3; ++a) req->crop_nf[a] = nc[a];
@@ -2802,6 +2820,8 @@ static int transform_fine(efgp_nufft_s* plan, const GridGeom& g, double2* fine, 
             return EFGP_OK;
         }
     }
+    const int rcc = convert();
+    if (rcc != EFGP_OK) return rcc;
     const int rc = fft_c2c(plan->ctx, plan->dim, g.nf, nbatch, fine, isign < 0, stream);      // in-house line kernels, hipFFT beyond their sizes
     if (rc != EFGP_OK) return rc;
     *fine_out = fine;
@@ -2886,12 +2906,9 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
             *fine_out = nullptr;
             return EFGP_OK;
         }
-        const int rb = (int)((g.cells + 63) / 64);
-        hipLaunchKernelGGL((reduce_slabs_kernel<true>), dim3(rb, nbatch), dim3(512), 0, stream, (const double*)gacc, 1,
-                           channels, g.cells, (const double*)d_scale, fine, 1);
-        EFGP_HIP_CHECK(hipGetLastError());
+        const FftAccSource accsrc{(long long*)gacc, channels, g.cells, (const double*)d_scale, 1};     // converted (and cleared) by whoever reads it
         ctx->slabs_zero_bytes = acc_bytes;
-        return transform_fine(plan, g, fine, nbatch, isign, stream, req, scale_out ? *scale_out : nullptr, fine_out);
+        return transform_fine(plan, g, fine, nbatch, isign, stream, req, scale_out ? *scale_out : nullptr, fine_out, &accsrc);
     }
     // 2-D with many points per fine-grid cell: register accumulation over base-cell-sorted points
     {
@@ -2955,6 +2972,8 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         int rc = get_bins(plan, tg, channels, stream, &bins);
         if (rc != EFGP_OK) return rc;
         const size_t acc_bytes = (size_t)nbatch * channels * (size_t)g.cells * sizeof(long long);
+        const size_t known_zero = ctx->slabs_zero_bytes;
+        const void* slabs_before = ctx->buf[SLOT_SLABS];
         long long* gacc = (long long*)scratch(ctx, SLOT_SLABS, acc_bytes);
         double2* fine = (double2*)scratch(ctx, SLOT_FINE, (size_t)nbatch * (size_t)g.cells * sizeof(double2));
         char* misc = scale_slot(ctx, stream);
@@ -2962,7 +2981,8 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
         double* d_scale = (double*)misc;
         unsigned long long* d_cmax = (unsigned long long*)(misc + 56);
         if (scale_out) *scale_out = d_scale;
-        EFGP_HIP_CHECK(hipMemsetAsync(gacc, 0, acc_bytes, stream));
+        // the kernel that converts the accumulator clears what it reads: back-to-back passes need no memset launch
+        if (known_zero < acc_bytes || slabs_before != (const void*)gacc) EFGP_HIP_CHECK(hipMemsetAsync(gacc, 0, acc_bytes, stream));
         // the global int64 grid sums over ALL points: bound the scale with N instead of points per workgroup
         const ScaleJob job{floor_bound, mode == STR_REAL_AND_ONES ? 1 : 0, plan->npts, d_scale, 61};
         if (need_max) {
@@ -3003,11 +3023,9 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
             set_error("tiled spread kernel launch failed: %s", hipGetErrorString(e));
             return EFGP_EHIP;
         }
-        const int blocks = (int)((g.cells + 63) / 64);
-        hipLaunchKernelGGL((reduce_slabs_kernel<true>), dim3(blocks, nbatch), dim3(512), 0, stream, (const double*)gacc, 1,
-                           channels, g.cells, (const double*)d_scale, fine);
-        EFGP_HIP_CHECK(hipGetLastError());
-        return transform_fine(plan, g, fine, nbatch, isign, stream, req, scale_out ? *scale_out : nullptr, fine_out);
+        const FftAccSource accsrc{gacc, channels, g.cells, (const double*)d_scale, 1};     // converted (and cleared) by whoever reads it
+        ctx->slabs_zero_bytes = acc_bytes;
+        return transform_fine(plan, g, fine, nbatch, isign, stream, req, scale_out ? *scale_out : nullptr, fine_out, &accsrc);
     }
     int nwg = 1;
     if (use_lds) {
