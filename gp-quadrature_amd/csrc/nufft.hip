@@ -2039,7 +2039,9 @@ static int get_window(efgp_nufft_s* plan, const int64_t* n_modes, hipStream_t st
     // from 4e6 points on a 2-D plan takes the finer grid / narrower window (N = 1e7, mtot = 23: spread + gather 316 -> 276 us on
     // the same box).  The accumulator -> modes step behind them grows with the grid: as ONE launch it went from 20 to 47-60 us
     // (180 x 180 cells) and ate the gain -- the two-launch form (grid_rows_kernel + rows_modes_kernel) takes 12 / 17 us.
-    const bool dense = d == 2 && plan->npts >= kDensePoints && std::getenv("EFGP_NO_DENSE_SIGMA") == nullptr;
+    const char* dense_env = std::getenv("EFGP_DENSE_POINTS");           // experiments: another threshold for the dense-sigma rule
+    const int64_t dense_from = dense_env ? std::max<int64_t>(1, std::atoll(dense_env)) : kDensePoints;
+    const bool dense = d == 2 && plan->npts >= dense_from && std::getenv("EFGP_NO_DENSE_SIGMA") == nullptr;
     for (void* vp : plan->ctx->window_cache) {
         WindowSet* w = (WindowSet*)vp;
         bool same = w->dim == d && w->tol == plan->tol && w->dense == dense;
