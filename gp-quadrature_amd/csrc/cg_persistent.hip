@@ -1234,6 +1234,196 @@ __global__ __launch_bounds__(h64::kThreadsH) void cg_herm64_kernel(Args a) {
     if (tid == 0) a.iters[row] = it;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1-D systems (round 3): the whole solve in ONE WAVE per system.  cg_persistent_kernel above spends ~8 us per iteration on a
+// 1-D block of 63 unknowns (BASELINE configs[0] is such a model: mtot 35, F = 128): its passes are built for grids -- 1024
+// threads, a workgroup barrier per radix stage, two-level block reductions -- and a single 128-point line leaves all but a few
+// lanes idle at every barrier.  Here a system is one wave: the vectors in registers (<= 4 entries per lane: n <= 255, F <= 512),
+// the line transform a radix-4 / radix-2 Stockham ping-pong in LDS with wave-level synchronisation only, the spectrum and the
+// twiddles resident in LDS, dot products by wave reductions.  Same operator (zero-padded input at [0, n), product read at
+// [n - 1, 2 n - 1)), recurrences and stopping rules as cg_persistent_kernel (cg.py:86-244).
+// ------------------------------------------------------------------------------------------------
+namespace l1d {
+constexpr int KS = 4;
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// forward transform of the F-point line in `x` (F = 2^lg), scratch `y`; twiddles tw[q] = exp(-2 pi i q / F); returns the buffer
+// that holds the result (natural order).  All 64 lanes of the wave take part.
+__device__ __forceinline__ double2* wave_fft(double2* x, double2* y, int F, int lg, const double2* __restrict__ tw) {
+    const int lane = threadIdx.x;
+    int Ns = 1, rem = lg;
+    while (rem >= 2) {
+        const int nb = F >> 2, tstep = F / (Ns * 4);
+        for (int j = lane; j < nb; j += 64) {
+            const int k = j & (Ns - 1), j0 = ((j - k) << 2) + k;
+            double2 v0 = x[j], v1 = x[j + nb], v2 = x[j + 2 * nb], v3 = x[j + 3 * nb];
+            if (k != 0) {
+                v1 = cmulp(v1, tw[k * tstep]);
+                v2 = cmulp(v2, tw[2 * k * tstep]);
+                v3 = cmulp(v3, tw[3 * k * tstep]);
+            }
+            const double2 t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3), d13 = csub(v1, v3);
+            const double2 t3 = make_double2(d13.y, -d13.x);              // (v1 - v3) * (-i)
+            y[j0] = cadd(t0, t2);
+            y[j0 + Ns] = cadd(t1, t3);
+            y[j0 + 2 * Ns] = csub(t0, t2);
+            y[j0 + 3 * Ns] = csub(t1, t3);
+        }
+        wave_sync();
+        double2* t = x;
+        x = y;
+        y = t;
+        Ns <<= 2;
+        rem -= 2;
+    }
+    if (rem == 1) {
+        const int nb = F >> 1;                                           // Ns = F / 2: tstep = 1
+        for (int j = lane; j < nb; j += 64) {
+            const int k = j & (Ns - 1), j0 = ((j - k) << 1) + k;
+            const double2 v0 = x[j];
+            double2 v1 = x[j + nb];
+            if (k != 0) v1 = cmulp(v1, tw[k]);
+            y[j0] = cadd(v0, v1);
+            y[j0 + Ns] = csub(v0, v1);
+        }
+        wave_sync();
+        double2* t = x;
+        x = y;
+        y = t;
+    }
+    return x;
+}
+}  // namespace l1d
+
+__global__ __launch_bounds__(64) void cg_line1d_kernel(Args a) {
+    using namespace l1d;
+    extern __shared__ double2 lds2[];
+    const int F = a.g.F[0], n = a.g.n[0], M = a.g.M;
+    const int lg = 31 - __clz(F);
+    double2* const X = lds2;
+    double2* const Y = lds2 + F;
+    double2* const TW = Y + F;
+    double2* const VH = TW + F;
+    const int lane = threadIdx.x, row = blockIdx.x;
+    const int64_t base = (int64_t)row * M;
+    for (int q = lane; q < F; q += 64) {
+        TW[q] = a.g.tw[0][q];
+        VH[q] = a.vhat[q];
+    }
+    double2 xv[KS], rv[KS], pv[KS], wsv[KS];
+    double dg[KS];
+    const bool precond = a.diag != nullptr || a.diag_scale != nullptr;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int t = lane + 64 * s;
+        if (t < M) {
+            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x[base + t];
+            wsv[s] = a.ws[t];
+            dg[s] = jacobi_entry(a, wsv[s], t);
+        } else {
+            xv[s] = wsv[s] = make_double2(0.0, 0.0);
+            dg[s] = 1.0;
+        }
+        rv[s] = pv[s] = make_double2(0.0, 0.0);
+    }
+    wave_sync();
+    auto apply_A = [&](const double2 (&u)[KS], double2 (&Au)[KS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int t = lane + 64 * s;
+            if (t < M) X[t] = cmulp(wsv[s], u[s]);
+        }
+        for (int q = n + lane; q < F; q += 64) X[q] = make_double2(0.0, 0.0);
+        wave_sync();
+        double2* R = wave_fft(X, Y, F, lg, TW);
+        double2* O = R == X ? Y : X;
+        for (int q = lane; q < F; q += 64) {
+            const double2 m = cmulp(R[q], VH[q]);
+            R[q] = make_double2(m.x, -m.y);                               // conjugate: the inverse transform by a forward one
+        }
+        wave_sync();
+        const double2* Z = wave_fft(R, O, F, lg, TW);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int t = lane + 64 * s;
+            if (t < M) {
+                const double2 z = Z[n - 1 + t];
+                const double2 gg = cmulp(wsv[s], make_double2(z.x, -z.y));
+                if (a.variant == 0) Au[s] = make_double2(gg.x + a.sigmasq * u[s].x, gg.y + a.sigmasq * u[s].y);
+                else Au[s] = make_double2(gg.x / a.sigmasq + u[s].x, gg.y / a.sigmasq + u[s].y);
+            } else {
+                Au[s] = make_double2(0.0, 0.0);
+            }
+        }
+        wave_sync();                                                      // the buffers are rewritten by the next application
+    };
+    double2 Ap[KS];
+    if (a.zero_x0) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) Ap[s] = make_double2(0.0, 0.0);
+    } else {
+        apply_A(xv, Ap);
+    }
+    double rz = 0.0, bb = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int t = lane + 64 * s;
+        if (t < M) {
+            double2 bv = a.b[base + t];
+            if (a.b_times_ws) bv = cmulp(wsv[s], bv);
+            rv[s] = csub(bv, Ap[s]);
+            pv[s] = precond ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            rz += rv[s].x * pv[s].x + rv[s].y * pv[s].y;
+            bb += bv.x * bv.x + bv.y * bv.y;
+        }
+    }
+    rz = wave_sum(rz);
+    bb = wave_sum(bb);
+    const double bn = sqrt(bb);
+    const double den = bn > 0.0 ? bn : 1.0;
+    int it = 0;
+    for (; it < a.max_iter;) {
+        apply_A(pv, Ap);
+        double pAp = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pAp += pv[s].x * Ap[s].x + pv[s].y * Ap[s].y;
+        pAp = wave_sum(pAp) + 1e-16;
+        const double alpha = rz / pAp;
+        double rr = 0.0, rzn = 0.0;
+        double2 zv[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            xv[s].x += alpha * pv[s].x;
+            xv[s].y += alpha * pv[s].y;
+            rv[s].x -= alpha * Ap[s].x;
+            rv[s].y -= alpha * Ap[s].y;
+            zv[s] = precond ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            rr += rv[s].x * rv[s].x + rv[s].y * rv[s].y;
+            rzn += rv[s].x * zv[s].x + rv[s].y * zv[s].y;
+        }
+        rr = wave_sum(rr);
+        rzn = wave_sum(rzn);
+        ++it;
+        const double rnorm = sqrt(rr);
+        if (a.hist && row == 0 && lane == 0 && it <= a.hist_cap) a.hist[it - 1] = rnorm / (den + 1e-16);
+        const bool conv = a.early_stop && ((rnorm / (den + 1e-16) < a.tol) || (a.batched && rnorm < 1e-12));
+        if (!a.batched && conv) break;                  // cg.py:132 (before the preconditioner / p update)
+        const double beta = rzn / (rz + 1e-16);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pv[s] = make_double2(zv[s].x + beta * pv[s].x, zv[s].y + beta * pv[s].y);
+        rz = rzn;
+        if (conv) break;                                // cg.py:229-241 (after the p update)
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int t = lane + 64 * s;
+        if (t < M) a.x[base + t] = xv[s];
+    }
+    if (lane == 0) a.iters[row] = it;
+}
+
 // Spectrum of the Toeplitz vector for the 64 x 64 circulant grid in ONE launch (efgpnd.py:1283-1290: pad to the FFT
 // box, forward fftn): `factor * v` zero-padded into LDS, four radix-8 Stockham stages as in the solver above, result
 // in natural order.  Replaces pad_scale_kernel + two rocFFT launches (~14 us of dependent 4-5 us launches per fit).
@@ -1820,6 +2010,10 @@ int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, con
         KernelTimer timer("cg_solve", stream);
         if (variant == 0) hipLaunchKernelGGL(cg_herm64_kernel<0>, dim3(rows), dim3(h64::kThreadsH), lds_h, stream, a);
         else hipLaunchKernelGGL(cg_herm64_kernel<1>, dim3(rows), dim3(h64::kThreadsH), lds_h, stream, a);
+    } else if (tg.d == 1 && !lz && g.n[0] <= 64 * l1d::KS - 1 && g.F[0] >= 8 && g.F[0] <= 512 && (g.F[0] & (g.F[0] - 1)) == 0 &&
+               std::getenv("EFGP_NO_CG_LINE1D") == nullptr) {
+        KernelTimer timer("cg_solve", stream);             // 1-D: one wave per system
+        hipLaunchKernelGGL(cg_line1d_kernel, dim3(rows), dim3(64), (size_t)4 * g.F[0] * sizeof(double2), stream, a);
     } else if (fast64) {
         static bool attr64 = false;
         if (!attr64) {
