@@ -116,48 +116,70 @@ int es_make_params(double tol, double sigma, EsParams* p) {
     return 0;
 }
 
+namespace {
+// Gauss-Legendre nodes and weights on [-1, 1] (Newton iteration on P_n), computed once per process
+struct GaussLegendre96 {
+    static constexpr int nq = 96;
+    long double xs[nq], wt[nq];
+    GaussLegendre96() {
+        const long double pi = acosl(-1.0L);
+        for (int i = 0; i < nq; ++i) {
+            long double x = cosl(pi * (i + 0.75L) / (nq + 0.5L));
+            long double dp = 1;
+            for (int it = 0; it < 100; ++it) {
+                long double p0 = 1.0L, p1 = x;
+                for (int k = 2; k <= nq; ++k) {
+                    long double pk = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k;
+                    p0 = p1; p1 = pk;
+                }
+                dp = nq * (x * p1 - p0) / (x * x - 1.0L);
+                long double dx = p1 / dp;
+                x -= dx;
+                if (fabsl(dx) < 1e-19L) break;
+            }
+            {   // recompute derivative at the converged node
+                long double p0 = 1.0L, p1 = x;
+                for (int k = 2; k <= nq; ++k) {
+                    long double pk = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k;
+                    p0 = p1; p1 = pk;
+                }
+                dp = nq * (x * p1 - p0) / (x * x - 1.0L);
+            }
+            xs[i] = x;
+            wt[i] = 2.0L / ((1.0L - x * x) * dp * dp);
+        }
+    }
+};
+}  // namespace
+
 void es_deconv_factors(const EsParams& p, int64_t nf, int64_t n_modes, std::vector<double>* out) {
-    // Gauss-Legendre on [0,1] (integrand even); nodes by Newton iteration on P_n.
-    const int nq = 96;
-    std::vector<long double> xs(nq), wt(nq);
+    // Gauss-Legendre on [0,1] (integrand even).  Round 3: a training loop that changes the mode count at every step (1-D models)
+    // spent 2.5-6.7 ms per window here -- 96 expl + sqrtl + cosl per mode.  The window values at the nodes do not depend on the
+    // mode and the factor is even in it: same operations on the same operands as before (bit-identical factors), a third of the
+    // transcendentals per mode and half the modes.
+    static const GaussLegendre96 gl;
+    constexpr int nq = GaussLegendre96::nq;
     const long double pi = acosl(-1.0L);
-    for (int i = 0; i < nq; ++i) {
-        long double x = cosl(pi * (i + 0.75L) / (nq + 0.5L));
-        long double dp = 1;
-        for (int it = 0; it < 100; ++it) {
-            long double p0 = 1.0L, p1 = x;
-            for (int k = 2; k <= nq; ++k) {
-                long double pk = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k;
-                p0 = p1; p1 = pk;
-            }
-            dp = nq * (x * p1 - p0) / (x * x - 1.0L);
-            long double dx = p1 / dp;
-            x -= dx;
-            if (fabsl(dx) < 1e-19L) break;
-        }
-        {   // recompute derivative at the converged node
-            long double p0 = 1.0L, p1 = x;
-            for (int k = 2; k <= nq; ++k) {
-                long double pk = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k;
-                p0 = p1; p1 = pk;
-            }
-            dp = nq * (x * p1 - p0) / (x * x - 1.0L);
-        }
-        xs[i] = x;
-        wt[i] = 2.0L / ((1.0L - x * x) * dp * dp);
+    long double zs[nq], tq[nq];
+    for (int q = 0; q < nq; ++q) {
+        // map node from [-1,1] to z in [0,1]:  z = (x+1)/2, weight/2; integrand even -> times 2
+        const long double z = 0.5L * (gl.xs[q] + 1.0L);
+        const long double ph = expl((long double)p.beta * (sqrtl(std::max(0.0L, 1.0L - z * z)) - 1.0L));
+        zs[q] = z;
+        tq[q] = gl.wt[q] * 0.5L * 2.0L * ph;
     }
     out->resize((size_t)n_modes);
     const int64_t kmin = -(n_modes / 2);
     for (int64_t i = 0; i < n_modes; ++i) {
-        long double k = (long double)(kmin + i);
+        const int64_t kk = kmin + i;
+        if (kk > 0 && -kk >= kmin) {                       // the factor of -k is already there (cos is even)
+            (*out)[(size_t)i] = (*out)[(size_t)(-kk - kmin)];
+            continue;
+        }
+        long double k = (long double)kk;
         long double arg = k * p.w * pi / (long double)nf;
         long double acc = 0;
-        for (int q = 0; q < nq; ++q) {
-            // map node from [-1,1] to z in [0,1]:  z = (x+1)/2, weight/2; integrand even -> times 2
-            long double z = 0.5L * (xs[q] + 1.0L);
-            long double ph = expl((long double)p.beta * (sqrtl(std::max(0.0L, 1.0L - z * z)) - 1.0L));
-            acc += wt[q] * 0.5L * 2.0L * ph * cosl(arg * z);
-        }
+        for (int q = 0; q < nq; ++q) acc += tq[q] * cosl(arg * zs[q]);
         long double P = 0.5L * p.w * acc;
         (*out)[(size_t)i] = (double)(1.0L / P);
     }
