@@ -12,13 +12,15 @@ Toeplitz FFT 64^2), NUFFT tol 1e-7, CG tol 1e-4 (the reference's default).
 
 One step = one GP fit + posterior mean at the training points:
   grid construction (host) -> ONE fused spread pass over the points for (F*y, Toeplitz vector) ->
-  rocFFT + deconvolve -> Toeplitz setup -> Jacobi-PCG to tolerance -> type-2 interpolation at x.
+  accumulator -> modes (pruned transforms, no run-time compilation) -> Toeplitz setup -> Jacobi-PCG to tolerance -> type-2 interpolation at x.
 Inputs are resident in HBM before the timed region.  With N GPUs the metric's GLOBAL problem (N = 1e6 points)
 is sharded over the ranks (strong scaling: every rank holds N / n_gpus points, the gridded partial sums are
 all-reduced over RCCL, CG is replicated) and `value` is the true fits/s of that global problem.  Extra keys:
 `weak_scaling` (1e6 points PER rank, fits/s of the n_gpus x 1e6 problem) and `north_star_n1e7` (the
 north_star's N = 1e7, d = 2 configuration: spread / gather / ordering microseconds per launch and their
-fractions of the HBM peak; global N = 1e7 sharded over the ranks = BASELINE configs[3]).
+fractions of the HBM peak; global N = 1e7 sharded over the ranks = BASELINE configs[3]), and -- N = 1 only --
+`other_configs`: BASELINE configs[4] (3-D Matern-3/2, N = 5e6: first fit, refit, gradient step) and the hard case of
+configs[3] (2-D, 256^2 circulant grid: fit, mean) on synthetic data of their shape.
 
 The JSON line also carries `roofline` for the dominant N-scale kernel (the fused spread launch,
 timed with HIP events on its launch stream inside the library) and `cpu_baseline` (the CPU oracle
@@ -122,6 +124,58 @@ def model_costs(dev, x, y):
         return 1e3 * sorted(ts)[len(ts) // 2]
     plain, forced = one("auto"), one(True)
     return {"one_shot_fit_ms": plain, "one_shot_fit_with_layout_ms": forced, "layout_once_ms": forced - plain}
+
+
+def other_configs(dev):
+    """BASELINE configs beyond the headline, one GPU, synthetic data of their shape (extras of the N=1 run, ~3 s):
+    `configs4_3d_n5e6` -- configs[4]: 3-D Matern-3/2 (l = 0.2, eps 1e-3 -> mtot 57, 128^3 circulant grid), N = 5e6: first fit of
+    the process for this model, forced refit (123 CG iterations), hyper-gradient step (Hutchinson trace, T = 2);
+    `configs3_hard_2d_256sq` -- the hard case of configs[3]: 2-D SE l = 0.05 (mtot 71, 256^2 circulant grid), N = 1e6: fit and
+    posterior mean at the N points."""
+    from efgpnd import EFGPND
+    from kernels.matern import Matern
+    from kernels.squared_exponential import SquaredExponential
+
+    def timed(fn, reps):
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize(dev)
+            ts.append(1e3 * (time.perf_counter() - t0))
+        return sorted(ts)[len(ts) // 2]
+
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(21)
+    N3 = 5_000_000
+    x = torch.rand(N3, 3, generator=g, dtype=torch.float64, device=dev) * 2 - 1
+    y = torch.sin(3 * x[:, 0]) * torch.cos(4 * x[:, 1]) * torch.cos(2 * x[:, 2]) + 0.3 * torch.randn(N3, generator=g, dtype=torch.float64, device=dev)
+    m = EFGPND(x, y, Matern(dimension=3, nu=1.5, init_lengthscale=0.2, init_variance=1.5), sigmasq=0.2, eps=1e-3, nufft_eps=1e-6,
+               estimate_params=False, opts={"cg_tolerance": 1e-5, "mean_cg_warm_start": False})
+    first = timed(m.fit, 1)
+    timed(m.fit, 1)
+    refit = timed(m.fit, 3)
+    M = m.last_fit_stats["feature_count"]
+    V = torch.ones(2, M, dtype=torch.float64)
+    V[1, ::2] = -1
+    step = lambda: m.compute_gradients(trace_samples=2, cg_tol=1e-3, probe_seed=99, probes_V=V)    # noqa: E731
+    timed(step, 1)
+    grad = timed(step, 3)
+    out["configs4_3d_n5e6"] = {"first_fit_ms": first, "refit_ms": refit, "gradient_step_ms_T2": grad, "mtot": int(m.last_fit_stats["mtot"]),
+                               "mean_cg_iters": int(m.last_fit_stats["mean_cg_iters"])}
+    del m, x, y
+    x, y = synth(1_000_000, 2, 1000, dev)
+    m = EFGPND(x, y, SquaredExponential(dimension=2, init_lengthscale=0.05, init_variance=2.0), sigmasq=0.2, eps=1e-4, nufft_eps=1e-7,
+               estimate_params=False, opts={"cg_tolerance": 1e-4, "mean_cg_warm_start": False})
+    fit = lambda: m._compute_common_parameters(force_recompute=True)      # noqa: E731
+    mean = lambda: m.predict(x, return_variance=False)                     # noqa: E731
+    for _ in range(3):
+        fit()
+        mean()
+    out["configs3_hard_2d_256sq"] = {"fit_ms": timed(fit, 5), "mean_ms": timed(mean, 5), "mtot": int(m.last_fit_stats["mtot"]),
+                                     "mean_cg_iters": int(m.last_fit_stats["mean_cg_iters"])}
+    return out
 
 
 def north_star(dev, rank, world, distributed, barrier):
@@ -376,6 +430,7 @@ def main():
             del opm
 
     costs = model_costs(dev, x, y) if (world == 1 and rank == 0 and not args.no_extras) else None
+    others = other_configs(dev) if (world == 1 and rank == 0 and not args.no_extras) else None
     # extra legs (every rank takes part: they contain collectives)
     weak = None
     star = None
@@ -467,6 +522,7 @@ def main():
             rec["cg_mid_general_us_per_iter"] = cg_mid_general
         if world == 1 and not args.no_extras:
             rec["model_costs"] = costs
+            rec["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(1000)
         print(json.dumps(rec))
