@@ -3,11 +3,13 @@ vectors produced by the reference's own code (oracle/gen_golden.py).
 
 Tolerance: north_star asks posterior mean / variance within 1e-5 relative (float64).  Quantities
 that feed the solve (F*y, Toeplitz vector) are checked to the NUFFT tolerance requested here (1e-9)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from _golden import load_case, rel
+from _golden import GOLDEN, load_case, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -70,23 +72,30 @@ def test_default_tolerance_iterations(name):
     m.fit()
     it = m.last_fit_stats["mean_cg_iters"]
     ref_it = int(g["iters_1e4"])
-    # Near the loose default tolerance the residual of an ill-conditioned system oscillates around the
-    # threshold for tens of iterations (c3: |r|/|b| dips below 1e-4 at iterations 175, 178, 182, 195, 199, ...), so
-    # the first crossing moves with FFT rounding (rocFFT picks kernels per process).  Exact for short solves;
-    # for long ones a 30 % band plus the defining property: the returned iterate meets the tolerance.
-    if ref_it < 60:
-        assert it == ref_it
+    # Round 3: the band comes from the REFERENCE's own behaviour, stored in the round-3 fixtures (oracle/gen_golden_r3.py): under a
+    # 1e-13 perturbation of its Toeplitz vector the reference itself stops at 195 instead of 175 on c3 (|r|/|b| dips below 1e-4 at
+    # iterations 175, 178, 182, 195, ...), at 152 instead of 150 on c2, and does not move on c1.  Equal counts elsewhere
+    # (+-1 beyond 100 iterations where no such fixture exists); always the defining property: the iterate meets the tolerance.
+    spread, beta_bound = 0, 5e-2
+    r3_path = os.path.join(GOLDEN, name + "_r3.npz")
+    if os.path.exists(r3_path):
+        r3 = np.load(r3_path)
+        spread = abs(int(r3["wfit_iters_1e4"][0]) - int(r3["sens_wfit_iters_1e4"][0]))
+        # beta: 10 x the reference's own move (Toeplitz-vector perturbation, NUFFT results accurate to 1e-11), at most the old 5e-2
+        beta_bound = min(5e-2, 10.0 * max(float(r3["sens_wfit_beta1_1e4"]), float(r3["sens_wfit_nufft_beta1_1e4"])))
+        assert abs(it - ref_it) <= spread + (max(1, int(0.02 * ref_it)) if spread else 0), (name, it, ref_it, spread)
     else:
-        assert 0.7 * ref_it <= it <= 1.3 * ref_it
+        assert abs(it - ref_it) <= (1 if ref_it > 100 else 0), (name, it, ref_it)
     from efgpnd import create_A_mean
     st = m._fit_state
     A = create_A_mean(st["ws"], m._toeplitz, st["sig"], torch.complex128)
     rhs = st["ws"] * st["Fy"]
     res = float(torch.linalg.norm(rhs - A(m._beta)) / torch.linalg.norm(rhs))
     assert res < 1.05e-4
-    # at the loose default tolerance the iterate moves by ~tol*cond when the stop flips by one pass
-    # (SURVEY section 7 "hard parts"); only a coarse agreement is meaningful here
-    assert rel(m._fit_state["ws"] * m._beta, torch.from_numpy(g["ws"]) * torch.from_numpy(g["beta_1e4"])) < 5e-2
+    # at the loose default tolerance the iterate moves by ~tol*cond when the stop flips by one pass (SURVEY section 7 "hard parts")
+    dev_beta = rel(m._fit_state["ws"] * m._beta, torch.from_numpy(g["ws"]) * torch.from_numpy(g["beta_1e4"]))
+    print(f"\n{name}: iterations hip={it} ref={ref_it} (reference's own spread {spread}); ws*beta deviates by {dev_beta:.2e} (bound {beta_bound:.1e})")
+    assert dev_beta < beta_bound
 
 
 @pytest.mark.parametrize("name", ["s1_se2d_n100", "s2_matern12_1d_n200", "c1_se1d_n5000", "c2_se2d_n100000",
