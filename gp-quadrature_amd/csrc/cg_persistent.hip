@@ -1533,7 +1533,7 @@ __global__ __launch_bounds__(kThreads) void fft2d64_batch_kernel(const void* __r
 int fft2d64_batch_launch(const void* src, int src_is_real, int64_t src_stride, int L0, int L1, double2* dst, int64_t dst_stride,
                          int nbatch, hipStream_t stream) {
     using namespace pcg;
-    static bool attr = false;
+    bool& attr = per_device_flag("fft2d64_batch");
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)fft2d64_batch_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e == hipSuccess)
@@ -1565,7 +1565,7 @@ bool toeplitz_vhat_fused_eligible(const ToepGeom& g) {
 
 int toeplitz_vhat_fused_launch(const double2* v, int L0, int L1, double factor, double2* vhat, hipStream_t stream) {
     using namespace pcg;
-    static bool attr = false;
+    bool& attr = per_device_flag("vhat_2d64");
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)toeplitz_vhat_2d64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024 - 256);
@@ -1723,7 +1723,7 @@ bool toeplitz_apply_fused_eligible(const ToepGeom& g) {
 int toeplitz_apply_fused_launch(const ToepGeom& g, const double2* tw64, const double2* vhat, const double2* pre, const double2* post,
                                 const void* x, int x_is_real, double2* y, int rows, hipStream_t stream) {
     using namespace pcg;
-    static bool attr = false;
+    bool& attr = per_device_flag("apply_2d64");
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)toeplitz_apply_2d64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024 - 256);
@@ -1982,7 +1982,7 @@ int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, con
     }
 #endif
     const size_t lds = ((size_t)2 * g.padded + g.tw_lds_total) * sizeof(double2);
-    static bool attr_set = false;
+    bool& attr_set = per_device_flag("cg_persistent");
     if (!attr_set && lds > 65536) {
         hipError_t e = hipFuncSetAttribute((const void*)cg_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024 - 256);
@@ -1996,7 +1996,7 @@ int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, con
                         std::getenv("EFGP_NO_CG64") == nullptr;
     const bool herm64 = fast64 && hermitian && !lz && (g.n[0] & 1) && g.n[0] <= 31 && std::getenv("EFGP_NO_CG_HERM") == nullptr;
     if (herm64) {
-        static bool attr_h = false;
+        bool& attr_h = per_device_flag("cg_herm64");
         const size_t lds_h = (size_t)h64::kLdsElems * sizeof(double2);
         if (!attr_h) {
             hipError_t e2 = hipFuncSetAttribute((const void*)cg_herm64_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
@@ -2015,7 +2015,7 @@ int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, con
         KernelTimer timer("cg_solve", stream);             // 1-D: one wave per system
         hipLaunchKernelGGL(cg_line1d_kernel, dim3(rows), dim3(64), (size_t)4 * g.F[0] * sizeof(double2), stream, a);
     } else if (fast64) {
-        static bool attr64 = false;
+        bool& attr64 = per_device_flag("cg_2d64");
         if (!attr64) {
             hipError_t e2 = hipFuncSetAttribute((const void*)cg_persistent_2d64_kernel,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);

@@ -28,6 +28,13 @@ void set_error(const char* fmt, ...) {
 static std::mutex g_mu;
 static std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
 
+bool& per_device_flag(const char* key) {
+    static std::map<std::pair<int, std::string>, bool> flags;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return flags[std::make_pair(dev, std::string(key))];
+}
+
 DeviceCtx* device_ctx(int device) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_ctx.find(device);
@@ -336,6 +343,11 @@ int efgp_window_width(double tol, double sigma) { return es_width_for_tol(tol, s
 int64_t efgp_fine_grid_size(int64_t n_modes, double tol) {
     if (n_modes < 1) return 0;
     return es_fine_size(n_modes, tol, 2);
+}
+
+int64_t efgp_fine_grid_size_nd(int64_t n_modes, double tol, int dim, int dense) {
+    if (n_modes < 1 || dim < 1 || dim > 3) return 0;
+    return es_fine_size(n_modes, tol, dim, dense != 0);
 }
 
 int efgp_window_eval(double tol, double sigma, double X, int64_t* first_cell_out, double* vals_out, int* w_out,

@@ -95,6 +95,10 @@ struct DeviceCtx {
     hipEvent_t aux_event = nullptr;
 };
 
+// a once-per-DEVICE flag (function attributes such as hipFuncAttributeMaxDynamicSharedMemorySize are per device: a
+// process-wide static would leave the second GPU of a process without them); keyed by a site name, for the current device
+bool& per_device_flag(const char* key);
+
 // returns the context of `device` (creates it, queries properties); nullptr + error on failure
 DeviceCtx* device_ctx(int device);
 // grow-only scratch; synchronises the device before replacing a buffer.  nullptr on failure.

@@ -221,11 +221,17 @@ int64_t es_fine_size(int64_t n_modes, double tol, int dim, bool dense) {
     int64_t pick = best;
     if (2 * n_modes <= coarse_limit && std::getenv("EFGP_DENSE_FINE_SIZES") == nullptr) {
         // the first ladder size that needs no wider a window than the dense choice (the width falls with the ratio)
+        // The width model is not monotone in the ratio beyond the calibrated range (its error constant grows with sigma), so a
+        // ladder size with a window as narrow as the dense choice's need not exist (tol ~ 0.035, n = 40: W = 2 at 100 cells,
+        // W = 3 on 96, 128, 192, ... and at every ratio >= 5): stop where es_make_params clamps the ratio -- the width no
+        // longer changes beyond it -- and keep the dense choice.
         pick = 0;
-        for (int64_t p2 = 32; !pick; p2 *= 2) {
+        for (int64_t p2 = 32; !pick && p2 <= (int64_t)1 << 40; p2 *= 2) {
             for (int64_t c : {p2, p2 + p2 / 2})
                 if (!pick && c >= 2 * n_modes && es_width_for_tol(tol, (double)c / (double)n_modes) <= best_w) pick = c;
+            if ((double)p2 > kSigmaCalibrated * (double)n_modes && p2 >= 2 * n_modes) break;
         }
+        if (!pick) pick = best;
     }
     // Dense 2-D point sets (round 3): when millions of points share a few thousand fine cells the grid is nearly free (the MFMA
     // spreader flushes register tiles into an L2-resident accumulator, the small-grid transforms are dense DFT launches of

@@ -273,9 +273,16 @@ struct SlowWindow {
 };
 static int launch_pass(DeviceCtx* ctx, const double2* src, double2* dst, int64_t len, int64_t n_src, int64_t n_dst, int64_t stride, int64_t outer,
                        bool forward, hipStream_t stream, const SlowWindow* win = nullptr, const FftAccSource* acc = nullptr) {
-    static bool attr_set = false;
+    // the most the L rule below can ask for: one line of the longest length (131104 B) or 150 KB of strided lines
+    constexpr int kPassLdsMax = 150 << 10;
+    static_assert(2 * (kFftMaxLine + 1) * (int)sizeof(double2) <= kPassLdsMax, "a single line must fit the LDS budget");
+    bool& attr_set = per_device_flag("own_fft_pass");
     if (!attr_set) {
-        EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)own_fft_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (kFftMaxLine + 1) * (int)sizeof(double2)));
+        if (kPassLdsMax + 256 > ctx->max_lds) {
+            set_error("own_fft: the device offers %d bytes of LDS per workgroup, the line transform needs %d", ctx->max_lds, kPassLdsMax + 256);
+            return EFGP_EUNSUPPORTED;
+        }
+        EFGP_HIP_CHECK(hipFuncSetAttribute((const void*)own_fft_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPassLdsMax));
         attr_set = true;
     }
     OwnFftPass p;
@@ -306,7 +313,7 @@ static int launch_pass(DeviceCtx* ctx, const double2* src, double2* dst, int64_t
     // (128-byte segments), all of them resident for short lines
     const int64_t bytes_per_line = 2 * (int64_t)p.ld * (int64_t)sizeof(double2);
     int L = (int)std::max<int64_t>(1, (48 << 10) / bytes_per_line);
-    if (stride > 1) L = std::max(L, (int)std::min<int64_t>(8, (150 << 10) / bytes_per_line));
+    if (stride > 1) L = std::max(L, (int)std::min<int64_t>(8, (int64_t)kPassLdsMax / bytes_per_line));
     L = std::min(L, 32);
     const int64_t avail = stride > 1 ? stride : outer;
     L = (int)std::max<int64_t>(1, std::min<int64_t>(L, avail));

@@ -64,13 +64,25 @@ def solve_rows_sharded(shards, rhs, solve):
     R = rhs.shape[0]
     lo, hi = shard_bounds(R, shards.world_size, shards.rank)
     full = torch.zeros_like(rhs)
-    rows = torch.zeros(R, dtype=torch.float64, device=rhs.device)
+    rows = torch.zeros(R + 1, dtype=torch.float64, device=rhs.device)     # [R]: number of ranks whose local solve failed
+    failure = None
     if hi > lo:
-        x, its = solve(rhs[lo:hi])
-        full[lo:hi] = x.reshape(hi - lo, -1)
-        rows[lo:hi] = torch.as_tensor(its, device=rhs.device).to(torch.float64).reshape(-1)
+        # a rank whose solve raises (refused input, out of memory, a HIP error) must still reach the collective -- its peers
+        # would wait in it for ever -- so the failure travels as a flag and EVERY rank raises behind the all-reduce
+        try:
+            x, its = solve(rhs[lo:hi])
+            full[lo:hi] = x.reshape(hi - lo, -1)
+            rows[lo:hi] = torch.as_tensor(its, device=rhs.device).to(torch.float64).reshape(-1)
+        except Exception as err:       # noqa: BLE001 -- re-raised below, on all ranks
+            failure = err
+            full.zero_()
+            rows[R] = 1.0
     shards.sum_many_([full, rows])
-    return full, rows.to(torch.int32)
+    failed = int(rows[R].item()) if (failure is not None or shards.active) else 0
+    if failed:
+        raise RuntimeError(f"efgp_hip: the row-sharded batched solve failed on {failed} of {shards.world_size} ranks"
+                           + (f" (this rank: {failure})" if failure is not None else " (not this one)")) from failure
+    return full, rows[:R].to(torch.int32)
 
 
 class PointShards:
@@ -94,6 +106,21 @@ class PointShards:
     @property
     def active(self):
         return self.enabled and self.world_size > 1
+
+    def agree(self, key, value, device):
+        """A per-rank decision that selects which collectives follow (e.g. whether a batched solve is split by rows: it depends
+        on the environment and on the local device) must be the same on every rank, or the ranks enter mismatched collectives
+        and hang.  Checked once per `key` with one small all-reduce; raises on every rank when the ranks differ."""
+        cache = self.__dict__.setdefault("_agreed", {})
+        if key in cache or not self.active:
+            return value
+        v = float(int(value))
+        tot = self.sum_scalars([v, v * v], device)
+        if abs(tot[0] - v * self.world_size) > 0.5 or abs(tot[1] - v * v * self.world_size) > 0.5:
+            raise RuntimeError(f"efgp_hip: ranks disagree on {key!r} (this rank: {value}); set EFGP_SHARD_ROWS identically on all "
+                               "ranks and use identical devices")
+        cache[key] = value
+        return value
 
     def sum_(self, t):
         """In-place SUM all-reduce of a real or complex tensor (complex goes as interleaved reals)."""

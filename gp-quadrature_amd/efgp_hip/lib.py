@@ -42,6 +42,7 @@ _SIGNATURES = {
     "efgp_window_width": (_I, [_D, _D]),
     "efgp_window_eval": (_I, [_D, _D, _D, _PI64, C.POINTER(_D), C.POINTER(_I), C.POINTER(_D)]),
     "efgp_fine_grid_size": (_I64, [_I64, _D]),
+    "efgp_fine_grid_size_nd": (_I64, [_I64, _D, _I, _I]),
     "efgp_window_deconv": (_I, [_D, _I64, _I64, C.POINTER(_D)]),
     "efgp_nufft_create": (_I, [C.POINTER(_VP), _I, _I, _I64, _VP, C.POINTER(_D), _D, _D]),
     "efgp_nufft_destroy": (_I, [_VP]),

@@ -741,14 +741,19 @@ def _rows_over_ranks(shards, top, R):
     grids take many CUs per system (cooperative launch, multi-kernel 3-D iteration) and go through the rows in slabs:
     splitting pays as soon as every rank gets a row.  opts / env EFGP_SHARD_ROWS=0 keeps every solve replicated."""
     import os
-    if shards is None or not shards.active or R < shards.world_size or os.environ.get("EFGP_SHARD_ROWS", "1") == "0":
+    if shards is None or not shards.active or R < shards.world_size:
         return False
     cells = 1
     for f in top.fft_shape:
         cells *= int(f)
-    if cells <= 4096:                                   # circulant grid of one workgroup (64 x 64, short 1-D lines)
-        return R > torch.cuda.get_device_properties(top.dev).multi_processor_count
-    return True
+    if os.environ.get("EFGP_SHARD_ROWS", "1") == "0":
+        split = False
+    elif cells <= 4096:                                 # circulant grid of one workgroup (64 x 64, short 1-D lines)
+        split = R > torch.cuda.get_device_properties(top.dev).multi_processor_count
+    else:
+        split = True
+    # the decision selects the collectives that follow: it must be identical on all ranks (checked once per shape)
+    return shards.agree(("rows_over_ranks", cells, R), split, top.dev)
 
 
 def _solve_batched(shards, top, ws, sig, variant, B_all, tol, *, early_stop, diag, max_iter=None, hermitian=False):
@@ -757,12 +762,34 @@ def _solve_batched(shards, top, ws, sig, variant, B_all, tol, *, early_stop, dia
     (X (R, M), iteration count: int-like)."""
     from efgp_hip.ops import LazyIterations
     from efgp_hip.dist import solve_rows_sharded
+    cells = 1
+    for f in top.fft_shape:
+        cells *= int(f)
 
     def solve(block):
         res = cg_solve_async(top, ws, sig, variant, block, None, tol, max_iter=max_iter, early_stop=early_stop, diag=diag,
                              batched=True, hermitian=hermitian)
         if res is not None:
-            return res[0], res[1]._rows_dev
+            if cells <= 4096:
+                return res[0], res[1]._rows_dev          # one workgroup per system: no grid barrier, nothing to re-solve
+            # cooperative launch (128^2..512^2 grids): a grid barrier that could not get its workgroups resident together
+            # leaves -3 in the row counts and NaN in those systems.  Nobody downstream reads the counts before using the
+            # solutions (diag_sums_nd, the gradient's assemble launch), so they are read HERE (one host wait behind a
+            # solve of milliseconds) and dead systems go through the synchronous solver's multi-launch iteration.
+            X, rows_dev = res[0], res[1]._rows_dev
+            rows = [int(v) for v in rows_dev.tolist()]
+            if any(v == -2 for v in rows):
+                res[1].rows                                # raises the Hermitian refusal
+            dead = [i for i, v in enumerate(rows) if v == -3]
+            if dead:
+                ix = torch.tensor(dead, device=X.device)
+                xd, _, rd = cg_solve(top, ws, sig, variant, block.reshape(len(rows), -1)[ix], None, tol, max_iter=max_iter,
+                                     early_stop=early_stop, diag=diag, batched=True, hermitian=hermitian)
+                X.reshape(len(rows), -1)[ix] = xd.reshape(len(dead), -1)
+                for i, v in zip(dead, rd):
+                    rows[i] = int(v)
+                rows_dev = torch.tensor(rows, dtype=torch.int32, device=X.device)
+            return X, rows_dev
         x, _, rows = cg_solve(top, ws, sig, variant, block, None, tol, max_iter=max_iter, early_stop=early_stop, diag=diag,
                               batched=True, hermitian=hermitian)
         return x, rows

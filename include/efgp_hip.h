@@ -68,6 +68,9 @@ int efgp_window_eval(double tol, double sigma, double X, int64_t* first_cell_out
  * wider than the best 2^a3^b5^c size in [2, 2.5] n_modes would need; larger grids take that dense choice.  (A training
  * loop changes n_modes every few steps and every new FFT length is a runtime compilation in rocFFT.) */
 int64_t efgp_fine_grid_size(int64_t n_modes, double tol);
+/* the same choice for a plan of dimension dim in {1, 2, 3}; dense != 0: the 2-D rule of plans with >= 4e6 points (a grid whose
+ * window is one cell narrower).  Always returns (the ladder search is bounded; host only). */
+int64_t efgp_fine_grid_size_nd(int64_t n_modes, double tol, int dim, int dense);
 /* out[i] = Fourier-side correction for CMCL mode i (host array of n_modes doubles) */
 int efgp_window_deconv(double tol, int64_t nf, int64_t n_modes, double* out);
 

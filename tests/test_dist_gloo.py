@@ -132,6 +132,27 @@ def _rows_worker(rank, world, port, q):
             gathered = [None] * world
             dist.all_gather_object(gathered, X.numpy().tobytes())
             ok = ok and all(gv == gathered[0] for gv in gathered)          # identical bits on all ranks
+        # a rank whose local solve raises must not leave its peers waiting in the all-reduce: every rank raises behind it
+        rhs = torch.complex(torch.randn(4, M, generator=g, dtype=torch.float64), torch.randn(4, M, generator=g, dtype=torch.float64))
+
+        def solve_bad(block):
+            if rank == 1:
+                raise ValueError("refused on rank 1")
+            xb, its = O.cg_batched(A, block, torch.zeros_like(block), 1e-10)
+            return xb, [its] * block.shape[0]
+        try:
+            solve_rows_sharded(PointShards(), rhs, solve_bad)
+            ok = False
+        except RuntimeError as err:
+            ok = ok and "1 of 2 ranks" in str(err) and (("refused on rank 1" in str(err)) == (rank == 1))
+        # a per-rank decision that selects collectives is checked for agreement (and cached per key)
+        sh = PointShards()
+        ok = ok and sh.agree("same", True, "cpu") is True and sh.agree("same", True, "cpu") is True
+        try:
+            sh.agree("differs", rank == 0, "cpu")
+            ok = False
+        except RuntimeError as err:
+            ok = ok and "disagree" in str(err)
         q.put((rank, ok and worst < 1e-9, worst))
     finally:
         dist.destroy_process_group()

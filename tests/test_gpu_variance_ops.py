@@ -69,3 +69,31 @@ def test_rccl_comm_world_of_one():
     sh = PointShards(comm=comm)
     assert sh.world_size == 1 and not sh.active and sh.sum_scalars([1.5], dev) == [1.5]
     comm.close()
+
+
+def test_stochastic_variance_survives_a_dead_grid_barrier(monkeypatch):
+    """The Hutchinson solves of the stochastic variance on a 128 x 128 circulant grid run as ONE cooperative launch
+    (cg_coop2d_kernel) whose hand-rolled grid barrier can die when its workgroups are not resident together; the systems it
+    hit then hold NaN and -3 iterations.  diag_sums_nd reads no iteration counts, so `_solve_batched` must notice and
+    re-solve those systems through the multi-launch iteration (reference: efgpnd.py:1634-1664, 1827-1838).  The test hook
+    EFGP_COOP_TEST_DEAD kills every barrier of every cooperative launch."""
+    from efgpnd import EFGPND
+    from kernels.matern import Matern
+    g = torch.Generator().manual_seed(5)
+    N = 3000
+    x = torch.rand(N, 2, dtype=torch.float64, generator=g)
+    y = torch.sin(5 * x[:, 0]) * torch.cos(3 * x[:, 1]) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
+    kern = Matern(dimension=2, nu=2.5, init_lengthscale=0.1, init_variance=1.0)
+    model = EFGPND(x.cuda(), y.cuda(), kern, sigmasq=0.1, eps=1e-3, nufft_eps=1e-8, estimate_params=False,
+                   opts={"cg_tolerance": 1e-8})
+    model.fit()
+    xn = torch.rand(64, 2, dtype=torch.float64, generator=g).cuda()
+    Mtot = int(model.last_fit_stats["feature_count"])
+    assert tuple(model._toeplitz.fft_shape) == (128, 128)
+    probes = (torch.randint(0, 2, (6, Mtot), generator=g) * 2 - 1).to(torch.float64).cuda()
+    _, var_ok = model.predict(xn, variance_method="stochastic", variance_probes=probes)
+    monkeypatch.setenv("EFGP_COOP_TEST_DEAD", "1")
+    _, var_dead = model.predict(xn, variance_method="stochastic", variance_probes=probes, force_recompute=False)
+    monkeypatch.delenv("EFGP_COOP_TEST_DEAD")
+    assert torch.isfinite(var_dead).all()
+    assert float((var_dead - var_ok).abs().max()) < 1e-6 * float(var_ok.abs().max())

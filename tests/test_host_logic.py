@@ -243,3 +243,27 @@ def test_native_spectral_weights_match_the_kernel_classes():
         assert float((ws - ws_ref).abs().max() / ws_ref.abs().max()) < 1e-14
         assert float((dp - dp_ref).abs().max() / dp_ref.abs().max()) < 1e-13
         assert float(ws.imag.abs().max()) == 0.0
+
+
+def test_fine_grid_size_always_returns():
+    """es_fine_size's ladder search must terminate for every tolerance / mode count / dimension (the width model is not
+    monotone in the upsampling ratio beyond its calibrated range: tol ~ 0.035, 40 modes has W = 2 only on the dense
+    100-cell grid, never on a ladder size -- the search used to double until overflow).  Sweep incl. that band; the result
+    is a 2^a 3^b 5^c size >= 2 n whose window is no wider than the ladder's first candidate would need."""
+    from efgp_hip.lib import lib
+    L = lib()
+    tols = [10 ** (-12 + 11.7 * i / 119) for i in range(120)] + [0.0346 + 0.0025 * i / 39 for i in range(40)]
+    for dim in (1, 2, 3):
+        for dense in (0, 1):
+            for n in range(1, 257):
+                for tol in tols:
+                    c = L.efgp_fine_grid_size_nd(n, tol, dim, dense)
+                    assert c >= 2 * n and c >= 32, (n, tol, dim, dense, c)
+                    m = c
+                    for p in (2, 3, 5):
+                        while m % p == 0:
+                            m //= p
+                    assert m == 1, (n, tol, dim, dense, c)
+    # the advisor's example: falls back to the dense choice (100 cells, W = 2)
+    assert L.efgp_fine_grid_size_nd(40, 0.035, 2, 0) == 100
+    assert L.efgp_window_width(0.035, 100 / 40) == 2
