@@ -1235,6 +1235,353 @@ __global__ __launch_bounds__(h64::kThreadsH) void cg_herm64_kernel(Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Hermitian solve on the SMALLEST circulant grid (round 4): 48 x 48 for blocks of up to 23 x 23 modes.
+// The Toeplitz product is exact on any circulant grid F >= 2 n - 1 (wrap-around lands outside the crop window,
+// efgpnd.py:1266-1271: the reference's own `_next_fast_fft_size` branch); next_pow2 is a choice.  The headline block
+// (mtot 23, 2 n - 1 = 45) fits 48 = 3 * 16: 0.56 x the grid of cg_herm64_kernel -- 24 packed column lines instead of 32, 48-point
+// lines instead of 64-point ones.  Same structure as cg_herm64_kernel (rows k0 >= 0 only, two real columns per complex column
+// transform, CG vectors in the row lanes' registers, the norm test on an idle wave, refusal of non-conforming input), same
+// recurrences and stopping rules (cg.py:86-153 / 155-244); results differ from the 64 x 64 embedding by rounding only.
+// fft_shape / efgp_toeplitz_apply keep the reference's grid.
+//
+// A 48-point line lives in 8 adjacent lanes as 48 = 6 x 8, in two mirrored factorizations so that every pruned stage is a
+// radix-8 butterfly with four live legs (dft8_in4 / dft8_out4 of the 64-point kernel) on SIX lanes holding positions j + 6 t,
+// and every full stage a radix-6 butterfly on EIGHT lanes holding positions j + 8 t:
+//   "6x8" (phases A, B: zero-padded input):  lanes j < 6: DFT-8 over t of x[j + 6 t] (t in {0, 1, 6, 7} live) -> exchange ->
+//                                            lanes k < 8: twiddle w48^(k t), DFT-6 over t -> X[k + 8 k2], k2 < 6
+//   "8x6" (phases C, D: cropped output):     lanes j < 8: DFT-6 over t of x[j + 8 t], twiddle w48^(j k) -> exchange ->
+//                                            lanes k < 6: DFT-8 over the 8 writers -> X[k + 6 k2], k2 in {0, 1, 6, 7} kept
+// The output layout of one is the input layout of the other: the CG vectors stay in the registers of the lanes j < 6 of a row
+// (slots k1 = j, j + 6, j - 12, j - 6) between D and the next A, and the spectrum multiply between B and C works on registers.
+// ------------------------------------------------------------------------------------------------
+namespace h48 {
+constexpr int kThreadsH = 256, kWavesH = kThreadsH / 64;
+constexpr int F = 48, HF = 24, NR = 12;  // grid, packed column pairs, stored rows k0 = 0..11
+constexpr int LDR = 56;                  // pitch of the G rows (8 mod 16)
+constexpr int LT = 28;                   // pitch of the T rows (24 packed columns)
+constexpr int LX = 72;                   // row lanes' exchange scratch per line: [writer][value], writer pitch 9
+constexpr int LQ = 82;                   // column lanes' exchange scratch per line (2 mod 16)
+constexpr int G_ELEMS = NR * LDR, T_ELEMS = 2 * NR * LT, Q_ELEMS = HF * LQ;
+static_assert(NR * LX <= Q_ELEMS, "the row lines' scratch aliases the column lines' scratch");
+constexpr int kLdsElems = G_ELEMS + T_ELEMS + Q_ELEMS;     // 53 KB
+
+// forward DFT-6 in natural order: even / odd split into two DFT-3
+__device__ __forceinline__ void dft3(double2 b0, double2 b1, double2 b2, double2& x0, double2& x1, double2& x2) {
+    const double s = 0.86602540378443864676;
+    const double2 sm = cadd(b1, b2), df = csub(b1, b2);
+    x0 = cadd(b0, sm);
+    const double2 m = make_double2(fma(-0.5, sm.x, b0.x), fma(-0.5, sm.y, b0.y));
+    x1 = make_double2(fma(s, df.y, m.x), fma(-s, df.x, m.y));      // m - i s (b1 - b2)
+    x2 = make_double2(fma(-s, df.y, m.x), fma(s, df.x, m.y));
+}
+__device__ __forceinline__ void dft6(double2 (&v)[6]) {
+    const double s = 0.86602540378443864676;
+    double2 e0, e1, e2, o0, o1, o2;
+    dft3(v[0], v[2], v[4], e0, e1, e2);
+    dft3(v[1], v[3], v[5], o0, o1, o2);
+    const double2 w1 = make_double2(fma(s, o1.y, 0.5 * o1.x), fma(-s, o1.x, 0.5 * o1.y));        // w6   o1, w6 = (1/2, -s)
+    const double2 w2 = make_double2(fma(s, o2.y, -0.5 * o2.x), fma(-s, o2.x, -0.5 * o2.y));      // w6^2 o2
+    v[0] = cadd(e0, o0);
+    v[3] = csub(e0, o0);
+    v[1] = cadd(e1, w1);
+    v[4] = csub(e1, w1);
+    v[2] = cadd(e2, w2);
+    v[5] = csub(e2, w2);
+}
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// "6x8", second half: the lanes j < 6 of a line hand their eight first-stage outputs over (scratch [writer][value], pitch 9);
+// every lane k < 8 takes value k of the six writers, twiddles with tw[t - 1] = w48^(k t) and runs the radix-6 stage:
+// u[k2] = X[k + 8 k2].
+__device__ __forceinline__ void exchange_8to6(const double2 (&v)[8], double2 (&u)[6], bool writer, double2* __restrict__ wr,
+                                              const double2* __restrict__ rd, const double2 (&tw)[5]) {
+    wave_sync();
+    if (writer) s64::store8_all<1>(wr, v);
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 6; ++t) u[t] = rd[9 * t];
+#pragma unroll
+    for (int t = 1; t < 6; ++t) u[t] = cmulp(u[t], tw[t - 1]);
+    dft6(u);
+}
+// "8x6", second half: every lane j < 8 has run the radix-6 stage on u and twiddles its outputs with tw[k - 1] = w48^(j k); the
+// lanes k < 6 take value k of the eight writers and run the radix-8 stage of which the outputs 0, 1, 6, 7 are wanted:
+// v[k2] = X[k + 6 k2].
+__device__ __forceinline__ void exchange_6to8(double2 (&u)[6], double2 (&v)[8], double2* __restrict__ wr, const double2* __restrict__ rd,
+                                              const double2 (&tw)[5]) {
+#pragma unroll
+    for (int t = 1; t < 6; ++t) u[t] = cmulp(u[t], tw[t - 1]);
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 6; ++t) wr[t] = u[t];
+    wave_sync();
+    s64::load8_all<9>(rd, v);
+    h64::dft8_out4(v);
+}
+}  // namespace h48
+
+template <int VARIANT>
+__global__ __launch_bounds__(h48::kThreadsH) void cg_herm48_kernel(Args a) {
+    using namespace h48;
+    using h64::block_sum_h;
+    using h64::block_sum_pair_h;
+    using h64::dft8_in4;
+    using h64::div_rcp;
+    constexpr int KS = 4;
+    static_assert(h64::kWavesH == kWavesH, "the block reductions are shared with the 64 x 64 kernel");
+    extern __shared__ double2 lds2[];
+    __shared__ double red[4 * kWavesH];
+    __shared__ double s_rcp;             // 1 / (<r,z> + 1e-16) for the next beta, computed by an idle wave during A
+    __shared__ int s_stop;               // convergence decision of the last completed iteration, taken by an idle wave during A
+    double2* const Gb = lds2;                    // G[k0][f1], k0 = 0..11 (rows beyond h are zero), f1 = 0..47
+    double2* const Tb = lds2 + G_ELEMS;          // conj T[row(p)][q]: rows p = 0..11 and 36..47 (stored at p - 24)
+    double2* const Qb = Tb + T_ELEMS;            // exchange scratch: column lines (B/C), aliased by the row lines (A, D)
+    const int n = a.g.n[0], h = (n - 1) / 2, M = a.g.M;
+    const int row = blockIdx.x;
+    const int64_t base = (int64_t)row * M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // row role (12 lines x 8 lanes: wave 0 and half of wave 1): lane = k0 * 8 + j, the vector lives in the lanes j < 6;
+    // column role (waves 0..2): lane = jc * 8 + ql, packed column q = 8 wave + ql < 24
+    const int k0 = tid >> 3, j = tid & 7;
+    const bool row_role = tid < 8 * NR, vec_role = row_role && j < 6;
+    const int jc = lane >> 3, ql = lane & 7, q = wave * 8 + ql;
+    const bool col_role = wave < 3, col6 = jc < 6;
+    const int k0s = row_role ? k0 : 0;
+    double2* const xw = Qb + k0s * LX + 9 * j;
+    const double2* const xr = Qb + k0s * LX + j;
+    const int qs = col_role ? q : 0;
+    double2* const qw = Qb + qs * LQ + 9 * jc;
+    const double2* const qr = Qb + qs * LQ + jc;
+
+    double2 twr[5], twc[5];              // w48^(lane-in-line * t), t = 1..5 (35 at most: no wrap)
+#pragma unroll
+    for (int t = 1; t < 6; ++t) {
+        twr[t - 1] = a.g.tw[0][j * t];
+        twc[t - 1] = a.g.tw[0][jc * t];
+    }
+    // real spectrum of the centred lags, halved (the unpacking of D averages two terms): vhat = w^((n-1)(f0+f1)) S
+    double sa[6], sb[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int f0 = jc + 8 * t;
+        const double2 va = a.vhat[f0 * F + qs], vb = a.vhat[f0 * F + qs + HF];
+        const double2 wa = a.g.tw[0][((n - 1) * (f0 + qs)) % F], wb = a.g.tw[0][((n - 1) * (f0 + qs + HF)) % F];
+        sa[t] = 0.5 * (va.x * wa.x + va.y * wa.y);
+        sb[t] = -0.5 * (vb.x * wb.x + vb.y * wb.y);      // sign: conjugation in front of the inverse transform
+    }
+    const bool z6_ok = jc > 0;                            // row 12 - jc exists
+    const int jr = col6 ? jc : 0;                         // rows this lane packs in B (the lanes jc >= 6 only take part in the radix-6 stages)
+
+    // vector slots of a row lane j < 6: positions j + 6 t, t in {0, 1, 6, 7} <-> k1 = j, j + 6, j - 12, j - 6
+    double2 xv[KS], rv[KS], pv[KS];
+    double wsr[KS], dg[KS], rdg[KS];     // ws is real here (checked below): ws * u costs two multiplies
+    bool ok[KS];
+    int idx[KS];
+    const bool precond = a.diag != nullptr || a.diag_scale != nullptr;
+    const double wgt = k0 == 0 ? 1.0 : 2.0;
+    double ws_bad = 0.0;                 // > 0: ws is not real and even
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k1 = s == 0 ? j : (s == 1 ? j + 6 : (s == 2 ? j - 12 : j - 6));
+        ok[s] = vec_role && k0 <= h && k1 <= h && -k1 <= h;
+        idx[s] = ok[s] ? (k0 + h) * n + (k1 + h) : 0;
+        double ws_im = 0.0;
+        if (ok[s]) {
+            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x[base + idx[s]];
+            const double2 w = a.ws[idx[s]], wm = a.ws[M - 1 - idx[s]];
+            wsr[s] = w.x;
+            ws_im = w.y * w.y + (w.x - wm.x) * (w.x - wm.x) + wm.y * wm.y;
+            dg[s] = jacobi_entry(a, w, idx[s]);
+        } else {
+            xv[s] = make_double2(0.0, 0.0);
+            wsr[s] = 0.0;
+            dg[s] = 1.0;
+        }
+        ws_bad += ws_im;
+        rdg[s] = 1.0 / dg[s];
+        rv[s] = pv[s] = make_double2(0.0, 0.0);
+    }
+
+    int stop = 0;
+    double rcp_rz = 0.0;
+    auto apply_A = [&](const double2 (&u)[KS], double2 (&Au)[KS]) __attribute__((always_inline)) {
+        double2 v[8], u6[6];
+        // A ("6x8"): rows k0 >= 0, modes k1 wrapped to positions k1 mod 48 -> G[k0][f1]
+        if (row_role) {
+            dft8_in4(make_double2(wsr[0] * u[0].x, wsr[0] * u[0].y), make_double2(wsr[1] * u[1].x, wsr[1] * u[1].y),
+                     make_double2(wsr[2] * u[2].x, wsr[2] * u[2].y), make_double2(wsr[3] * u[3].x, wsr[3] * u[3].y), v);
+            exchange_8to6(v, u6, j < 6, xw, xr, twr);     // u6[k2] = G[k0][j + 8 k2]
+            double2* g0 = Gb + k0 * LDR + j;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) g0[8 * t] = u6[t];
+        }
+        __syncthreads();
+        stop = s_stop;
+        rcp_rz = s_rcp;
+        if (stop) return;                                 // uniform: the iteration that just started is abandoned
+        // B ("6x8"): packed columns z[k0] = G[k0][q] + i G[k0][q + 24] (k0 >= 0), conj G[-k0][q] + i conj G[-k0][q + 24] (k0 < 0),
+        // rows of lane jc < 6: k0 = jc, jc + 6, jc - 12, jc - 6
+        if (col_role) {
+            const double2* g0 = Gb + q;
+            const double2 a0 = g0[jr * LDR], b0 = g0[jr * LDR + HF];
+            const double2 a1 = g0[(jr + 6) * LDR], b1 = g0[(jr + 6) * LDR + HF];
+            const double2 a6 = g0[((12 - jr) % 12) * LDR], b6 = g0[((12 - jr) % 12) * LDR + HF];
+            const double2 a7 = g0[(6 - jr) * LDR], b7 = g0[(6 - jr) * LDR + HF];
+            // jc = 0 reads row k0 = 0, whose modes +k1 and -k1 are BOTH stored: drop the imaginary parts (the projection onto
+            // coefficient arrays of real functions; see cg_herm64_kernel)
+            const double2 z0 = jc == 0 ? make_double2(a0.x, b0.x) : make_double2(a0.x - b0.y, a0.y + b0.x);
+            const double2 z1 = make_double2(a1.x - b1.y, a1.y + b1.x);
+            double2 z6 = make_double2(a6.x + b6.y, b6.x - a6.y);
+            const double2 z7 = make_double2(a7.x + b7.y, b7.x - a7.y);
+            if (!z6_ok) z6 = make_double2(0.0, 0.0);
+            dft8_in4(z0, z1, z6, z7, v);
+            exchange_8to6(v, u6, col6, qw, qr, twc);      // u6[t] = R_q[f0] + i R_{q+24}[f0], f0 = jc + 8 t
+            // C ("8x6"): times the real spectrum, conjugate, forward transform = conj of the inverse transform
+#pragma unroll
+            for (int t = 0; t < 6; ++t) u6[t] = make_double2(u6[t].x * sa[t], u6[t].y * sb[t]);
+            dft6(u6);
+            exchange_6to8(u6, v, qw, qr, twc);            // lanes jc < 6: v[k2] = conj T[jc + 6 k2], k2 in {0, 1, 6, 7}
+            if (col6) {
+                double2* t0 = Tb + jc * LT + q;
+                t0[0] = v[0];
+                t0[6 * LT] = v[1];
+                t0[12 * LT] = v[6];                       // p = jc + 36, stored at p - 24
+                t0[18 * LT] = v[7];
+            }
+        }
+        __syncthreads();
+        // D ("8x6"): row k0 >= 0 of the result from the packed columns at +k0 and -k0; conjugated inputs, forward transform
+        if (row_role) {
+            const double2* tp = Tb + k0 * LT + j;
+            const double2* tm = Tb + (k0 == 0 ? 0 : 2 * NR - k0) * LT + j;
+#pragma unroll
+            for (int u3 = 0; u3 < 3; ++u3) {
+                const double2 P = tp[8 * u3], Mv = tm[8 * u3];
+                u6[u3] = make_double2(P.x + Mv.x, P.y - Mv.y);
+                u6[u3 + 3] = make_double2(-P.y - Mv.y, P.x - Mv.x);
+            }
+            dft6(u6);
+            exchange_6to8(u6, v, xw, xr, twr);            // lanes j < 6: v[k2] = conj Y[k0][j + 6 k2], k2 in {0, 1, 6, 7}
+            const double2 y[KS] = {s64::conjd(v[0]), s64::conjd(v[1]), s64::conjd(v[6]), s64::conjd(v[7])};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const double2 gg = make_double2(wsr[s] * y[s].x, wsr[s] * y[s].y);
+                double2 val;
+                if (VARIANT == 0) val = make_double2(gg.x + a.sigmasq * u[s].x, gg.y + a.sigmasq * u[s].y);
+                else val = make_double2(gg.x / a.sigmasq + u[s].x, gg.y / a.sigmasq + u[s].y);
+                // the lanes j >= 6 of a line only lend their radix-6 stages: what they read in the radix-8 stage is stale scratch
+                Au[s] = ok[s] ? val : make_double2(0.0, 0.0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) Au[s] = make_double2(0.0, 0.0);
+        }
+    };
+
+    if (tid == 0) {
+        s_stop = 0;
+        s_rcp = 0.0;
+    }
+    double2 Ap[KS];
+    if (a.zero_x0) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) Ap[s] = make_double2(0.0, 0.0);
+    } else {
+        apply_A(xv, Ap);
+    }
+    double rz = 0.0, bb = 0.0, asym = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (ok[s]) {
+            double2 bv = a.b[base + idx[s]];
+            double2 bm = a.b[base + (M - 1 - idx[s])];                 // mode -k: must be the conjugate
+            if (a.b_times_ws) {
+                bv = make_double2(wsr[s] * bv.x, wsr[s] * bv.y);
+                bm = make_double2(wsr[s] * bm.x, wsr[s] * bm.y);
+            }
+            asym += (bv.x - bm.x) * (bv.x - bm.x) + (bv.y + bm.y) * (bv.y + bm.y);
+            rv[s] = csub(bv, Ap[s]);
+            pv[s] = precond ? make_double2(div_rcp(rv[s].x, dg[s], rdg[s]), div_rcp(rv[s].y, dg[s], rdg[s])) : rv[s];
+            rz += rv[s].x * pv[s].x + rv[s].y * pv[s].y;
+            bb += bv.x * bv.x + bv.y * bv.y;
+        }
+    }
+    rz *= wgt;
+    bb *= wgt;
+    block_sum_pair_h(rz, bb, red);
+    asym = block_sum_h(asym, red);
+    ws_bad = block_sum_h(ws_bad, red + kWavesH);      // (disjoint scratch: no barrier between the two sums' reads and writes)
+    if (!(asym <= 1e-16 * bb) || ws_bad != 0.0) {
+        // not the coefficients of a real function (rounding leaves ~1e-32 |b|^2): refuse loudly instead of solving another system
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (ok[s]) {
+                a.x[base + idx[s]] = make_double2(__builtin_nan(""), __builtin_nan(""));
+                a.x[base + (M - 1 - idx[s])] = make_double2(__builtin_nan(""), __builtin_nan(""));
+            }
+        }
+        if (tid == 0) a.iters[row] = -2;
+        return;
+    }
+    const double bn = sqrt(bb);
+    const double den = bn > 0.0 ? bn : 1.0;
+    const double den_eps = den + 1e-16, rcp_den = 1.0 / den_eps;
+    // as in cg_herm64_kernel: the row waves carry the dependent chain, wave 3 (idle during A) takes the norm test of iteration i
+    // and the reciprocal for the next beta; its decision is read behind the first barrier of the next operator application
+    if (wave == 3 && lane == 0) s_rcp = 1.0 / (rz + 1e-16);
+    int it = 0;
+    for (; it < a.max_iter;) {
+        apply_A(pv, Ap);
+        if (stop) break;
+        double pAp = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pAp += pv[s].x * Ap[s].x + pv[s].y * Ap[s].y;
+        pAp = block_sum_h(pAp * wgt, red) + 1e-16;
+        const double alpha = rz / pAp;
+        double rr = 0.0, rzn = 0.0;
+        double2 zv[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            xv[s].x += alpha * pv[s].x;
+            xv[s].y += alpha * pv[s].y;
+            rv[s].x -= alpha * Ap[s].x;
+            rv[s].y -= alpha * Ap[s].y;
+            zv[s] = precond ? make_double2(div_rcp(rv[s].x, dg[s], rdg[s]), div_rcp(rv[s].y, dg[s], rdg[s])) : rv[s];
+            rr += rv[s].x * rv[s].x + rv[s].y * rv[s].y;
+            rzn += rv[s].x * zv[s].x + rv[s].y * zv[s].y;
+        }
+        rr *= wgt;
+        rzn *= wgt;
+        block_sum_pair_h(rr, rzn, red);
+        ++it;
+        if (wave == 3) {
+            const double ratio = div_rcp(sqrt(rr), den_eps, rcp_den);
+            const bool conv = a.early_stop && ((ratio < a.tol) || (a.batched && sqrt(rr) < 1e-12));
+            if (lane == 0) {
+                if (a.hist && row == 0 && it <= a.hist_cap) a.hist[it - 1] = ratio;
+                s_stop = conv ? 1 : 0;
+                s_rcp = 1.0 / (rzn + 1e-16);
+            }
+        }
+        // cg.py:132 / 229: the test sits before (single) or after (batched) this update; p is not an output
+        const double beta = div_rcp(rzn, rz + 1e-16, rcp_rz);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pv[s] = make_double2(zv[s].x + beta * pv[s].x, zv[s].y + beta * pv[s].y);
+        rz = rzn;
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (ok[s]) {
+            a.x[base + idx[s]] = xv[s];
+            if (k0 > 0) a.x[base + (M - 1 - idx[s])] = s64::conjd(xv[s]);     // mode -k
+        }
+    }
+    if (tid == 0) a.iters[row] = it;
+}
+
+// ------------------------------------------------------------------------------------------------
 // 1-D systems (round 3): the whole solve in ONE WAVE per system.  cg_persistent_kernel above spends ~8 us per iteration on a
 // 1-D block of 63 unknowns (BASELINE configs[0] is such a model: mtot 35, F = 128): its passes are built for grids -- 1024
 // threads, a workgroup barrier per radix stage, two-level block reductions -- and a single 128-point line leaves all but a few
@@ -1427,10 +1774,9 @@ __global__ __launch_bounds__(64) void cg_line1d_kernel(Args a) {
 // Spectrum of the Toeplitz vector for the 64 x 64 circulant grid in ONE launch (efgpnd.py:1283-1290: pad to the FFT
 // box, forward fftn): `factor * v` zero-padded into LDS, four radix-8 Stockham stages as in the solver above, result
 // in natural order.  Replaces pad_scale_kernel + two rocFFT launches (~14 us of dependent 4-5 us launches per fit).
-__global__ __launch_bounds__(kThreads) void toeplitz_vhat_2d64_kernel(const double2* __restrict__ v, int L0, int L1,
-                                                                      double factor, double2* __restrict__ vhat) {
+__device__ __forceinline__ void toeplitz_vhat_2d64_body(const double2* __restrict__ v, int L0, int L1, double factor,
+                                                        double2* __restrict__ vhat, double2* lds2) {
     using namespace s64;
-    extern __shared__ double2 lds2[];
     double2* const bufA = lds2;
     double2* const bufB = lds2 + BUF;
     const int tid = threadIdx.x;
@@ -1474,6 +1820,85 @@ __global__ __launch_bounds__(kThreads) void toeplitz_vhat_2d64_kernel(const doub
     dft_fwd<8>(x);
 #pragma unroll
     for (int t = 0; t < 8; ++t) vhat[(j + 8 * t) * F + c] = x[t];
+}
+__global__ __launch_bounds__(kThreads) void toeplitz_vhat_2d64_kernel(const double2* __restrict__ v, int L0, int L1,
+                                                                      double factor, double2* __restrict__ vhat) {
+    extern __shared__ double2 lds2[];
+    toeplitz_vhat_2d64_body(v, L0, L1, factor, vhat, lds2);
+}
+
+// The same for the 48 x 48 circulant grid of cg_herm48_kernel (round 4): vhat[f0][f1] = factor * sum_l v[l] w48^(f0 l0 + f1 l1).
+// Lines as in that kernel: 8 adjacent lanes, "8x6" (radix 6 on eight lanes, radix 8 on six), rows then columns, 64 line slots.
+__device__ __forceinline__ void toeplitz_vhat_2d48_body(const double2* __restrict__ v, int L0, int L1, double factor,
+                                                        double2* __restrict__ vhat, double2* lds2) {
+    constexpr int F = 48, LD = 49, LX = 72;
+    double2* const buf = lds2;                       // [48][LD]
+    double2* const scr = lds2 + F * LD;              // [64 lines][writer 9 j + value]
+    const int tid = threadIdx.x;
+    for (int t = tid; t < F * F; t += kThreads) {
+        const int i0 = t / F, i1 = t - i0 * F;
+        double2 x = make_double2(0.0, 0.0);
+        if (i0 < L0 && i1 < L1) {
+            x = v[i0 * L1 + i1];
+            x.x *= factor;
+            x.y *= factor;
+        }
+        buf[i0 * LD + i1] = x;
+    }
+    const int line = tid >> 3, j = tid & 7;
+    const bool act = line < F;
+    double2 tw[5];
+#pragma unroll
+    for (int t = 1; t < 6; ++t) {
+        double sn, cs;
+        sincospi(-(double)(j * t) / 24.0, &sn, &cs);      // exp(-2 pi i j t / 48)
+        tw[t - 1] = make_double2(cs, sn);
+    }
+    double2* const wr = scr + line * LX + 9 * j;
+    const double2* const rd = scr + line * LX + j;
+    double2 u6[6], x8[8];
+    __syncthreads();
+    // dimension 1 (contiguous): line = row
+#pragma unroll
+    for (int t = 0; t < 6; ++t) u6[t] = act ? buf[line * LD + j + 8 * t] : make_double2(0.0, 0.0);
+    h48::dft6(u6);
+#pragma unroll
+    for (int t = 1; t < 6; ++t) u6[t] = cmulp(u6[t], tw[t - 1]);
+    h48::wave_sync();
+#pragma unroll
+    for (int t = 0; t < 6; ++t) wr[t] = u6[t];
+    h48::wave_sync();
+    s64::load8_all<9>(rd, x8);
+    dft_fwd<8>(x8);
+    if (act && j < 6) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) buf[line * LD + j + 6 * t] = x8[t];
+    }
+    __syncthreads();
+    // dimension 0: line = column
+#pragma unroll
+    for (int t = 0; t < 6; ++t) u6[t] = act ? buf[(j + 8 * t) * LD + line] : make_double2(0.0, 0.0);
+    h48::dft6(u6);
+#pragma unroll
+    for (int t = 1; t < 6; ++t) u6[t] = cmulp(u6[t], tw[t - 1]);
+    h48::wave_sync();
+#pragma unroll
+    for (int t = 0; t < 6; ++t) wr[t] = u6[t];
+    h48::wave_sync();
+    s64::load8_all<9>(rd, x8);
+    dft_fwd<8>(x8);
+    if (act && j < 6) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) vhat[(j + 6 * t) * F + line] = x8[t];
+    }
+}
+// both spectra of an operator in ONE launch (two workgroups on two CUs): a dependent launch costs more than either transform
+__global__ __launch_bounds__(kThreads) void toeplitz_vhat_pair_kernel(const double2* __restrict__ v, int L0, int L1, double factor64,
+                                                                      double2* __restrict__ vhat64, double factor48,
+                                                                      double2* __restrict__ vhat48) {
+    extern __shared__ double2 lds2[];
+    if (vhat64 != nullptr && blockIdx.x == 0) toeplitz_vhat_2d64_body(v, L0, L1, factor64, vhat64, lds2);
+    else toeplitz_vhat_2d48_body(v, L0, L1, factor48, vhat48, lds2);
 }
 
 // Batched variant for the lag-sum correlation of the stochastic variance (variance_ops.hip): transform b reads the
@@ -1580,6 +2005,30 @@ int toeplitz_vhat_fused_launch(const double2* v, int L0, int L1, double factor, 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("Toeplitz spectrum (64x64) launch failed: %s", hipGetErrorString(e));
+        return EFGP_EHIP;
+    }
+    return EFGP_OK;
+}
+
+// vhat64 (may be null) and vhat48 in one launch; both are FFT(zero-padded v) / (their grid size), natural order
+int toeplitz_vhat_pair_launch(const double2* v, int L0, int L1, double2* vhat64, double2* vhat48, hipStream_t stream) {
+    using namespace pcg;
+    bool& attr = per_device_flag("vhat_pair");
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)toeplitz_vhat_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 256);
+        if (e != hipSuccess) {
+            set_error("Toeplitz spectra (64x64 + 48x48): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return EFGP_EHIP;
+        }
+        attr = true;
+    }
+    const size_t lds = vhat64 ? (size_t)2 * s64::BUF * sizeof(double2) : (size_t)(48 * 49 + 64 * 72) * sizeof(double2);
+    hipLaunchKernelGGL(toeplitz_vhat_pair_kernel, dim3(vhat64 ? 2 : 1), dim3(kThreads), lds, stream, v, L0, L1, 1.0 / 4096.0, vhat64,
+                       1.0 / 2304.0, vhat48);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("Toeplitz spectra (64x64 + 48x48) launch failed: %s", hipGetErrorString(e));
         return EFGP_EHIP;
     }
     return EFGP_OK;
@@ -1801,7 +2250,8 @@ bool persistent_cg_eligible(const ToepGeom& tg) {
 int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, const double2* vhat, const double2* ws,
                          const double* diag, double sigmasq, int variant, double tol, int early_stop, int batched,
                          int max_iter, const double2* b, double2* x, int rows, int* d_iters, hipStream_t stream,
-                         const double* diag_scale, int b_times_ws, int zero_x0, const LanczosOut* lz, int hermitian) {
+                         const double* diag_scale, int b_times_ws, int zero_x0, const LanczosOut* lz, int hermitian,
+                         const Herm48Operands* h48) {
     using namespace pcg;
     Args a;
     Geom& g = a.g;
@@ -1995,7 +2445,27 @@ int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, con
     const bool fast64 = tg.d == 2 && g.F[0] == 64 && g.F[1] == 64 && g.n[0] == g.n[1] && g.n[0] <= 32 &&
                         std::getenv("EFGP_NO_CG64") == nullptr;
     const bool herm64 = fast64 && hermitian && !lz && (g.n[0] & 1) && g.n[0] <= 31 && std::getenv("EFGP_NO_CG_HERM") == nullptr;
-    if (herm64) {
+    // blocks of up to 23 x 23 modes: the smallest circulant grid, 48 x 48 (the operator holds a second spectrum for it)
+    const bool herm48 = herm64 && h48 != nullptr && h48->vhat != nullptr && g.n[0] <= 23 && std::getenv("EFGP_NO_CG48") == nullptr;
+    if (herm48) {
+        bool& attr_h = per_device_flag("cg_herm48");
+        const size_t lds_h = (size_t)h48::kLdsElems * sizeof(double2);
+        if (!attr_h) {
+            hipError_t e2 = hipFuncSetAttribute((const void*)cg_herm48_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
+            if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)cg_herm48_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
+            if (e2 != hipSuccess) {
+                set_error("persistent CG (48x48, Hermitian): hipFuncSetAttribute failed: %s", hipGetErrorString(e2));
+                return EFGP_EHIP;
+            }
+            attr_h = true;
+        }
+        a.vhat = h48->vhat;
+        g.F[0] = g.F[1] = 48;
+        g.tw[0] = g.tw[1] = h48->tw;
+        KernelTimer timer("cg_solve", stream);
+        if (variant == 0) hipLaunchKernelGGL(cg_herm48_kernel<0>, dim3(rows), dim3(h48::kThreadsH), lds_h, stream, a);
+        else hipLaunchKernelGGL(cg_herm48_kernel<1>, dim3(rows), dim3(h48::kThreadsH), lds_h, stream, a);
+    } else if (herm64) {
         bool& attr_h = per_device_flag("cg_herm64");
         const size_t lds_h = (size_t)h64::kLdsElems * sizeof(double2);
         if (!attr_h) {

@@ -2305,7 +2305,33 @@ struct efgp_toeplitz_s {
     double2* vhat_cg = nullptr;
     double2* tw_cg[3] = {nullptr, nullptr, nullptr};
     bool cg64 = false;
+    // 2-D blocks of up to 23 x 23 modes (2 n - 1 <= 48): the HERMITIAN solves (the model's mean systems) run on the smallest
+    // circulant grid, 48 x 48 (cg_herm48_kernel, round 4), from a third spectrum made in the same launch as the 64 x 64 one
+    double2* vhat48 = nullptr;
+    Herm48Operands h48 = {nullptr, nullptr};
 };
+
+// exp(-2 pi i q / n), q < n, on the device (cached per context)
+static double2* twiddle_table_for(DeviceCtx* ctx, int64_t n, hipStream_t stream) {
+    auto it = ctx->twiddles.find(n);
+    if (it != ctx->twiddles.end()) return (double2*)it->second;
+    std::vector<double2> tw((size_t)n);
+    const long double two_pi = 2.0L * acosl(-1.0L);
+    for (int64_t q = 0; q < n; ++q) {
+        long double ang = -two_pi * (long double)q / (long double)n;
+        tw[(size_t)q] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    double2* dtw = nullptr;
+    if (hipMalloc((void**)&dtw, (size_t)n * sizeof(double2)) != hipSuccess ||
+        hipMemcpyAsync(dtw, tw.data(), (size_t)n * sizeof(double2), hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) {
+        if (dtw) (void)hipFree(dtw);
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    ctx->twiddles[n] = dtw;
+    return dtw;
+}
 
 // geometry, twiddles and spectrum the single-launch CG kernels use for this operator
 static void cg_operands(const efgp_toeplitz_s* op, const ToepGeom** g, const double2* const** tw, const double2** vhat) {
@@ -2385,9 +2411,25 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
         gv.M *= gv.n[a];
     }
     int rc = EFGP_OK;
+    // Hermitian solves of blocks up to 23 x 23 run on the 48 x 48 circulant grid: its spectrum rides in the launch that makes the
+    // 64 x 64 one (this grid's, or the embedding's below)
+    const bool want48 = dim == 2 && op->g.n[0] == op->g.n[1] && (op->g.n[0] & 1) && op->g.n[0] <= 23 && op->g.F[0] <= 64 &&
+                        op->g.F[0] == op->g.F[1] && persistent_cg_eligible(op->g) && std::getenv("EFGP_NO_CG48") == nullptr &&
+                        std::getenv("EFGP_NO_CG64") == nullptr && std::getenv("EFGP_NO_CG_HERM") == nullptr;
+    if (want48) {
+        const double2* tw48 = twiddle_table_for(ctx, 48, stream);
+        op->vhat48 = tw48 ? (double2*)pool_alloc(ctx, (size_t)2304 * sizeof(double2)) : nullptr;
+        if (op->vhat48) op->h48.tw = tw48;
+    }
+    bool made48 = false;
     if (toeplitz_vhat_fused_eligible(op->g)) {
-        rc = toeplitz_vhat_fused_launch((const double2*)v, (int)op->Ls[0], (int)op->Ls[1], 1.0 / (double)op->g.Ftot, op->vhat,
-                                        stream);
+        if (op->vhat48) {
+            rc = toeplitz_vhat_pair_launch((const double2*)v, (int)op->Ls[0], (int)op->Ls[1], op->vhat, op->vhat48, stream);
+            made48 = rc == EFGP_OK;
+        } else {
+            rc = toeplitz_vhat_fused_launch((const double2*)v, (int)op->Ls[0], (int)op->Ls[1], 1.0 / (double)op->g.Ftot, op->vhat,
+                                            stream);
+        }
     } else {
         hipLaunchKernelGGL(pad_scale_kernel, grid_for(op->g.Ftot, 1, kVecThreads), dim3(kVecThreads), 0, stream, gv,
                            (const double2*)v, gv.M, (const double2*)nullptr, (const int*)nullptr, (const int*)nullptr,
@@ -2478,7 +2520,14 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
             }
             if (ok) op->tw_cg[0] = op->tw_cg[1] = (double2*)ctx->twiddles[64];
         }
-        if (ok) ok = toeplitz_vhat_fused_launch((const double2*)v, (int)op->Ls[0], (int)op->Ls[1], 1.0 / 4096.0, op->vhat_cg, stream) == EFGP_OK;
+        if (ok) {
+            if (op->vhat48 && !made48) {
+                ok = toeplitz_vhat_pair_launch((const double2*)v, (int)op->Ls[0], (int)op->Ls[1], op->vhat_cg, op->vhat48, stream) == EFGP_OK;
+                made48 = ok;
+            } else {
+                ok = toeplitz_vhat_fused_launch((const double2*)v, (int)op->Ls[0], (int)op->Ls[1], 1.0 / 4096.0, op->vhat_cg, stream) == EFGP_OK;
+            }
+        }
         if (ok) {
             op->cg64 = true;
         } else {
@@ -2486,6 +2535,12 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
             if (op->vhat_cg) pool_free(ctx, op->vhat_cg, (size_t)4096 * sizeof(double2));
             op->vhat_cg = nullptr;
         }
+    }
+    if (op->vhat48 && made48) {
+        op->h48.vhat = op->vhat48;
+    } else if (op->vhat48) {          // no 64 x 64 launch carried it (grid not on the fused path): the Hermitian solves keep 64 x 64
+        pool_free(ctx, op->vhat48, (size_t)2304 * sizeof(double2));
+        op->vhat48 = nullptr;
     }
     *op_out = op;
     return EFGP_OK;
@@ -2498,6 +2553,7 @@ int efgp_toeplitz_destroy(efgp_toeplitz_t* op) {
     // finishes before any later enqueue on that stream can overwrite a recycled block (single stream)
     if (op->vhat) pool_free(op->ctx, op->vhat, (size_t)op->g.Ftot * sizeof(double2));
     if (op->vhat_cg) pool_free(op->ctx, op->vhat_cg, (size_t)4096 * sizeof(double2));
+    if (op->vhat48) pool_free(op->ctx, op->vhat48, (size_t)2304 * sizeof(double2));
     if (op->vhat_c) pool_free(op->ctx, op->vhat_c, (size_t)op->g.Ftot * sizeof(double2));
     if (op->vc3) pool_free(op->ctx, op->vc3, (size_t)op->g.Ftot * sizeof(double));
     delete op;
@@ -3284,7 +3340,7 @@ static int cg_solve_async_impl(efgp_toeplitz_t* op, const void* ws, double sigma
     cg_operands(op, &gq, &twq, &vq);
     return persistent_cg_launch(*gq, twq, vq, (const double2*)ws, precond_diag, sigmasq,
                                 variant, tol, early_stop, batched_semantics, max_iter, (const double2*)b, (double2*)x, nbatch,
-                                row_iters_dev, stream, nullptr, 0, 0, nullptr, hermitian);
+                                row_iters_dev, stream, nullptr, 0, 0, nullptr, hermitian, op->h48.vhat ? &op->h48 : nullptr);
 }
 
 int efgp_lanczos(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const void* z, int nprobes, int steps,
@@ -3325,7 +3381,8 @@ int efgp_cg_solve_mean_async(efgp_toeplitz_t* op, const void* ws, double sigmasq
     cg_operands(op, &gq, &twq, &vq);
     return persistent_cg_launch(*gq, twq, vq, (const double2*)ws, nullptr, sigmasq, 0, tol,
                                 early_stop, 0, max_iter, (const double2*)fy, (double2*)x, 1, iters_dev, stream, diag_scale_dev,
-                                1, 1, nullptr, /*hermitian: F*y of a real y, Toeplitz vector of real weights*/ 1);
+                                1, 1, nullptr, /*hermitian: F*y of a real y, Toeplitz vector of real weights*/ 1,
+                                op->h48.vhat ? &op->h48 : nullptr);
 }
 
 int efgp_vdot_real(int device, const void* a, int a_is_complex, const void* b, int b_is_complex, int64_t count,

@@ -22,17 +22,27 @@ struct LanczosOut {
     double* norm2;     // [rows] |b|^2, may be null
 };
 
+// operands of cg_herm48_kernel: the operator's spectrum on the 48 x 48 circulant grid (FFT of the zero-padded Toeplitz vector
+// / 2304, natural order) and exp(-2 pi i q / 48), q < 48
+struct Herm48Operands {
+    const double2* vhat;
+    const double2* tw;
+};
+
 // single-launch CG with the FFT in LDS (cg_persistent.hip)
 bool persistent_cg_eligible(const ToepGeom& g);
 int persistent_cg_launch(const ToepGeom& g, const double2* const* twiddles, const double2* vhat, const double2* ws,
                          const double* diag, double sigmasq, int variant, double tol, int early_stop, int batched,
                          int max_iter, const double2* b, double2* x, int rows, int* d_iters, hipStream_t stream,
                          const double* diag_scale = nullptr, int b_times_ws = 0, int zero_x0 = 0, const LanczosOut* lz = nullptr,
-                         int hermitian = 0 /* b, x0 and the Toeplitz vector are coefficient arrays of real functions */);
+                         int hermitian = 0 /* b, x0 and the Toeplitz vector are coefficient arrays of real functions */,
+                         const Herm48Operands* h48 = nullptr /* 2-D blocks <= 23 x 23: Hermitian solves run on the 48 x 48 grid */);
 
 // spectrum of the Toeplitz vector on the 64 x 64 circulant grid in one launch (cg_persistent.hip)
 bool toeplitz_vhat_fused_eligible(const ToepGeom& g);
 int toeplitz_vhat_fused_launch(const double2* v, int L0, int L1, double factor, double2* vhat, hipStream_t stream);
+// the 64 x 64 spectrum (vhat64, may be null) and the 48 x 48 spectrum in one launch, each divided by its grid size
+int toeplitz_vhat_pair_launch(const double2* v, int L0, int L1, double2* vhat64, double2* vhat48, hipStream_t stream);
 // forward 64 x 64 transforms of nbatch zero-padded L0 x L1 arrays (complex or real), one workgroup each (cg_persistent.hip)
 int fft2d64_batch_launch(const void* src, int src_is_real, int64_t src_stride, int L0, int L1, double2* dst, int64_t dst_stride,
                          int nbatch, hipStream_t stream);

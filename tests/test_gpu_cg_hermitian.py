@@ -326,3 +326,40 @@ def test_hermitian_3d_batched_warm_start_and_refusal():
     xa, ia, _ = cg_solve(op2, ws2.cuda(), 0.3, 0, b2.cuda(), None, 1e-8, batched=False, hermitian=True)
     xb, ib, _ = cg_solve(op2, ws2.cuda(), 0.3, 0, b2.cuda(), None, 1e-8, batched=False)
     assert ia == ib and torch.equal(xa, xb)
+
+
+@pytest.mark.parametrize("mtot,precond,tol", [(23, True, 1e-10), (23, False, 1e-6), (21, True, 1e-8), (19, True, 1e-12), (13, True, 1e-8),
+                                              (11, False, 1e-8), (5, True, 1e-10), (1, True, 1e-10), (25, True, 1e-8)])
+def test_smallest_circulant_grid_48_equals_64(mtot, precond, tol, monkeypatch):
+    """Blocks of up to 23 x 23 modes: the Hermitian solve runs on the 48 x 48 circulant grid (cg_herm48_kernel; any F >= 2 n - 1
+    embeds the Toeplitz product exactly, efgpnd.py:1266-1271) -- against the 64 x 64 kernel (EFGP_NO_CG48) and the oracle:
+    same iteration counts, solutions to cond x tol, true residual at the oracle's.  mtot 25 (2 n - 1 = 49) must stay on 64."""
+    from efgp_hip import ToeplitzOp, cg_solve_mean_async, kernel_timing, kernel_timing_read
+    from oracle import efgp_oracle as O
+    v, T, ws, fy = _system(mtot, 17)
+    vd = v.cuda()
+    centre = vd[tuple((s - 1) // 2 for s in vd.shape)].real
+    op = ToeplitzOp(vd)
+    assert tuple(op.fft_shape) == ((64, 64) if mtot >= 17 else tuple(op.fft_shape))      # the reference's grid is what is reported
+    beta, lazy = cg_solve_mean_async(op, ws.cuda(), 0.25, centre if precond else None, fy.cuda(), tol)
+    it48 = int(lazy)
+    monkeypatch.setenv("EFGP_NO_CG48", "1")
+    beta64, lazy64 = cg_solve_mean_async(op, ws.cuda(), 0.25, centre if precond else None, fy.cuda(), tol)
+    it64 = int(lazy64)
+    monkeypatch.delenv("EFGP_NO_CG48")
+    slack = 1 + it64 // (200 if precond else 50)
+    xtol = (100 if precond else 1e4) * tol
+    assert abs(it48 - it64) <= slack, (it48, it64)
+    assert _rel(beta, beta64) < xtol
+    if mtot == 25:
+        assert torch.equal(beta, beta64)              # same kernel both times
+    rhs = ws * fy
+    diag = (float(centre) * ws.abs().pow(2).real + 0.25) if precond else None
+    A = O.make_A_mean(ws, T, 0.25)
+    xo, ito = O.cg_single(A, rhs, torch.zeros_like(rhs), tol, diag=diag)
+    assert abs(it48 - ito) <= slack and _rel(beta, xo) < xtol
+    true_h = float(torch.linalg.norm(A(beta.cpu()) - rhs) / torch.linalg.norm(rhs))
+    true_o = float(torch.linalg.norm(A(xo) - rhs) / torch.linalg.norm(rhs))
+    assert true_h < 1.05 * true_o + 0.1 * tol, (true_h, true_o)
+    bq = beta.cpu().reshape(mtot, mtot)
+    assert torch.equal(torch.flip(bq, dims=(0, 1)).conj()[: mtot // 2], bq[: mtot // 2])
