@@ -616,7 +616,7 @@ def main():
                        "achieved_GBs": interp_bytes / (1e-3 * interp_ms / max(interp_n, 1)) / 1e9 if interp_n else None},
             # the mean solve is ONE persistent launch (one CU): largest share of the step, latency/VALU bound by design,
             # priced here against the survey's per-iteration bytes 16*(F_tot + 8M) x the iterations of the launch
-            "cg_solve": {"kernel": "cg_herm64_kernel (whole mean solve, one launch; real transforms on the 64 x 64 grid)",
+            "cg_solve": {"kernel": "cg_herm48_kernel (whole mean solve, one launch; real transforms on the 48 x 48 circulant grid)",
                          "avg_launch_us": 1e3 * cgs_ms / max(cgs_n, 1), "iterations": mean_iters,
                          "bytes_per_launch": cg_bytes,
                          "achieved_GBs": cg_bytes / (1e-3 * cgs_ms / max(cgs_n, 1)) / 1e9 if cgs_n else None,

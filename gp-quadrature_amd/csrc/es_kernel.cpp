@@ -42,15 +42,31 @@ long double cell_value(int w, double beta, int j, long double s) {
     return expl((long double)beta * (sqrtl(q) - 1.0L));
 }
 
-// Chebyshev interpolant of degree deg on [-1,1] -> monomial coefficients
-void cheb_fit(int w, double beta, int j, int deg, long double* mono) {
+// cos(pi k (i + 1/2) / n) and the Chebyshev nodes cos(pi (i + 1/2) / n) of one degree: the same for every cell of a window, so
+// they are built once per degree (round 4: a training step with a new mode count spent 0.2-0.4 ms per window set in cosl / expl)
+struct ChebTables {
+    int n = 0;
+    std::vector<long double> node, ck;        // node[i], ck[k * n + i]
+    void build(int n_) {
+        n = n_;
+        const long double pi = acosl(-1.0L);
+        node.resize(n);
+        ck.resize((size_t)n * n);
+        for (int i = 0; i < n; ++i) node[i] = cosl(pi * (i + 0.5L) / n);
+        for (int k = 0; k < n; ++k)
+            for (int i = 0; i < n; ++i) ck[(size_t)k * n + i] = cosl(pi * k * (i + 0.5L) / n);
+    }
+};
+
+// Chebyshev interpolant of degree deg on [-1,1] -> monomial coefficients (same operations on the same operands as the original
+// per-cell version: bit-identical coefficients)
+void cheb_fit(int w, double beta, int j, int deg, const ChebTables& tab, long double* mono) {
     const int n = deg + 1;
     std::vector<long double> fv(n), a(n);
-    const long double pi = acosl(-1.0L);
-    for (int i = 0; i < n; ++i) fv[i] = cell_value(w, beta, j, cosl(pi * (i + 0.5L) / n));
+    for (int i = 0; i < n; ++i) fv[i] = cell_value(w, beta, j, tab.node[i]);
     for (int k = 0; k < n; ++k) {
         long double acc = 0;
-        for (int i = 0; i < n; ++i) acc += fv[i] * cosl(pi * k * (i + 0.5L) / n);
+        for (int i = 0; i < n; ++i) acc += fv[i] * tab.ck[(size_t)k * n + i];
         a[k] = acc * (k == 0 ? 1.0L : 2.0L) / n;
     }
     // sum_k a_k T_k(s) -> monomials, by the three-term recurrence on coefficient vectors
@@ -72,16 +88,26 @@ void cheb_fit(int w, double beta, int j, int deg, long double* mono) {
     }
 }
 
-double fit_error(const EsParams& p) {
+// the window's values at the 201 check points of every cell: they do not depend on the degree under test
+constexpr int kCheckPoints = 201;
+void fit_reference(int w, double beta, std::vector<double>* ref) {
+    ref->resize((size_t)w * kCheckPoints);
+    for (int j = 0; j < w; ++j)
+        for (int t = 0; t < kCheckPoints; ++t) {
+            double s = -1.0 + 2.0 * t / 200.0;
+            (*ref)[(size_t)j * kCheckPoints + t] = (double)cell_value(w, beta, j, s);
+        }
+}
+
+double fit_error(const EsParams& p, const std::vector<double>& ref) {
     double worst = 0.0;
     const int stride = kMaxDegree + 1;
     for (int j = 0; j < p.w; ++j) {
-        for (int t = 0; t <= 200; ++t) {
+        for (int t = 0; t < kCheckPoints; ++t) {
             double s = -1.0 + 2.0 * t / 200.0;
             double acc = p.coef[j * stride + p.degree];
             for (int k = p.degree - 1; k >= 0; --k) acc = acc * s + p.coef[j * stride + k];
-            double ref = (double)cell_value(p.w, p.beta, j, s);
-            worst = std::max(worst, std::fabs(acc - ref));
+            worst = std::max(worst, std::fabs(acc - ref[(size_t)j * kCheckPoints + t]));
         }
     }
     return worst;
@@ -104,13 +130,17 @@ int es_make_params(double tol, double sigma, EsParams* p) {
     // 3e-9 until degree 14 -- 55 % more Horner work in every spread / gather kernel for nothing measurable.)
     const double target = std::max(0.1 * tol, 2e-15);
     long double mono[kMaxDegree + 1];
+    std::vector<double> ref;
+    fit_reference(p->w, p->beta, &ref);
+    ChebTables tab;
     for (int deg = std::min(kMaxDegree, std::max(4, p->w + 1)); deg <= kMaxDegree; ++deg) {
         p->degree = deg;
+        tab.build(deg + 1);
         for (int j = 0; j < p->w; ++j) {
-            cheb_fit(p->w, p->beta, j, deg, mono);
+            cheb_fit(p->w, p->beta, j, deg, tab, mono);
             for (int k = 0; k <= kMaxDegree; ++k) p->coef[j * stride + k] = (k <= deg) ? (double)mono[k] : 0.0;
         }
-        p->fit_error = fit_error(*p);
+        p->fit_error = fit_error(*p, ref);
         if (p->fit_error <= target) break;
     }
     return 0;
@@ -170,17 +200,28 @@ void es_deconv_factors(const EsParams& p, int64_t nf, int64_t n_modes, std::vect
     }
     out->resize((size_t)n_modes);
     const int64_t kmin = -(n_modes / 2);
+    // cos(k theta_q), theta_q = (w pi / nf) z_q, for k = 0 .. kmax at every node by Reinsch's form of the three-term recurrence
+    // (d_{k+1} = d_k + delta c_k, c_{k+1} = c_k + d_{k+1}, delta = -4 sin^2(theta / 2): the error grows like k eps_80bit, far
+    // below a double's rounding) instead of one cosl per (mode, node): round 4, 0.15-0.25 ms per window set -> microseconds;
+    // the factors equal the cosl version's to the last bit or one ulp (tests/test_host_logic.py).
+    const int64_t kmax = std::max<int64_t>(-kmin, n_modes - 1 + kmin);
+    std::vector<long double> acc((size_t)kmax + 1, 0.0L);
+    const long double base = (long double)p.w * pi / (long double)nf;
+    for (int q = 0; q < nq; ++q) {
+        const long double theta = base * zs[q];
+        const long double sh = sinl(0.5L * theta);
+        const long double delta = -4.0L * sh * sh;
+        long double c = 1.0L, d = 0.5L * delta;          // c_0 = 1, d_1 = c_1 - c_0 = -2 sin^2(theta / 2)
+        acc[0] += tq[q];
+        for (int64_t k = 1; k <= kmax; ++k) {
+            c += d;                                       // c_k
+            acc[(size_t)k] += tq[q] * c;
+            d += delta * c;                               // d_{k+1}
+        }
+    }
     for (int64_t i = 0; i < n_modes; ++i) {
         const int64_t kk = kmin + i;
-        if (kk > 0 && -kk >= kmin) {                       // the factor of -k is already there (cos is even)
-            (*out)[(size_t)i] = (*out)[(size_t)(-kk - kmin)];
-            continue;
-        }
-        long double k = (long double)kk;
-        long double arg = k * p.w * pi / (long double)nf;
-        long double acc = 0;
-        for (int q = 0; q < nq; ++q) acc += tq[q] * cosl(arg * zs[q]);
-        long double P = 0.5L * p.w * acc;
+        long double P = 0.5L * p.w * acc[(size_t)(kk < 0 ? -kk : kk)];
         (*out)[(size_t)i] = (double)(1.0L / P);
     }
 }

@@ -38,6 +38,54 @@ TWO_PI = 2.0 * math.pi
 _CONV_TOL = 6e-8       # tolerance the reference hard-codes for the Toeplitz vector (efgpnd.py:1418)
 
 
+class _StageRanges:
+    """roctx ranges named after the reference's stage timers (efgpnd.py:61-280 `stage_times`, :888-966 predict), so that a
+    `rocprofv3 --marker-trace --kernel-trace` timeline of a gradient step or a prediction reads by stage.  Off unless
+    EFGP_ROCTX=1 (a push / pop pair costs about a microsecond of host time each; a 0.4-ms step has ten stages).
+    torch.cuda.nvtx IS roctx on ROCm builds.  Stage names are known when a stage ENDS (`lap(name)`), so the range of the
+    stage that follows is opened from the fixed order below."""
+    ORDER = ["0_book_keeping", "1_frequency_grid_setup", "2_nufft_setup", "3_toeplitz_setup", "4_solve_cg", "5_compute_term2",
+             "6_monte_carlo_trace", "7_batch_cg_solve", "7.5_compute_alpha", "8_gradient_calculation", "9_log_marginal_likelihood"]
+    enabled = os.environ.get("EFGP_ROCTX", "0") == "1"
+
+    def __init__(self, outer, first=None):
+        self.depth = 0
+        if self.enabled:
+            self._push(outer)
+            if first is not None:
+                self._push(first)
+
+    def _push(self, name):
+        torch.cuda.nvtx.range_push(name)
+        self.depth += 1
+
+    def _pop(self):
+        if self.depth > 0:
+            torch.cuda.nvtx.range_pop()
+            self.depth -= 1
+
+    def lap(self, name):
+        """Stage `name` has ended: close its range, open the one of the stage that follows it."""
+        if not self.enabled:
+            return
+        if self.depth > 1:
+            self._pop()
+        k = self.ORDER.index(name) if name in self.ORDER else -1
+        if 0 <= k < len(self.ORDER) - 1:
+            self._push(self.ORDER[k + 1])
+
+    def stage(self, name):
+        """Open a named range inside the outer one (predict: 'predict_mean', 'compute_variance')."""
+        if self.enabled:
+            if self.depth > 1:
+                self._pop()
+            self._push(name)
+
+    def close(self):
+        while self.depth > 0:
+            self._pop()
+
+
 def _cmplx(real_dtype: torch.dtype) -> torch.dtype:
     """complex dtype matching a real dtype (reference: efgpnd.py:1233-1234)."""
     return torch.complex64 if real_dtype == torch.float32 else torch.complex128
@@ -331,6 +379,15 @@ class _Grid:
         host_ok = self.M * d <= 16384 and type(kernel).__name__ != "Matern"
         where = self.xis if host_ok else up(self.xis, dev)
         S = kernel.spectral_density(where).to(torch.float64)
+        # The fused solvers treat every system of a model as coefficients of REAL functions (section 4.4 of DESIGN.md), which
+        # needs ws real and even on the symmetric grid -- true for the spectral density of any real stationary kernel.  The
+        # built-in kernels (native path above) are even by construction; a user-supplied spectral_density is checked here, once
+        # per grid, so that a broken one is a ValueError at the fit and not NaN coefficients from the kernel's refusal.
+        Sf = S.reshape(-1)
+        if not bool(torch.isfinite(Sf).all()) or bool((Sf < 0).any()) or \
+                float((Sf - Sf.flip(0)).abs().max()) > 1e-12 * float(Sf.abs().max()):
+            raise ValueError(f"{type(kernel).__name__}.spectral_density must be finite, non-negative and even (S(-xi) = S(xi)) on "
+                             "the frequency grid: it is the spectral density of a real stationary kernel")
         self.ws = up(torch.sqrt(S.to(torch.complex128) * self.h ** d), dev)       # (M,) complex, imag 0
         if want_grad:
             self.dprime = up((self.h ** d * kernel.spectral_grad(where)).to(torch.complex128), dev)   # (M,H)
@@ -449,6 +506,7 @@ def efgpnd_gradient_batched(
     rdtype = x.dtype
     stages: Dict[str, float] = {}
     tic = [time.perf_counter()]
+    ranges = _StageRanges("efgpnd_gradient_batched", "0_book_keeping")
 
     def lap(name):
         if do_profiling:                      # device-accurate stage times only when asked: a sync per stage is not free
@@ -456,6 +514,7 @@ def efgpnd_gradient_batched(
         now = time.perf_counter()
         stages[name] = stages.get(name, 0.0) + (now - tic[0])
         tic[0] = now
+        ranges.lap(name)
 
     # 0) book keeping -------------------------------------------------------------------------
     dev = compute_device(x, device=device)
@@ -665,6 +724,7 @@ def efgpnd_gradient_batched(
         for k_, v_ in stages.items():
             print(f"  {k_:28s} {v_:.6f}")
 
+    ranges.close()
     grad = grad.to(device=out_device, dtype=rdtype)
     return (grad, log_marginal) if compute_log_marginal else grad
 
@@ -1265,6 +1325,7 @@ class EFGPND(nn.Module):
         if d != st["d"]:
             raise ValueError(f"x_new has {d} columns, the model was built on {st['d']}")
         t0 = time.perf_counter()
+        ranges = _StageRanges("EFGPND.predict", "predict_mean")
         shape = (st["mtot"],) * d                       # carried explicitly (the reference re-derives it, :908)
         # the plan over x_new is kept while the same tensor (same storage, same version) comes back with the same grid:
         # predicting at the training points after every refit is the reference's own usage (efgpnd_ex.ipynb cell 23)
@@ -1278,6 +1339,7 @@ class EFGPND(nn.Module):
         out_mean = mean.to(device=self.device, dtype=rdtype)
         t1 = time.perf_counter()
         if return_variance:
+            ranges.stage("compute_variance")
             if variance_probes is None and self._shards.active and variance_method.lower() == "stochastic":
                 # replicas must estimate the SAME lag sums: rank 0's draw (reference draw: efgpnd.py:1644)
                 variance_probes = (torch.randint(0, 2, (hutchinson_probes, st["ws"].numel()), device=dev) * 2 - 1).to(torch.float64)
@@ -1296,6 +1358,7 @@ class EFGPND(nn.Module):
                 self._nan_scalar = torch.full((1,), float("nan"), device=self.device, dtype=rdtype)     # once per model
             var = self._nan_scalar.expand(B)
         t2 = time.perf_counter()
+        ranges.close()
         if do_profiling:
             torch.cuda.synchronize(dev)
             print(f"predict_mean {t1 - t0:.6f}s  compute_variance {t2 - t1:.6f}s")

@@ -381,3 +381,33 @@ def test_kernel_timing_name_filter():
         assert kernel_timing_read("spread")[1] == 1 and kernel_timing_read("interp")[1] == 1
     finally:
         kernel_timing(False)
+
+
+def test_user_kernel_with_a_non_even_spectral_density_is_a_value_error():
+    """The fused solvers carry every system of a model as coefficients of real functions, which needs `ws` real and even.  The
+    built-in kernels are; a user subclass whose spectral_density is not even (not the density of a real stationary kernel) must
+    fail at the fit with a ValueError -- not with NaN coefficients from the Hermitian kernel's refusal.  A subclass with an even
+    density (here: the parent's, scaled) goes through the same torch path and fits."""
+    from efgpnd import EFGPND
+    from kernels.squared_exponential import SquaredExponential
+
+    class Skewed(SquaredExponential):
+        def spectral_density(self, xid):
+            S = super().spectral_density(xid)
+            first = xid[..., 0] if xid.ndim > 1 else xid
+            return S * (1.0 + 0.1 * torch.tanh(first))
+
+    class Scaled(SquaredExponential):
+        def spectral_density(self, xid):
+            return 0.5 * super().spectral_density(xid)
+
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(2000, 2, dtype=torch.float64, generator=g) * 2 - 1).cuda()
+    y = torch.sin(3 * x[:, 0]) + 0.1 * torch.randn(2000, dtype=torch.float64, generator=g).cuda()
+    bad = EFGPND(x, y, Skewed(dimension=2, init_lengthscale=0.3, init_variance=1.0), sigmasq=0.1, eps=1e-3, estimate_params=False)
+    with pytest.raises(ValueError, match="even"):
+        bad.fit()
+    ok = EFGPND(x, y, Scaled(dimension=2, init_lengthscale=0.3, init_variance=1.0), sigmasq=0.1, eps=1e-3, estimate_params=False)
+    ok.fit()
+    mean, _ = ok.predict(x[:50], return_variance=False)
+    assert torch.isfinite(mean).all() and int(ok.last_fit_stats["mean_cg_iters"]) > 0

@@ -267,3 +267,27 @@ def test_fine_grid_size_always_returns():
     # the advisor's example: falls back to the dense choice (100 cells, W = 2)
     assert L.efgp_fine_grid_size_nd(40, 0.035, 2, 0) == 100
     assert L.efgp_window_width(0.035, 100 / 40) == 2
+
+
+def test_window_design_matches_round3_outputs():
+    """Round 4 took the transcendental-heavy parts out of the host-side window design (a training step with a new mode count
+    paid 0.2-0.4 ms per window set): cosine tables shared by the cells, reference values hoisted out of the degree search,
+    deconvolution factors by Reinsch's cosine recurrence instead of one cosl per (mode, node).  Against the round-3 library's
+    outputs (tests/golden/window_design_r3.npz, written before the change): widths, shape parameters and window polynomial
+    values bit-identical, correction factors within one ulp."""
+    import ctypes as C
+    from efgp_hip.lib import lib
+    from _golden import GOLDEN
+    L = lib()
+    g = np.load(f"{GOLDEN}/window_design_r3.npz")
+    first, vals, w, beta = C.c_int64(), (C.c_double * 16)(), C.c_int(), C.c_double()
+    for i, (tol, nf, n) in enumerate(g["cases"]):
+        nf, n = int(nf), int(n)
+        out = (C.c_double * n)()
+        assert L.efgp_window_deconv(float(tol), nf, n, out) == 0
+        a, b = np.array(out[:]), g[f"deconv_{i}"]
+        assert float((np.abs(a - b) / np.spacing(np.abs(b))).max()) <= 1.0, (tol, nf, n)
+        for r, X in enumerate((10.3, 7.77, 21.5, 3.999999)):
+            assert L.efgp_window_eval(float(tol), nf / n, X, C.byref(first), vals, C.byref(w), C.byref(beta)) == 0
+            assert w.value == int(g[f"w_{i}"][0]) and beta.value == float(g[f"beta_{i}"][0])
+            assert np.array_equal(np.array(vals[:w.value]), g[f"eval_{i}"][r]), (tol, nf, n, X)
