@@ -340,6 +340,8 @@ int efgp_kernel_timing_read(const char* name, double* total_ms_out, int64_t* lau
 
 int efgp_window_width(double tol, double sigma) { return es_width_for_tol(tol, sigma); }
 
+int efgp_window_width_nd(double tol, double sigma, int dim) { return es_width_for_tol(tol, sigma, dim); }
+
 int64_t efgp_fine_grid_size(int64_t n_modes, double tol) {
     if (n_modes < 1) return 0;
     return es_fine_size(n_modes, tol, 2);

@@ -16,19 +16,31 @@ double es_window(double z, double beta) {
 
 static const double kSigmaCalibrated = 5.0;   // upper end of the upsampling ratios the width formula was fitted on
 
-// Measured l2 error of this window (1-D, exact window values, against the exact sums; round 3 re-measured for sigma up to 5):
-//   err ~ C(sigma) exp(-pi w sqrt(1 - 1/sigma)),   C = e^1.5 for sigma <= 2.6, growing linearly to ~3 e^1.5 at sigma = 5
-// (the shape parameter beta = 0.976 pi w (1 - 1/(2 sigma)) is the sigma = 2 optimum carried along; it loses a factor 2-3 on
-// fine grids: w = 7 at sigma = 3.2 / 4.3 measured 1.2e-7 / 5e-8).
-static double es_log_error_constant(double sigma) { return 1.5 + std::log1p(std::max(0.0, sigma - 2.6)); }
+// Measured l2 error of this window against the exact sums, round 4: 3000 random transforms (tools/r4/fuzz_over2.py, seeds 0-29:
+// d = 1..3, 3..90 modes, tolerances 1e-3..1e-11, 1..3e5 points), error = K e^1.5 exp(-pi w sqrt(1 - 1/sigma)) with
+//   K median / max   sigma 2.0-2.2   2.5-2.8    2.8-3.2    3.2-4      (the shape parameter beta = 0.976 pi w (1 - 1/(2 sigma)) is
+//   d = 1            1.25 / 3.1     1.6 / 4.2  1.8 / 3.6  2.0 / 5.4   the sigma = 2 optimum carried along: it loses on fine grids;
+//   d = 2            1.74 / 3.5     2.2 / 4.1  2.6 / 5.8  3.0 / 6.0   the errors of the axes add up; the maximum over point positions
+//   d = 3            2.26 / 4.2     2.8 / 5.1  3.0 / 6.6  3.7 / 9.7   is about twice the median)
+// The round-3 model (C = e^1.5 up to sigma 2.6, no dimension) sized the window for the 1-D median: worst case 4.13 x the
+// requested tolerance.  The constant below is HALF the measured maximum, i.e. every case of that set lands within 2 x its
+// tolerance: ln C = 1.5 + {0.45, 0.70, 0.90}[d - 1] + log1p(0.35 (sigma - 2)), + 0.7 for mode boxes so small that their grid is
+// the 32-cell minimum at a ratio beyond 5.  EFGP_WIDTH_MODEL_R3=1 restores the round-3 model (A/B measurements).
+static double es_log_error_constant(double sigma, int dim, bool tiny_box) {
+    static const bool r3 = std::getenv("EFGP_WIDTH_MODEL_R3") != nullptr;
+    if (r3) return 1.5 + std::log1p(std::max(0.0, sigma - 2.6));
+    static const double dim_term[3] = {0.45, 0.70, 0.90};
+    return 1.5 + dim_term[std::min(3, std::max(1, dim)) - 1] + std::log1p(0.35 * std::max(0.0, sigma - 2.0)) + (tiny_box ? 0.7 : 0.0);
+}
 
-int es_width_for_tol(double tol, double sigma) {
+int es_width_for_tol(double tol, double sigma, int dim) {
     if (!(tol > 0.0)) tol = 1e-16;
     if (tol < 1e-16) tol = 1e-16;
     if (sigma < 1.1) sigma = 1.1;
+    const bool tiny_box = sigma > kSigmaCalibrated;
     if (sigma > kSigmaCalibrated) sigma = kSigmaCalibrated;
     double rate = M_PI * std::sqrt(1.0 - 1.0 / sigma);
-    int w = (int)std::ceil((std::log(1.0 / tol) + es_log_error_constant(sigma)) / rate);
+    int w = (int)std::ceil((std::log(1.0 / tol) + es_log_error_constant(sigma, dim, tiny_box)) / rate);
     return std::min(kMaxWidth, std::max(2, w));
 }
 
@@ -115,14 +127,14 @@ double fit_error(const EsParams& p, const std::vector<double>& ref) {
 
 }  // namespace
 
-int es_make_params(double tol, double sigma, EsParams* p) {
+int es_make_params(double tol, double sigma, EsParams* p, int dim) {
     if (!p) return -1;
     std::memset(p, 0, sizeof(*p));
     // Tiny mode boxes sit on the 32-cell minimum grid (sigma up to ~10), outside the range the error model was
     // calibrated on: design the window as for sigma = 5 (a finer grid than assumed only moves the aliases further
     // out).  Found by tools/fuzz_nufft.py: 3-D, 4 modes per axis, tol 1e-7 gave 1.2e-6 with the sigma = 8 window.
+    p->w = es_width_for_tol(tol, sigma, dim);
     if (sigma > kSigmaCalibrated) sigma = kSigmaCalibrated;
-    p->w = es_width_for_tol(tol, sigma);
     p->beta = 0.976 * M_PI * p->w * (1.0 - 1.0 / (2.0 * sigma));
     const int stride = kMaxDegree + 1;
     // Fit error budget: a tenth of the tolerance.  (A twentieth made the search overshoot for the common W = 8,
@@ -250,9 +262,9 @@ int64_t es_fine_size(int64_t n_modes, double tol, int dim, bool dense) {
     const int64_t lo = std::max<int64_t>(32, next_smooth_even(2 * n_modes));
     const int64_t hi = std::max<int64_t>(lo, (5 * n_modes) / 2);
     int64_t best = lo;
-    int best_w = es_width_for_tol(tol, (double)lo / (double)n_modes);
+    int best_w = es_width_for_tol(tol, (double)lo / (double)n_modes, dim);
     for (int64_t c = next_smooth_even(lo + 2); c <= hi; c = next_smooth_even(c + 2)) {
-        const int w = es_width_for_tol(tol, (double)c / (double)n_modes);
+        const int w = es_width_for_tol(tol, (double)c / (double)n_modes, dim);
         if (w < best_w) {
             best_w = w;
             best = c;
@@ -269,7 +281,7 @@ int64_t es_fine_size(int64_t n_modes, double tol, int dim, bool dense) {
         pick = 0;
         for (int64_t p2 = 32; !pick && p2 <= (int64_t)1 << 40; p2 *= 2) {
             for (int64_t c : {p2, p2 + p2 / 2})
-                if (!pick && c >= 2 * n_modes && es_width_for_tol(tol, (double)c / (double)n_modes) <= best_w) pick = c;
+                if (!pick && c >= 2 * n_modes && es_width_for_tol(tol, (double)c / (double)n_modes, dim) <= best_w) pick = c;
             if ((double)p2 > kSigmaCalibrated * (double)n_modes && p2 >= 2 * n_modes) break;
         }
         if (!pick) pick = best;
@@ -281,10 +293,10 @@ int64_t es_fine_size(int64_t n_modes, double tol, int dim, bool dense) {
     // <= 5) whose window is one cell narrower.  Grids of <= 128 cells must keep the gather's two 16-byte-aligned copies inside the
     // 160 KB of LDS (interp_real2_pair_kernel).
     if (dense && dim == 2) {
-        const int w0 = es_width_for_tol(tol, (double)pick / (double)n_modes);
+        const int w0 = es_width_for_tol(tol, (double)pick / (double)n_modes, dim);
         const int64_t top = std::min<int64_t>(256, 5 * n_modes);
         for (int64_t c = next_smooth_even(pick + 2); c <= top; c = next_smooth_even(c + 2)) {
-            const int w = es_width_for_tol(tol, (double)c / (double)n_modes);
+            const int w = es_width_for_tol(tol, (double)c / (double)n_modes, dim);
             if (w >= w0) continue;
             const int64_t pitch = (c + 2 * ((w + 1) / 2) + 1) & ~(int64_t)1;
             const bool gather_fits = 2 * (c + w - 1) * pitch * 8 <= 160 * 1024;

@@ -29,11 +29,12 @@ struct EsParams {
 // window value, z in [-1,1]
 double es_window(double z, double beta);
 
-// width for a requested tolerance at upsampling ratio sigma = nf / n_modes
-int es_width_for_tol(double tol, double sigma);
+// width for a requested tolerance at upsampling ratio sigma = nf / n_modes in a transform of `dim` dimensions (the errors of the
+// axes add up)
+int es_width_for_tol(double tol, double sigma, int dim = 1);
 
 // fill p (w, beta, polynomials) for tolerance/sigma; returns 0 or negative error
-int es_make_params(double tol, double sigma, EsParams* p);
+int es_make_params(double tol, double sigma, EsParams* p, int dim = 1);
 
 // Fourier-side correction factors: out[i] = 1 / P(k_i), i = 0..n_modes-1, with k in CMCL order
 // (k = -(n_modes/2) ... (n_modes-1)/2) where  P(k) = (w/2) * int_{-1}^{1} phi(z) cos(k w pi z / nf) dz.

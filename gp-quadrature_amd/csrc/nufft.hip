@@ -2061,7 +2061,7 @@ static int get_window(efgp_nufft_s* plan, const int64_t* n_modes, hipStream_t st
         w->nf[a] = a < d ? es_fine_size(n_modes[a], plan->tol, d, dense) : 1;
         if (a < d) sigma_min = std::min(sigma_min, (double)w->nf[a] / (double)w->nm[a]);
     }
-    es_make_params(plan->tol, sigma_min, &w->p);
+    es_make_params(plan->tol, sigma_min, &w->p, d);
     const int W = w->p.w, deg = w->p.degree;
     // two tables: [kMaxDegree+1][W] (rows above `deg` stay zero: padded Horner), then the first ceil(W/2)
     // polynomials again as [kMaxDegree+1][sym_row(W)] for window_eval

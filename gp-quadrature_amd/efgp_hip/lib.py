@@ -41,6 +41,7 @@ _SIGNATURES = {
     "efgp_kernel_timing_read": (_I, [C.c_char_p, C.POINTER(_D), _PI64]),
     "efgp_window_width": (_I, [_D, _D]),
     "efgp_window_eval": (_I, [_D, _D, _D, _PI64, C.POINTER(_D), C.POINTER(_I), C.POINTER(_D)]),
+    "efgp_window_width_nd": (_I, [_D, _D, _I]),
     "efgp_fine_grid_size": (_I64, [_I64, _D]),
     "efgp_fine_grid_size_nd": (_I64, [_I64, _D, _I, _I]),
     "efgp_window_deconv": (_I, [_D, _I64, _I64, C.POINTER(_D)]),

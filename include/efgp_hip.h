@@ -58,6 +58,8 @@ int efgp_kernel_timing_read(const char* name, double* total_ms_out, int64_t* lau
  * Exposed so the window selection can be unit-tested on a CPU-only machine. */
 /* width w chosen for tolerance `tol` at upsampling ratio sigma = nf/n_modes */
 int efgp_window_width(double tol, double sigma);
+/* the same for a transform of dim dimensions (the window errors of the axes add up: a plan of dimension dim uses this width) */
+int efgp_window_width_nd(double tol, double sigma, int dim);
 /* evaluates the w window values a point at fine-grid position X (grid units) contributes:
  * first_cell_out = ceil(X - w/2), vals_out[j] = window at cell first+j, both via the same
  * Horner polynomials the device kernels use.  vals_out holds >= 16 doubles (host). */

@@ -61,14 +61,14 @@ def test_fine_grid_sizes_sit_on_a_short_ladder():
                 m //= 2
             assert m in (1, 3), (n, nf)                       # 2^k or 3 * 2^k
             lo = max(32, smooth(2 * n))
-            w_dense = min(lib.efgp_window_width(tol, c / n) for c in range(lo, max(lo, 5 * n // 2) + 1, 2) if smooth(c) == c)
-            assert lib.efgp_window_width(tol, nf / n) <= w_dense
+            w_dense = min(lib.efgp_window_width_nd(tol, c / n, 2) for c in range(lo, max(lo, 5 * n // 2) + 1, 2) if smooth(c) == c)
+            assert lib.efgp_window_width_nd(tol, nf / n, 2) <= w_dense
             assert nf <= 4 * max(16, n)                        # at most two ladder steps above the minimum 2 n
             seen.add(nf)
         assert len(seen) <= 10                                 # 256 mode counts, ten FFT lengths
-        # the training run of the bench model (mtot 23 -> 17): one length for the Toeplitz boxes, one for the probes
-        assert {lib.efgp_fine_grid_size(4 * m + 1, 6e-8) for m in (8, 9, 10, 11)} == {96}
-        assert {lib.efgp_fine_grid_size(2 * m + 1, 1e-5) for m in (8, 9, 10, 11)} == {48}
+        # the training run of the bench model (mtot 23 -> 17): two lengths for the Toeplitz boxes, two for the probes
+        assert {lib.efgp_fine_grid_size(4 * m + 1, 6e-8) for m in (8, 9, 10, 11)} == {96, 128}
+        assert {lib.efgp_fine_grid_size(2 * m + 1, 1e-5) for m in (8, 9, 10, 11)} == {48, 64}
     assert lib.efgp_fine_grid_size(301, 6e-8) % 2 == 0 and lib.efgp_fine_grid_size(301, 6e-8) < 768     # large grids: dense choice
 
 

@@ -2,8 +2,9 @@
 tolerances 1e-3..1e-11, 1..3e5 points, coordinate scales 1e-2..1e2 with shifts, real / complex strengths, real-only outputs --
 type 1 and type 2 against the oracle's exact sums, and adjointness.  The window width, fine-grid size and dense-sigma rule are
 picked from the requested tolerance (es_kernel.cpp: `es_params`, `es_fine_size`), so this is the check that the error model
-behind those choices holds: every case within 10 x its tolerance (measured over 300 cases, seeds 0-2: worst 3.46 x,
-profiles/r3_fuzz_summary.txt)."""
+behind those choices holds: every case within 2 x its tolerance.  (Round 3's model sized the window for the 1-D median error:
+worst case 4.13 x over 3000 cases; round 4 re-measured the error constant per dimension and upsampling ratio -- es_kernel.cpp,
+profiles/r4_fuzz_summary.txt: worst 1.60 x over 1200 cases.)"""
 import os
 import sys
 
@@ -15,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("seed", [0, 3])
-def test_every_random_case_is_within_ten_times_its_tolerance(seed):
+def test_every_random_case_is_within_twice_its_tolerance(seed):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         import fuzz_nufft
@@ -24,4 +25,4 @@ def test_every_random_case_is_within_ten_times_its_tolerance(seed):
     worst, failures = fuzz_nufft.run(60, seed, verbose=False)
     print(f"\nseed {seed}: worst error / tol = {worst:.2f} over 60 cases")
     assert not failures, failures
-    assert worst <= 10.0
+    assert worst <= 2.0

@@ -40,7 +40,7 @@ def test_type1_vs_exact(d, nm, tol, complex_c):
     out = plan.type1(c.cuda(), (nm,) * d)
     ref = O.nudft_type1(x, h, c, (nm,) * d)
     assert out.shape == ref.shape
-    assert _rel(out, ref) < 5 * tol + 1e-13
+    assert _rel(out, ref) < 2 * tol + 1e-13
 
 
 @pytest.mark.parametrize("d,nm,tol", [(1, 35, 1e-6), (2, 23, 1e-4), (2, 45, 6e-8), (3, 11, 1e-5), (2, 141, 1e-9), (2, 24, 1e-6),
@@ -60,7 +60,7 @@ def test_type2_vs_exact(d, nm, tol, real_only):
     ref = O.nudft_type2(x, h, f, (nm,) * d)
     if real_only:
         ref = ref.real
-    assert _rel(out, ref) < 5 * tol + 1e-13
+    assert _rel(out, ref) < 2 * tol + 1e-13
 
 
 def test_type2_fft_order_and_batch():
@@ -135,15 +135,15 @@ def test_type1_tiled_large_grid(d, nm, tol, N):
     plan = NufftPlan(x.cuda(), h, tol)
     out = plan.type1(c.cuda(), (nm,) * d)
     ref = O.nudft_type1(x, h, c, (nm,) * d)
-    assert _rel(out, ref) < 5 * tol + 1e-13
+    assert _rel(out, ref) < 2 * tol + 1e-13
     # bitwise reproducible (integer accumulation): a second call gives identical bits
     out2 = plan.type1(c.cuda(), (nm,) * d)
     assert torch.equal(out, out2)
     y = torch.randn(N, generator=g, dtype=torch.float64)
     small = (nm + 1) // 2 if ((nm + 1) // 2) % 2 == 1 else (nm + 1) // 2 - 1
     Fy, v = plan.type1_pair(y.cuda(), (small,) * d, (nm,) * d)
-    assert _rel(Fy, O.nudft_type1(x, h, y, (small,) * d)) < 5 * tol + 1e-13
-    assert _rel(v, O.nudft_type1(x, h, torch.ones(N, dtype=torch.float64), (nm,) * d)) < 5 * tol + 1e-13
+    assert _rel(Fy, O.nudft_type1(x, h, y, (small,) * d)) < 2 * tol + 1e-13
+    assert _rel(v, O.nudft_type1(x, h, torch.ones(N, dtype=torch.float64), (nm,) * d)) < 2 * tol + 1e-13
 
 
 def test_type1_lds_path_is_bitwise_reproducible():
@@ -194,11 +194,11 @@ def test_type1_cell_sorted_register_path(nm, tol, N, monkeypatch):
     plan2 = NufftPlan(x.cuda(), 0.346, tol)
     Fy2, v2 = plan2.type1_pair(y.cuda(), (small, small), (nm, nm))
     Zf2 = plan2.type1_rademacher(5, 3, (small, small))
-    assert _rel(Fy, Fy2) < 5 * tol and _rel(v, v2) < 5 * tol and _rel(Zf, Zf2) < 5 * tol
+    assert _rel(Fy, Fy2) < 4 * tol and _rel(v, v2) < 4 * tol and _rel(Zf, Zf2) < 4 * tol
     sub = slice(0, 60000)                                    # exact reference on a sub-sample is enough for the constant
     ref_v = O.nudft_type1(x, 0.346, torch.ones(N, dtype=torch.float64), (nm, nm))
-    assert _rel(v, ref_v) < 5 * tol + 1e-13
-    assert _rel(cplx, (1 - 2j) * Fy) < 5 * tol + 1e-12
+    assert _rel(v, ref_v) < 2 * tol + 1e-13
+    assert _rel(cplx, (1 - 2j) * Fy) < 2 * tol + 1e-12
 
 
 @pytest.mark.parametrize("d,nm,tol", [(3, 21, 1e-9), (3, 23, 1e-6), (2, 141, 1e-7), (3, 12, 1e-5)])
@@ -221,7 +221,7 @@ def test_type2_tiled_gather_beyond_lds(d, nm, tol, real_only, monkeypatch):
     ref = torch.stack([O.nudft_type2(x[sub], h, f[b], (nm,) * d) for b in range(2)])
     if real_only:
         ref = ref.real
-    assert _rel(out[:, sub.cuda()], ref) < 5 * tol + 1e-13
+    assert _rel(out[:, sub.cuda()], ref) < 2 * tol + 1e-13
     monkeypatch.setenv("EFGP_NO_TILES", "1")
     plan2 = NufftPlan(x.cuda(), h, tol)
     out2 = plan2.type2(f.cuda(), (nm,) * d, real_only=real_only)

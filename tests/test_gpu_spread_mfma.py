@@ -53,11 +53,11 @@ def test_pair_on_layout_vs_exact(N, h, nm_y, nm_o, tol, kw, band_cells, monkeypa
     assert torch.equal(Fy, Fy2) and torch.equal(v, v2)          # exact integer accumulation: bitwise reproducible
     ref_y = O.nudft_type1(x, h, y, (nm_y, nm_y))
     ref_o = O.nudft_type1(x, h, torch.ones(N, dtype=torch.float64), (nm_o, nm_o))
-    assert _rel(Fy, ref_y) < 5 * tol
-    assert _rel(v, ref_o) < 5 * tol
+    assert _rel(Fy, ref_y) < 2 * tol
+    assert _rel(v, ref_o) < 2 * tol
     plain = NufftPlan(xd, h, tol)
     Fy0, v0 = plain.type1_pair(yd, (nm_y, nm_y), (nm_o, nm_o))
-    assert _rel(Fy, Fy0) < 5 * tol and _rel(v, v0) < 5 * tol
+    assert _rel(Fy, Fy0) < 4 * tol and _rel(v, v0) < 4 * tol
     assert abs(float(v[nm_o // 2, nm_o // 2].real) - N) < 1e-6 * N
 
 
@@ -92,17 +92,17 @@ def test_rows_and_probes_on_layout():
     Z = torch.randn(3, N, generator=g, dtype=torch.float64)
     out = plan.type1(Z.cuda(), (nm, nm))
     for b in range(3):
-        assert _rel(out[b], O.nudft_type1(x, h, Z[b], (nm, nm))) < 5 * tol
+        assert _rel(out[b], O.nudft_type1(x, h, Z[b], (nm, nm))) < 2 * tol
     c = torch.complex(Z[0], Z[1])
     outc = plan.type1(c.cuda(), (nm, nm))
-    assert _rel(outc, O.nudft_type1(x, h, c, (nm, nm))) < 5 * tol
+    assert _rel(outc, O.nudft_type1(x, h, c, (nm, nm))) < 2 * tol
     one = plan.type1(y.cuda(), (nm, nm))                       # the attached array as a single row: sorted copy
-    assert _rel(one, O.nudft_type1(x, h, y, (nm, nm))) < 5 * tol
+    assert _rel(one, O.nudft_type1(x, h, y, (nm, nm))) < 2 * tol
     seed, off = 1234567, 1000
     R = rademacher_fill(xd.device, seed, 3, N, index_offset=off)
     FR = plan.type1_rademacher(seed, 3, (nm, nm), index_offset=off)
     plain = NufftPlan(xd, h, tol)
-    assert _rel(FR, plain.type1(R, (nm, nm))) < 5 * tol
+    assert _rel(FR, plain.type1(R, (nm, nm))) < 4 * tol
     assert torch.equal(FR, plan.type1_rademacher(seed, 3, (nm, nm), index_offset=off))
 
 
@@ -155,16 +155,16 @@ def test_many_probe_rows_in_one_pass(T):
     seed, off = 99 + T, 7
     FR = plan.type1_rademacher(seed, T, (nm, nm), index_offset=off)
     R = rademacher_fill(xd.device, seed, T, N, index_offset=off)
-    assert _rel(FR, plain.type1(R, (nm, nm))) < 5 * tol
+    assert _rel(FR, plain.type1(R, (nm, nm))) < 4 * tol
     assert torch.equal(FR, plan.type1_rademacher(seed, T, (nm, nm), index_offset=off))
     g = torch.Generator().manual_seed(T)
     Z = torch.randn(T, N, generator=g, dtype=torch.float64)
     out = plan.type1(Z.cuda(), (nm, nm))
     for b in (0, T // 2, T - 1):
-        assert _rel(out[b], O.nudft_type1(x, h, Z[b], (nm, nm))) < 5 * tol
+        assert _rel(out[b], O.nudft_type1(x, h, Z[b], (nm, nm))) < 2 * tol
     C = torch.complex(Z[:3], Z[1:4])
     outc = plan.type1(C.cuda(), (nm, nm))
-    assert _rel(outc, plain.type1(C.cuda(), (nm, nm))) < 5 * tol
+    assert _rel(outc, plain.type1(C.cuda(), (nm, nm))) < 4 * tol
 
 
 @pytest.mark.parametrize("nm,big,h,tol", [((23, 23), (45, 45), 0.31, 6e-8), ((17, 29), (33, 57), 0.22, 1e-5), ((8, 12), (15, 23), 0.9, 1e-9),

@@ -15,7 +15,7 @@ from oracle import efgp_oracle as O  # noqa: E402
 
 
 def run(cases, seed, verbose=True):
-    """Returns (worst error / tol over the cases, list of failing case descriptions: error > 10 tol + 1e-12)."""
+    """Returns (worst error / tol over the cases, list of failing case descriptions: error > 2 tol + 1e-12)."""
     g = torch.Generator().manual_seed(seed)
 
     def ri(lo, hi):
@@ -67,13 +67,13 @@ def run(cases, seed, verbose=True):
         Ff = plan.type2(f.cuda(), shape)
         rhs = torch.vdot(c.to(torch.complex128).cuda(), Ff)
         ea = abs(complex(lhs - rhs)) / max(float(torch.linalg.norm(c) * torch.linalg.norm(Ff.cpu())), 1e-300)
-        bad = max(e1, e2, ea) > 10 * tol + 1e-12
+        bad = max(e1, e2, ea) > 2 * tol + 1e-12
         worst = max(worst, max(e1, e2, ea) / tol)
         desc = (f"case {case:3d} d={d} nm={nm} tol={tol:.0e} N={N} scale={scale:g} shift={shift:.3g} h={h:.3g} cplx={cplx} real_only={ro}: "
                 f"type1 {e1:.2e} type2 {e2:.2e} adjoint {ea:.2e}")
         if bad:
             failures.append(desc)
-        if verbose and (bad or case % 10 == 0):
+        if verbose and (bad or case % 10 == 0 or globals().get("_ALL")):
             print(f"case {case:3d} d={d} nm={nm} tol={tol:.0e} N={N} scale={scale:g} shift={shift:.3g} h={h:.3g} cplx={cplx} real_only={ro}: "
                   f"type1 {e1:.2e} type2 {e2:.2e} adjoint {ea:.2e}{'   <-- FAIL' if bad else ''}", flush=True)
     if verbose:
