@@ -1404,10 +1404,14 @@ __global__ __launch_bounds__(h48::kThreadsH) void cg_herm48_kernel(Args a) {
         rv[s] = pv[s] = make_double2(0.0, 0.0);
     }
 
+#ifdef EFGP_CG_STAMPS
+    long long stamp_prev = (long long)__builtin_readcyclecounter();
+#endif
     int stop = 0;
     double rcp_rz = 0.0;
     auto apply_A = [&](const double2 (&u)[KS], double2 (&Au)[KS]) __attribute__((always_inline)) {
         double2 v[8], u6[6];
+        EFGP_STAMP(7);
         // A ("6x8"): rows k0 >= 0, modes k1 wrapped to positions k1 mod 48 -> G[k0][f1]
         if (row_role) {
             dft8_in4(make_double2(wsr[0] * u[0].x, wsr[0] * u[0].y), make_double2(wsr[1] * u[1].x, wsr[1] * u[1].y),
@@ -1421,6 +1425,7 @@ __global__ __launch_bounds__(h48::kThreadsH) void cg_herm48_kernel(Args a) {
         stop = s_stop;
         rcp_rz = s_rcp;
         if (stop) return;                                 // uniform: the iteration that just started is abandoned
+        EFGP_STAMP(0);
         // B ("6x8"): packed columns z[k0] = G[k0][q] + i G[k0][q + 24] (k0 >= 0), conj G[-k0][q] + i conj G[-k0][q + 24] (k0 < 0),
         // rows of lane jc < 6: k0 = jc, jc + 6, jc - 12, jc - 6
         if (col_role) {
@@ -1452,6 +1457,7 @@ __global__ __launch_bounds__(h48::kThreadsH) void cg_herm48_kernel(Args a) {
             }
         }
         __syncthreads();
+        EFGP_STAMP(1);
         // D ("8x6"): row k0 >= 0 of the result from the packed columns at +k0 and -k0; conjugated inputs, forward transform
         if (row_role) {
             const double2* tp = Tb + k0 * LT + j;
@@ -1478,6 +1484,7 @@ __global__ __launch_bounds__(h48::kThreadsH) void cg_herm48_kernel(Args a) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) Au[s] = make_double2(0.0, 0.0);
         }
+        EFGP_STAMP(2);
     };
 
     if (tid == 0) {
@@ -1539,6 +1546,7 @@ __global__ __launch_bounds__(h48::kThreadsH) void cg_herm48_kernel(Args a) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) pAp += pv[s].x * Ap[s].x + pv[s].y * Ap[s].y;
         pAp = block_sum_h(pAp * wgt, red) + 1e-16;
+        EFGP_STAMP(3);
         const double alpha = rz / pAp;
         double rr = 0.0, rzn = 0.0;
         double2 zv[KS];
@@ -1554,7 +1562,9 @@ __global__ __launch_bounds__(h48::kThreadsH) void cg_herm48_kernel(Args a) {
         }
         rr *= wgt;
         rzn *= wgt;
+        EFGP_STAMP(4);
         block_sum_pair_h(rr, rzn, red);
+        EFGP_STAMP(5);
         ++it;
         if (wave == 3) {
             const double ratio = div_rcp(sqrt(rr), den_eps, rcp_den);

@@ -2654,6 +2654,7 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     if (const char* eg = std::getenv("EFGP_COOP_G")) G_lat = std::max(1, std::min(G_lat, std::atoi(eg)));   // experiments
     int G_min = 1;
     while (G_min < G_lat && ((nrow + G_min - 1) / G_min) * n1 > 8 * kLineThreads) G_min <<= 1;
+    if (const char* eg = std::getenv("EFGP_COOP_GMIN")) G_min = std::max(G_min, std::min(G_lat, std::atoi(eg)));   // experiments
     int G = G_lat;
     while (G > G_min && (int64_t)G * nbatch > ctx->num_cu) G >>= 1;
     const int ks = ((nrow + G - 1) / G) * n1 <= 4 * kLineThreads ? 4 : 8;

@@ -9,7 +9,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["EFGP_HIP_LIBRARY"] = os.path.join(ROOT, "gp-quadrature_amd", "efgp_hip", "libefgp_hip_stamps.so")
+os.environ.setdefault("EFGP_HIP_LIBRARY", os.path.join(ROOT, "gp-quadrature_amd", "efgp_hip", "libefgp_hip_stamps.so"))
 sys.path.insert(0, os.path.join(ROOT, "gp-quadrature_amd"))
 import torch  # noqa: E402
 import efgp_hip  # noqa: E402

@@ -23,13 +23,11 @@ for eps in (1e-3, 1e-4):
     g = torch.Generator().manual_seed(1)
     probes = (torch.randint(0, 2, (500, M), generator=g) * 2 - 1).to(torch.float64).to(dev)
     ref = None
-    for setting in (os.environ.get("SHAPES", "default,32,16,8,off").split(",")):
-        if setting == "off":
-            os.environ["EFGP_COOP_SOLO_PASS"] = "100000"      # no cap: the round-3 passes (still one grid)
-        elif setting == "default":
-            os.environ.pop("EFGP_COOP_SOLO_PASS", None)
+    for setting in (os.environ.get("SHAPES", "default,2,4,8,16").split(",")):
+        if setting == "default":
+            os.environ.pop("EFGP_COOP_GMIN", None)
         else:
-            os.environ["EFGP_COOP_SOLO_PASS"] = setting
+            os.environ["EFGP_COOP_GMIN"] = setting               # at least this many workgroups per system
         ts = []
         for _ in range(4):
             torch.cuda.synchronize()
@@ -40,4 +38,4 @@ for eps in (1e-3, 1e-4):
         if ref is None:
             ref = var.clone()
         err = float((var - ref).abs().max() / ref.abs().max())
-        print(f"eps {eps:g} mtot {m.last_fit_stats['mtot']} pass {setting}: {sorted(ts)[1]:.2f} ms (min {min(ts):.2f}); max dev from first setting {err:.1e}", flush=True)
+        print(f"eps {eps:g} mtot {m.last_fit_stats['mtot']} G_min {setting}: {sorted(ts)[1]:.2f} ms (min {min(ts):.2f}); max dev from first setting {err:.1e}", flush=True)
