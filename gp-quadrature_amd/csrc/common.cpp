@@ -135,6 +135,33 @@ int* pinned_host(DeviceCtx* ctx, size_t bytes) {
     return ctx->host_pinned;
 }
 
+int upload_small(DeviceCtx* ctx, const void* src, size_t bytes, void* dst, hipStream_t stream) {
+    if (bytes == 0) return EFGP_OK;
+    if (bytes > DeviceCtx::kUploadSlotBytes) {
+        EFGP_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+        EFGP_HIP_CHECK(hipStreamSynchronize(stream));
+        return EFGP_OK;
+    }
+    if (!ctx->up_ring) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, DeviceCtx::kUploadSlots * DeviceCtx::kUploadSlotBytes, hipHostMallocDefault) != hipSuccess) {
+            set_error("hipHostMalloc of the upload ring failed");
+            return EFGP_ENOMEM;
+        }
+        ctx->up_ring = (char*)p;
+        for (int i = 0; i < DeviceCtx::kUploadSlots; ++i) EFGP_HIP_CHECK(hipEventCreateWithFlags(&ctx->up_event[i], hipEventDisableTiming));
+    }
+    const int k = ctx->up_turn;
+    ctx->up_turn = (k + 1) % DeviceCtx::kUploadSlots;
+    if (ctx->up_used[k]) EFGP_HIP_CHECK(hipEventSynchronize(ctx->up_event[k]));      // eight uploads ago: long done
+    char* slot = ctx->up_ring + (size_t)k * DeviceCtx::kUploadSlotBytes;
+    std::memcpy(slot, src, bytes);
+    EFGP_HIP_CHECK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, stream));
+    EFGP_HIP_CHECK(hipEventRecord(ctx->up_event[k], stream));
+    ctx->up_used[k] = true;
+    return EFGP_OK;
+}
+
 static size_t pool_round(size_t bytes) { return (std::max<size_t>(bytes, 1) + 4095) & ~size_t(4095); }
 
 void* pool_alloc(DeviceCtx* ctx, size_t bytes) {
@@ -185,6 +212,11 @@ void release_ctx(int device) {
         for (int s = 0; s < SLOT_COUNT; ++s)
             if (c->buf[s]) (void)hipFree(c->buf[s]);
         if (c->host_pinned) (void)hipHostFree(c->host_pinned);
+        if (c->up_ring) {
+            (void)hipHostFree(c->up_ring);
+            for (int i = 0; i < DeviceCtx::kUploadSlots; ++i)
+                if (c->up_event[i]) (void)hipEventDestroy(c->up_event[i]);
+        }
         if (c->aux_event) (void)hipEventDestroy(c->aux_event);
         if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
         for (auto& kv : c->pool)

@@ -93,6 +93,13 @@ struct DeviceCtx {
     // side stream for hipGraph capture (capture is not allowed on the legacy default stream torch usually hands us)
     hipStream_t aux_stream = nullptr;
     hipEvent_t aux_event = nullptr;
+    // ring of pinned staging slots for small host -> device uploads that must not drain the stream (upload_small)
+    static constexpr int kUploadSlots = 8;
+    static constexpr size_t kUploadSlotBytes = size_t(64) << 10;
+    char* up_ring = nullptr;
+    hipEvent_t up_event[kUploadSlots] = {nullptr};
+    bool up_used[kUploadSlots] = {false};
+    int up_turn = 0;
 };
 
 // a once-per-DEVICE flag (function attributes such as hipFuncAttributeMaxDynamicSharedMemorySize are per device: a
@@ -106,6 +113,11 @@ void* scratch(DeviceCtx* ctx, Slot slot, size_t bytes);
 // cached batched complex-to-complex double plan bound to `stream`
 int fft_plan(DeviceCtx* ctx, int rank, const int64_t* n, int64_t batch, hipStream_t stream, hipfftHandle* out);
 int* pinned_host(DeviceCtx* ctx, size_t bytes);
+// Stream-ordered upload of a small host array WITHOUT waiting for the stream: the bytes are staged in one of a few pinned slots
+// (a slot is reused only after the event behind its last copy has passed).  A copy from pageable memory, or a
+// hipStreamSynchronize behind it to keep the source alive, stalls the host until everything queued has run -- in a training
+// loop that is every step with a new mode count.  Arrays beyond a slot fall back to the blocking copy.
+int upload_small(DeviceCtx* ctx, const void* src, size_t bytes, void* dst, hipStream_t stream);
 // pooled device blocks (rounded up to 4 KB multiples); pool_free returns the block to the free list
 void* pool_alloc(DeviceCtx* ctx, size_t bytes);
 void pool_free(DeviceCtx* ctx, void* p, size_t bytes);

@@ -1977,6 +1977,11 @@ struct WindowSet {          // device copies of the window data for one (toleran
     int dim = 0;
     bool dense = false;     // es_fine_size's rule for dense 2-D point sets
     EsParams p;
+    double* d_block = nullptr;      // ONE pooled device block behind d_coef and d_fac (round 4: one upload, no hipMalloc per set)
+    size_t block_bytes = 0;
+    DeviceCtx* ctx = nullptr;
+    hipStream_t up_stream = nullptr;   // the upload is ordered on this stream; other streams wait for `ready`
+    hipEvent_t ready = nullptr;
     double* d_coef = nullptr;       // [kMaxDegree+1][W], rows above `degree` are zero
     double* d_fac[3] = {nullptr, nullptr, nullptr};
     int64_t nm[3] = {0, 0, 0};
@@ -2026,9 +2031,8 @@ namespace efgp {
 
 static void free_window(WindowSet* w) {
     if (!w) return;
-    if (w->d_coef) (void)hipFree(w->d_coef);
-    for (int a = 0; a < 3; ++a)
-        if (w->d_fac[a]) (void)hipFree(w->d_fac[a]);
+    if (w->d_block && w->ctx) pool_free(w->ctx, w->d_block, w->block_bytes);
+    if (w->ready) (void)hipEventDestroy(w->ready);
     delete w;
 }
 
@@ -2047,6 +2051,7 @@ static int get_window(efgp_nufft_s* plan, const int64_t* n_modes, hipStream_t st
         bool same = w->dim == d && w->tol == plan->tol && w->dense == dense;
         for (int a = 0; a < d && same; ++a) same = w->nm[a] == n_modes[a];
         if (same) {
+            if (w->ready && stream != w->up_stream) EFGP_HIP_CHECK(hipStreamWaitEvent(stream, w->ready, 0));
             *out = w;
             return EFGP_OK;
         }
@@ -2072,28 +2077,39 @@ static int get_window(efgp_nufft_s* plan, const int64_t* n_modes, hipStream_t st
         for (int j = 0; j < (W + 1) / 2; ++j)
             coef[(size_t)(kMaxDegree + 1) * W + (size_t)k * RHP + j] = w->p.coef[j * (kMaxDegree + 1) + k];
     }
-    if (hipMalloc((void**)&w->d_coef, coef.size() * sizeof(double)) != hipSuccess) {
-        free_window(w);
-        set_error("hipMalloc window coefficients failed");
-        return EFGP_ENOMEM;
-    }
-    if (hipMemcpyAsync(w->d_coef, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess ||
-        hipStreamSynchronize(stream) != hipSuccess) {
-        free_window(w);
-        set_error("copy of window coefficients failed");
-        return EFGP_EHIP;
-    }
+    // coefficient tables and the correction factors of every axis in ONE pooled block and ONE stream-ordered upload from a pinned
+    // staging slot: a training step with a new mode count used to pay 1 + d hipMalloc calls and as many copies, each behind a
+    // hipStreamSynchronize that made the host wait for everything the step had queued
+    std::vector<double> host(coef);
+    size_t off[3] = {0, 0, 0};
     for (int a = 0; a < d; ++a) {
         std::vector<double> fac;
         es_deconv_factors(w->p, w->nf[a], w->nm[a], &fac);
-        if (hipMalloc((void**)&w->d_fac[a], fac.size() * sizeof(double)) != hipSuccess ||
-            hipMemcpyAsync(w->d_fac[a], fac.data(), fac.size() * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess ||
-            hipStreamSynchronize(stream) != hipSuccess) {
-            free_window(w);
-            set_error("upload of correction factors failed");
-            return EFGP_EHIP;
-        }
+        while (host.size() % 32) host.push_back(0.0);            // 256-byte alignment of every table
+        off[a] = host.size();
+        host.insert(host.end(), fac.begin(), fac.end());
     }
+    w->ctx = plan->ctx;
+    w->block_bytes = host.size() * sizeof(double);
+    w->d_block = (double*)pool_alloc(plan->ctx, w->block_bytes);
+    if (!w->d_block) {
+        free_window(w);
+        return EFGP_ENOMEM;
+    }
+    const int urc = upload_small(plan->ctx, host.data(), w->block_bytes, w->d_block, stream);
+    if (urc != EFGP_OK) {
+        free_window(w);
+        return urc;
+    }
+    w->up_stream = stream;
+    if (hipEventCreateWithFlags(&w->ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(w->ready, stream) != hipSuccess) {
+        (void)hipGetLastError();
+        EFGP_HIP_CHECK(hipStreamSynchronize(stream));          // no event: make the tables visible to every stream the old way
+        if (w->ready) (void)hipEventDestroy(w->ready);
+        w->ready = nullptr;
+    }
+    w->d_coef = w->d_block;
+    for (int a = 0; a < d; ++a) w->d_fac[a] = w->d_block + off[a];
     if (plan->ctx->window_cache.size() >= 64) {       // bound the cache: drop the oldest entry
         (void)hipDeviceSynchronize();
         free_window((WindowSet*)plan->ctx->window_cache.front());
