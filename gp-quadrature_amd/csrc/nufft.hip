@@ -889,7 +889,7 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_tile_kernel(TileSpreadA
 //   With the points counting-sorted by their first covered cell (tile size 1: the binning above), all
 //   points of a bin share the same W x W stencil, so their contributions can be summed in REGISTERS with
 //   plain FMAs and flushed once per run -- no LDS atomics in the inner loop (the LDS-resident spreader is
-//   bound by ~128 LDS atomics per point).
+//   bound by ~128 LDS atomics per point, see LABNOTES.md section 4.1).
 //   A wavefront takes a contiguous chunk of sorted points and walks the cell runs inside it, 16 points per
 //   iteration; all control flow is wave-uniform.  The 4 lanes of a point (one per DPP row: role = lane/16)
 //   each own one quadrant of the stencil (rows [0,RH) or the mirrored rows, columns likewise).  The window
@@ -2932,7 +2932,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     {
         // Opt-in (EFGP_CELLSORT=1): the kernel itself is 1.2-1.7x faster than the LDS-atomic spreader at >= 250 points
         // per cell, but the per-plan counting sort it needs (0.15 ms at N=1e6, 0.6 ms at N=1e7) only pays off after
-        // several passes over the same plan; see DESIGN.md.
+        // several passes over the same plan; see LABNOTES.md section 4.1.
         const char* force = std::getenv("EFGP_CELLSORT");
         const bool use_cells = force && force[0] == '1' && plan->dim == 2 && w->p.w <= kCellMaxW &&
                                w->p.degree <= w->p.w + 4 && g.cells <= 16384 && plan->npts > 0;

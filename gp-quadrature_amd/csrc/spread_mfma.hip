@@ -8,7 +8,7 @@
 // (c wx) (x) wy of two 8-vectors, and the sum over the points that share a stencil is a rank-K update
 // D += A B with K = points -- exactly what v_mfma_f64_16x16x4_f64 computes (4 points per instruction), with the
 // reduction over points done inside the matrix unit instead of by LDS atomics (the LDS-atomic spreader spends
-// 2 W^2 = 128 ds_add_u64 per point and is bound by LDS bank conflicts).
+// 2 W^2 = 128 ds_add_u64 per point and is bound by LDS bank conflicts, LABNOTES.md section 4.1).
 //   rows    (16) = (channel, x stencil cell): A[(ch, i)][k] = c_ch,k * wx_k[i]
 //   columns (16) = y stencil cell relative to the band's first one: B[k][j + off_k] = wy_k[j], 0 <= off_k <= 8
 // The tile belongs to one x-cell run of one band of the per-model point layout (points_layout.hpp); it is added

@@ -24,7 +24,7 @@ struct LagGeom {
 
 // Transform length of the zero-padded correlation: any length >= 2 n - 1 gives the same lags, so it comes from the short ladder
 // 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, ...  The exact lag-box size 2 mtot - 1 is an odd length that changes with every mtot, and
-// every FFT length new to the process is a runtime compilation in rocFFT (0.5-2 s each).
+// every FFT length new to the process is a runtime compilation in rocFFT (0.5-2 s each, see LABNOTES.md 4.6c).
 static int lag_length(int s) {
     for (int p2 = 1;; p2 *= 2) {
         if (p2 >= s) return p2;

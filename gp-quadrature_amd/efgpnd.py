@@ -379,7 +379,7 @@ class _Grid:
         host_ok = self.M * d <= 16384 and type(kernel).__name__ != "Matern"
         where = self.xis if host_ok else up(self.xis, dev)
         S = kernel.spectral_density(where).to(torch.float64)
-        # The fused solvers treat every system of a model as coefficients of REAL functions (section 4.4 of DESIGN.md), which
+        # The fused solvers treat every system of a model as coefficients of REAL functions (LABNOTES.md section 4.4), which
         # needs ws real and even on the symmetric grid -- true for the spectral density of any real stationary kernel.  The
         # built-in kernels (native path above) are even by construction; a user-supplied spectral_density is checked here, once
         # per grid, so that a broken one is a ValueError at the fit and not NaN coefficients from the kernel's refusal.
