@@ -610,11 +610,41 @@ __device__ __forceinline__ void wave_sync_lds() {
 // data of the lines was even loaded: 3-D mid0 kernel, one pass of <= 256 / (8 R) lines).
 // MUL = 4: the same with the two real spectra of every line already in LDS as double2 pairs, `mul`[k * mul_stride + l] (the
 // cooperative Hermitian solve keeps its workgroup's slice there: no global round trip inside the transform).
-template <int R, int MUL = 0>
+// B = 48 (round 4): lines of 48 R points (96, 192, 384 = 3 * 2^k) -- the smallest smooth circulant grids between the powers of two.
+// The R interleaved sub-transforms are 48-point lines as 6 x 8 in eight lanes (cg_persistent.hip, cg_herm48_kernel: radix 6 on
+// eight lanes, writer-side twiddles, radix 8 on six lanes), the sub-blocks of the exchanges are 48 entries long, and the combine
+// over r hands 48 / (8 R) = 3, 1.5, 0.75 butterflies to a lane (predicated beyond 48).
+__device__ __forceinline__ void dft3_inplace(double2 b0, double2 b1, double2 b2, double2& x0, double2& x1, double2& x2) {
+    const double s = 0.86602540378443864676;
+    const double2 sm = make_double2(b1.x + b2.x, b1.y + b2.y), df = make_double2(b1.x - b2.x, b1.y - b2.y);
+    x0 = make_double2(b0.x + sm.x, b0.y + sm.y);
+    const double2 m = make_double2(fma(-0.5, sm.x, b0.x), fma(-0.5, sm.y, b0.y));
+    x1 = make_double2(fma(s, df.y, m.x), fma(-s, df.x, m.y));
+    x2 = make_double2(fma(-s, df.y, m.x), fma(s, df.x, m.y));
+}
+__device__ __forceinline__ void dft6_inplace(double2 (&v)[6]) {
+    const double s = 0.86602540378443864676;
+    double2 e0, e1, e2, o0, o1, o2;
+    dft3_inplace(v[0], v[2], v[4], e0, e1, e2);
+    dft3_inplace(v[1], v[3], v[5], o0, o1, o2);
+    const double2 w1 = make_double2(fma(s, o1.y, 0.5 * o1.x), fma(-s, o1.x, 0.5 * o1.y));
+    const double2 w2 = make_double2(fma(s, o2.y, -0.5 * o2.x), fma(-s, o2.x, -0.5 * o2.y));
+    v[0] = make_double2(e0.x + o0.x, e0.y + o0.y);
+    v[3] = make_double2(e0.x - o0.x, e0.y - o0.y);
+    v[1] = make_double2(e1.x + w1.x, e1.y + w1.y);
+    v[4] = make_double2(e1.x - w1.x, e1.y - w1.y);
+    v[2] = make_double2(e2.x + w2.x, e2.y + w2.y);
+    v[5] = make_double2(e2.x - w2.x, e2.y - w2.y);
+}
+
+template <int R, int MUL = 0, int B = 64>
 __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, int ld, int nl, const double2* tw,
                                                   const double2* __restrict__ mul = nullptr, int64_t mul_stride = 0,
                                                   int64_t mul_pair = 0) {
-    constexpr int LPL = 8 * R, LINES = kLineThreads / LPL, U = R > 1 ? 8 / R : 1;
+    static_assert(B == 64 || (B == 48 && R >= 2), "sub-transforms of 64 points, or of 48 points under a combine");
+    constexpr int LPL = 8 * R, LINES = kLineThreads / LPL;
+    constexpr int U = B == 64 ? (R > 1 ? 8 / R : 1) : (48 + LPL - 1) / LPL;       // k1 values per lane in the combine
+    constexpr bool kPartial = B == 48 && U * LPL != 48;                          // the last k1 of a lane may lie beyond the block
     double psum = 0.0;          // MUL: this thread's share of sum_k Re(mul_k) |X_k|^2 over its lines (Parseval: <w, T w>)
     const int li = threadIdx.x & (LPL - 1), lsub = threadIdx.x / LPL;
     const int r = li >> 3, j = li & 7;
@@ -623,20 +653,39 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
         double2* s = src + (act ? l0 + lsub : l0) * ld;
         double2* d = dst + (act ? l0 + lsub : l0) * ld;
         double2 v[8];
+        if (B == 64) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = s[R * (j + 8 * t) + r];
-        dft8_inplace(v);
-        wave_sync_lds();
-        if (act) {
+            for (int t = 0; t < 8; ++t) v[t] = s[R * (j + 8 * t) + r];
+            dft8_inplace(v);
+            wave_sync_lds();
+            if (act) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) d[r * 64 + 8 * j + (m ^ j)] = v[m];
+                for (int m = 0; m < 8; ++m) d[r * 64 + 8 * j + (m ^ j)] = v[m];
+            }
+            wave_sync_lds();
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = d[r * 64 + 8 * t + (j ^ t)];
+#pragma unroll
+            for (int t = 1; t < 8; ++t) v[t] = cmul(v[t], tw[R * j * t]);            // w_64^(j t)
+            dft8_inplace(v);                                                        // v[t] = Y_r[j + 8 t]
+        } else {
+            double2 u6[6];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) u6[t] = s[R * (j + 8 * t) + r];
+            dft6_inplace(u6);
+#pragma unroll
+            for (int k = 1; k < 6; ++k) u6[k] = cmul(u6[k], tw[R * j * k]);          // w_48^(j k), writer side (35 R < 48 R: no wrap)
+            wave_sync_lds();
+            if (act) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) d[r * 48 + 6 * j + k] = u6[k];
+            }
+            wave_sync_lds();
+            const int jr = j < 6 ? j : 0;                                           // lanes 6, 7 of a sub-transform idle from here on
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = d[r * 48 + 6 * t + jr];
+            dft8_inplace(v);                                                        // v[t] = Y_r[j + 6 t], j < 6
         }
-        wave_sync_lds();
-#pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = d[r * 64 + 8 * t + (j ^ t)];
-#pragma unroll
-        for (int t = 1; t < 8; ++t) v[t] = cmul(v[t], tw[R * j * t]);            // w_64^(j t)
-        dft8_inplace(v);                                                        // v[t] = Y_r[j + 8 t]
         if (R == 1) {                                                           // a plain 64-point line: done
             if (MUL) {
                 double2 mv[8];
@@ -674,15 +723,16 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
             }
             continue;
         }
+        constexpr int PS = B == 64 ? 8 : 6;                                     // stride of a lane's outputs inside its sub-transform
 #pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = cmul(v[t], tw[r * (j + 8 * t)]);      // w_F^(r k1)
+        for (int t = 0; t < 8; ++t) v[t] = cmul(v[t], tw[r * ((B == 64 ? j : (j < 6 ? j : 0)) + PS * t)]);      // w_F^(r k1)
         wave_sync_lds();
-        if (act) {
+        if (act && (B == 64 || j < 6)) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) s[r * 64 + j + 8 * t] = v[t];
+            for (int t = 0; t < 8; ++t) s[r * B + j + PS * t] = v[t];
         }
         wave_sync_lds();
-        // combine over r: lane li takes k1 = li + LPL u, u < 8 / R
+        // combine over r: lane li takes k1 = li + LPL u, u < U (B = 48: while k1 < 48)
         double2 mv[MUL ? 8 : 1];
         if (MUL) {                                                              // requested now, used after the butterflies
             const int lq = act ? l0 + lsub : l0;
@@ -690,24 +740,25 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int q = 0; q < R; ++q) {
+                    const int k1 = (kPartial && li + LPL * u >= B) ? 0 : li + LPL * u;
                     if (MUL == 5) {
                         mv[u * R + q] = mul[u * R + q];
                     } else if (MUL == 4) {
-                        mv[u * R + q] = mul[(li + LPL * u + 64 * q) * (int)mul_stride + lq];
+                        mv[u * R + q] = mul[(k1 + B * q) * (int)mul_stride + lq];
                     } else if (MUL == 3) {
                         const double* rs = reinterpret_cast<const double*>(mul);
-                        mv[u * R + q] = make_double2(rs[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq],
-                                                     rs[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq + mul_pair]);
+                        mv[u * R + q] = make_double2(rs[(int64_t)(k1 + B * q) * mul_stride + lq],
+                                                     rs[(int64_t)(k1 + B * q) * mul_stride + lq + mul_pair]);
                     } else {
-                        mv[u * R + q] = mul[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq];
-                        if (MUL == 2) mv[u * R + q].y = mul[(int64_t)(li + LPL * u + 64 * q) * mul_stride + lq + mul_pair].x;
+                        mv[u * R + q] = mul[(int64_t)(k1 + B * q) * mul_stride + lq];
+                        if (MUL == 2) mv[u * R + q].y = mul[(int64_t)(k1 + B * q) * mul_stride + lq + mul_pair].x;
                     }
                 }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int q = 0; q < R; ++q) v[u * R + q] = s[q * 64 + li + LPL * u];
+            for (int q = 0; q < R; ++q) v[u * R + q] = s[q * B + ((kPartial && li + LPL * u >= B) ? 0 : li + LPL * u)];
         if (R == 8) {
             dft8_inplace(v);
         } else if (R == 4) {
@@ -723,7 +774,7 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const double2 a0 = v[2 * u], a1 = v[2 * u + 1];
                 v[2 * u] = make_double2(a0.x + a1.x, a0.y + a1.y);
                 v[2 * u + 1] = make_double2(a0.x - a1.x, a0.y - a1.y);
@@ -731,12 +782,13 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
         }
         if (MUL) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < U * R; ++i) {
+                const bool live = act && !(kPartial && li + LPL * (i / R) >= B);
                 if (MUL >= 2) {
-                    if (act) psum += mv[i].x * v[i].x * v[i].x + mv[i].y * v[i].y * v[i].y;
+                    if (live) psum += mv[i].x * v[i].x * v[i].x + mv[i].y * v[i].y * v[i].y;
                     v[i] = make_double2(0.5 * mv[i].x * v[i].x, -0.5 * mv[i].y * v[i].y);
                 } else {
-                    if (act) psum += mv[i].x * (v[i].x * v[i].x + v[i].y * v[i].y);
+                    if (live) psum += mv[i].x * (v[i].x * v[i].x + v[i].y * v[i].y);
                     const double2 m = cmul(v[i], mv[i]);
                     v[i] = make_double2(m.x, -m.y);
                 }
@@ -747,7 +799,8 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int q = 0; q < R; ++q) d[li + LPL * u + 64 * q] = v[u * R + q];
+                for (int q = 0; q < R; ++q)
+                    if (!(kPartial && li + LPL * u >= B)) d[li + LPL * u + B * q] = v[u * R + q];
         }
     }
     __syncthreads();
@@ -759,37 +812,48 @@ __device__ __forceinline__ double line_fft_inwave(double2* src, double2* dst, in
 // with every unrelated code change).  Operands are passed as offsets into the kernel's dynamic LDS so that the accesses
 // stay LDS instructions.
 extern __shared__ double2 efgp_line_lds[];
-template <int R, int MUL>
+template <int R, int MUL, int B = 64>
 __device__ __noinline__ double line_fft_inwave_call(int src_off, int dst_off, int ld, int nl, int tw_off, const double2* mul,
                                                     int64_t mul_stride, int64_t mul_pair = 0) {
-    return line_fft_inwave<R, MUL>(efgp_line_lds + src_off, efgp_line_lds + dst_off, ld, nl, efgp_line_lds + tw_off, mul, mul_stride,
-                                   mul_pair);
+    return line_fft_inwave<R, MUL, B>(efgp_line_lds + src_off, efgp_line_lds + dst_off, ld, nl, efgp_line_lds + tw_off, mul, mul_stride,
+                                      mul_pair);
+}
+// lengths the in-wave transforms cover: 64 R and (round 4) 48 R
+__device__ __host__ __forceinline__ bool line_fft_fast_len(int F) {
+    return F == 64 || F == 128 || F == 256 || F == 512 || F == 96 || F == 192 || F == 384;
+}
+// one dispatch over the line length for every multiply mode (MUL as in line_fft_inwave)
+template <int MUL>
+__device__ __forceinline__ double line_fft_dispatch(int F, int so, int dn, int ld, int nl, int to, const double2* mul, int64_t mul_stride,
+                                                    int64_t mul_pair) {
+    switch (F) {
+        case 128: return line_fft_inwave_call<2, MUL>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
+        case 256: return line_fft_inwave_call<4, MUL>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
+        case 512: return line_fft_inwave_call<8, MUL>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
+        case 96: return line_fft_inwave_call<2, MUL, 48>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
+        case 192: return line_fft_inwave_call<4, MUL, 48>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
+        default: return line_fft_inwave_call<8, MUL, 48>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);      // 384
+    }
 }
 // result buffer is always `dst`
 __device__ __forceinline__ double2* line_fft_fast(double2* src, double2* dst, int F, int ld, int nl, const double2* tw) {
     const int so = (int)(src - efgp_line_lds), dn = (int)(dst - efgp_line_lds), to = (int)(tw - efgp_line_lds);
     if (F == 64) line_fft_inwave_call<1, 0>(so, dn, ld, nl, to, nullptr, 0);
-    else if (F == 128) line_fft_inwave_call<2, 0>(so, dn, ld, nl, to, nullptr, 0);
-    else if (F == 256) line_fft_inwave_call<4, 0>(so, dn, ld, nl, to, nullptr, 0);
-    else line_fft_inwave_call<8, 0>(so, dn, ld, nl, to, nullptr, 0);
+    else line_fft_dispatch<0>(F, so, dn, ld, nl, to, nullptr, 0, 0);
     return dst;
 }
-// forward transform, spectrum multiply (mul[k * mul_stride + l]) and conjugation in one pass (F = 128, 256, 512)
+// forward transform, spectrum multiply (mul[k * mul_stride + l]) and conjugation in one pass (F = 96 .. 512)
 __device__ __forceinline__ double2* line_fft_fast_mul(double2* src, double2* dst, int F, int ld, int nl, const double2* tw,
                                                       const double2* mul, int64_t mul_stride, double& psum) {
     const int so = (int)(src - efgp_line_lds), dn = (int)(dst - efgp_line_lds), to = (int)(tw - efgp_line_lds);
-    if (F == 128) psum += line_fft_inwave_call<2, 1>(so, dn, ld, nl, to, mul, mul_stride);
-    else if (F == 256) psum += line_fft_inwave_call<4, 1>(so, dn, ld, nl, to, mul, mul_stride);
-    else psum += line_fft_inwave_call<8, 1>(so, dn, ld, nl, to, mul, mul_stride);
+    psum += line_fft_dispatch<1>(F, so, dn, ld, nl, to, mul, mul_stride, 0);
     return dst;
 }
 // the same for lines that carry two real columns (MUL = 2)
 __device__ __forceinline__ double2* line_fft_fast_mul2(double2* src, double2* dst, int F, int ld, int nl, const double2* tw,
                                                        const double2* mul, int64_t mul_stride, int64_t mul_pair, double& psum) {
     const int so = (int)(src - efgp_line_lds), dn = (int)(dst - efgp_line_lds), to = (int)(tw - efgp_line_lds);
-    if (F == 128) psum += line_fft_inwave_call<2, 2>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
-    else if (F == 256) psum += line_fft_inwave_call<4, 2>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
-    else psum += line_fft_inwave_call<8, 2>(so, dn, ld, nl, to, mul, mul_stride, mul_pair);
+    psum += line_fft_dispatch<2>(F, so, dn, ld, nl, to, mul, mul_stride, mul_pair);
     return dst;
 }
 // two real columns per line, spectra resident in LDS at offset spec_off (MUL = 4)
@@ -797,9 +861,7 @@ __device__ __forceinline__ double2* line_fft_fast_mul4(double2* src, double2* ds
                                                        const double2* spec_lds, int stride, double& psum) {
     const int so = (int)(src - efgp_line_lds), dn = (int)(dst - efgp_line_lds), to = (int)(tw - efgp_line_lds);
     const double2* mul = efgp_line_lds + (int)(spec_lds - efgp_line_lds);
-    if (F == 128) psum += line_fft_inwave_call<2, 4>(so, dn, ld, nl, to, mul, stride);
-    else if (F == 256) psum += line_fft_inwave_call<4, 4>(so, dn, ld, nl, to, mul, stride);
-    else psum += line_fft_inwave_call<8, 4>(so, dn, ld, nl, to, mul, stride);
+    psum += line_fft_dispatch<4>(F, so, dn, ld, nl, to, mul, stride, 0);
     return dst;
 }
 // two real columns per line, spectra given as a REAL array (MUL = 3)
@@ -833,7 +895,7 @@ __device__ __forceinline__ void spectrum_prefetch(const double* __restrict__ spe
 }
 // in-wave transform for the lengths it covers, the generic Stockham stages otherwise; the result buffer is returned
 __device__ __forceinline__ double2* line_fft_any(double2* A, double2* B, int F, int ld, int nl, const double2* tw) {
-    if (F == 64 || F == 128 || F == 256 || F == 512) return line_fft_fast(A, B, F, ld, nl, tw);
+    if (line_fft_fast_len(F)) return line_fft_fast(A, B, F, ld, nl, tw);
     return line_fft(A, B, F, ld, nl, tw);
 }
 
@@ -1104,7 +1166,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
     const int tid = threadIdx.x, wg = blockIdx.x, sys = blockIdx.y, G = a.G;
     const int n0 = (int)a.g.n[0], n1 = (int)a.g.n[1], F0 = (int)a.g.F[0], F1 = (int)a.g.F[1];
     const int ldr = F1 + 1, ldc = F0 + 1;
-    const int lgF1 = ilog2(F1), lgC = ilog2(a.lpbc);
+    const int lgC = ilog2(a.lpbc);
     const int bufsz = max(a.lines * ldr, a.lpbc * ldc);
     double2* A = lsm;
     double2* B = lsm + bufsz;
@@ -1224,8 +1286,8 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
                 if (ok[s] && lrow[s] >= p0 && lrow[s] < p0 + nl) A[(lrow[s] - p0) * ldr + lcol[s]] = cmul(u[s], wsv[s]);
             __syncthreads();
             const double2* X = line_fft_fast(A, B, F1, ldr, nl, tw1s);
-            for (int w = tid; w < (nl << lgF1); w += kLineThreads) {
-                const int l = w >> lgF1, i1 = w & (F1 - 1);
+            for (int w = tid; w < nl * F1; w += kLineThreads) {
+                const int l = w / F1, i1 = w - l * F1;
                 store_x2<SOLO>(b1 + (int64_t)(r0 + p0 + l) * F1 + i1, X[l * ldr + i1]);
             }
             __syncthreads();                                                  // the next pass refills the buffers
@@ -1279,12 +1341,12 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
 #pragma unroll
             for (int q = 0; q < kCoopLoads; ++q) {
                 const int w = tid + q * kLineThreads;
-                tmp[q] = w < (nl << lgF1) ? load_x2<SOLO>(b2 + (int64_t)(r0 + p0) * F1 + w) : make_double2(0.0, 0.0);   // rows are contiguous
+                tmp[q] = w < nl * F1 ? load_x2<SOLO>(b2 + (int64_t)(r0 + p0) * F1 + w) : make_double2(0.0, 0.0);   // rows are contiguous
             }
 #pragma unroll
             for (int q = 0; q < kCoopLoads; ++q) {
                 const int w = tid + q * kLineThreads;
-                if (w < (nl << lgF1)) A[(w >> lgF1) * ldr + (w & (F1 - 1))] = make_double2(tmp[q].x, -tmp[q].y);
+                if (w < nl * F1) A[(w / F1) * ldr + (w % F1)] = make_double2(tmp[q].x, -tmp[q].y);
             }
             __syncthreads();
             const double2* X = line_fft_fast(A, B, F1, ldr, nl, tw1s);
@@ -1409,7 +1471,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
     const int n0 = (int)a.g.n[0], n1 = (int)a.g.n[1], F0 = (int)a.g.F[0], F1 = (int)a.g.F[1];
     const int h0 = (n0 - 1) / 2, h1 = (n1 - 1) / 2, nh = h0 + 1, halfF1 = F1 >> 1;
     const int ldr = F1 + 1, ldc = F0 + 1;
-    const int lgF1 = ilog2(F1), lgC = ilog2(a.lpbc);
+    const int lgC = ilog2(a.lpbc);
     const int bufsz = max(a.lines * ldr, a.lpbc * ldc);
     double2* A = lsm;
     double2* B = lsm + bufsz;
@@ -1452,7 +1514,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
         lrow[s] = ok[s] ? e / n1 : 0;
         const int lcol = ok[s] ? e - lrow[s] * n1 : 0;
         const int k0 = r0 + lrow[s];
-        pos1[s] = (lcol - h1) & (F1 - 1);
+        pos1[s] = (lcol - h1 + F1) % F1;
         tix[s] = (h0 + k0) * n1 + lcol;
         wgt[s] = k0 == 0 ? 1.0 : 2.0;
         if (ok[s]) {
@@ -1523,8 +1585,8 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
                 if (ok[s] && lrow[s] >= p0 && lrow[s] < p0 + nl) A[(lrow[s] - p0) * ldr + pos1[s]] = make_double2(wsr[s] * u[s].x, wsr[s] * u[s].y);
             __syncthreads();
             const double2* X = line_fft_fast(A, B, F1, ldr, nl, tw1s);
-            for (int w = tid; w < (nl << lgF1); w += kLineThreads) {
-                const int l = w >> lgF1, i1 = w & (F1 - 1);
+            for (int w = tid; w < nl * F1; w += kLineThreads) {
+                const int l = w / F1, i1 = w - l * F1;
                 store_x2<SOLO>(b1 + (int64_t)(r0 + p0 + l) * F1 + i1, X[l * ldr + i1]);
             }
             __syncthreads();
@@ -1581,7 +1643,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
             COOP_STAMP(5);
             for (int w = tid; w < (nh << lgC); w += kLineThreads) {
                 const int l = w & (a.lpbc - 1), k0 = w >> lgC;
-                const double2 zp = Z[l * ldc + k0], zm = Z[l * ldc + ((F0 - k0) & (F0 - 1))];
+                const double2 zp = Z[l * ldc + k0], zm = Z[l * ldc + (k0 == 0 ? 0 : F0 - k0)];
                 const double px = zp.x, py = -zp.y, mx = zm.x, my = -zm.y;       // T[k0], T[-k0]
                 store_x2<SOLO>(b2 + (int64_t)k0 * F1 + c0 + l, make_double2(px + mx, py - my));            // T + conj T(-)
                 store_x2<SOLO>(b2 + (int64_t)k0 * F1 + c0 + l + halfF1, make_double2(py + my, mx - px));   // (T - conj T(-)) / i
@@ -1600,12 +1662,12 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
 #pragma unroll
             for (int q = 0; q < kCoopLoads; ++q) {
                 const int w = tid + q * kLineThreads;
-                tmp[q] = w < (nl << lgF1) ? load_x2<SOLO>(b2 + (int64_t)(r0 + p0) * F1 + w) : make_double2(0.0, 0.0);   // rows are contiguous
+                tmp[q] = w < nl * F1 ? load_x2<SOLO>(b2 + (int64_t)(r0 + p0) * F1 + w) : make_double2(0.0, 0.0);   // rows are contiguous
             }
 #pragma unroll
             for (int q = 0; q < kCoopLoads; ++q) {
                 const int w = tid + q * kLineThreads;
-                if (w < (nl << lgF1)) A[(w >> lgF1) * ldr + (w & (F1 - 1))] = make_double2(tmp[q].x, -tmp[q].y);
+                if (w < nl * F1) A[(w / F1) * ldr + (w % F1)] = make_double2(tmp[q].x, -tmp[q].y);
             }
             __syncthreads();
             COOP_STAMP(8);
@@ -2250,7 +2312,7 @@ __global__ __launch_bounds__(256) void center_spectrum_kernel(const double2* __r
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)F0 * F1) return;
     const int f0 = (int)(t / F1), f1 = (int)(t - (int64_t)f0 * F1);
-    const double2 a = tw0[((int64_t)(n0 - 1) * f0) & (F0 - 1)], b = tw1[((int64_t)(n1 - 1) * f1) & (F1 - 1)];
+    const double2 a = tw0[((int64_t)(n0 - 1) * f0) % F0], b = tw1[((int64_t)(n1 - 1) * f1) % F1];
     const double2 ph = make_double2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));      // conj(a b)
     out[t] = cmul(vhat[t], ph);
 }
@@ -2300,6 +2362,13 @@ struct efgp_toeplitz_s {
     // the specialised 64 x 64 kernels (any F >= 2 n - 1 embeds the Toeplitz product exactly; measured 3.1 us per iteration
     // against 9-11 us of the generic kernel on the 32 x 32 grid).  fft_shape / efgp_toeplitz_apply keep the reference's grid.
     double2* vhat_c = nullptr;   // lines_ok grids: centred spectrum for the cooperative solve (center_spectrum_kernel)
+    // Round 4: the cooperative solve runs on the smallest grid of the in-wave transforms (64 R or 48 R: 96, 128, 192, 256, 384, 512)
+    // that holds 2 n - 1 -- 141 -> 192 instead of 256, 81 -> 96 instead of 128 (0.56 x the grid).  fft_shape, efgp_toeplitz_apply
+    // and the multi-launch iteration keep the reference's power-of-two grid.
+    bool coop_small = false;
+    ToepGeom g_co;
+    double2* vhat_co = nullptr;  // centred spectrum on g_co
+    double2* tw_co[2] = {nullptr, nullptr};
     double* vc3 = nullptr;       // lines3_ok grids: REAL centred spectrum of the Hermitian 3-D iteration, built on first use
     ToepGeom g_cg;
     double2* vhat_cg = nullptr;
@@ -2498,6 +2567,51 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
             }
         }
     }
+    if (op->lines_ok && op->vhat_c && std::getenv("EFGP_NO_COOP_SMALL") == nullptr) {
+        static const int64_t ladder[] = {96, 128, 192, 256, 384, 512};
+        op->g_co = op->g;
+        op->g_co.Ftot = 1;
+        bool smaller = false;
+        for (int a = 0; a < 2; ++a) {
+            for (int64_t c : ladder)
+                if (c >= op->Ls[a]) {
+                    op->g_co.F[a] = c;
+                    break;
+                }
+            smaller = smaller || op->g_co.F[a] < op->g.F[a];
+            op->g_co.Ftot *= op->g_co.F[a];
+        }
+        if (smaller) {
+            op->tw_co[0] = twiddle_table_for(ctx, op->g_co.F[0], stream);
+            op->tw_co[1] = twiddle_table_for(ctx, op->g_co.F[1], stream);
+            op->vhat_co = (op->tw_co[0] && op->tw_co[1]) ? (double2*)pool_alloc(ctx, (size_t)op->g_co.Ftot * sizeof(double2)) : nullptr;
+            if (op->vhat_co) {
+                // spectrum on the small grid: FFT(zero-padded v) / Ftot, then the centring rotation in place
+                ToepGeom gp = op->g_co;
+                gp.M = 1;
+                for (int a = 0; a < 3; ++a) {
+                    gp.n[a] = op->Ls[a];
+                    gp.M *= gp.n[a];
+                }
+                hipLaunchKernelGGL(pad_scale_kernel, grid_for(gp.Ftot, 1, kVecThreads), dim3(kVecThreads), 0, stream, gp, (const double2*)v, gp.M,
+                                   (const double2*)nullptr, (const int*)nullptr, (const int*)nullptr, op->vhat_co, 1.0 / (double)gp.Ftot);
+                bool ok = hipGetLastError() == hipSuccess && fft_c2c(ctx, 2, op->g_co.F, 1, op->vhat_co, true, stream) == EFGP_OK;
+                if (ok) {
+                    hipLaunchKernelGGL(center_spectrum_kernel, dim3((unsigned)((op->g_co.Ftot + 255) / 256)), dim3(256), 0, stream, op->vhat_co,
+                                       op->tw_co[0], op->tw_co[1], (int)op->g.n[0], (int)op->g.n[1], (int)op->g_co.F[0], (int)op->g_co.F[1],
+                                       op->vhat_co);
+                    ok = hipGetLastError() == hipSuccess;
+                }
+                if (ok) {
+                    op->coop_small = true;
+                } else {
+                    (void)hipGetLastError();
+                    pool_free(ctx, op->vhat_co, (size_t)op->g_co.Ftot * sizeof(double2));
+                    op->vhat_co = nullptr;
+                }
+            }
+        }
+    }
     if (dim == 2 && op->persistent_ok && op->g.n[0] == op->g.n[1] && op->g.F[0] == op->g.F[1] && op->g.F[0] < 64 &&
         op->Ls[0] <= 63 && std::getenv("EFGP_NO_CG64_EMBED") == nullptr && std::getenv("EFGP_NO_CG64") == nullptr) {
         op->g_cg = op->g;
@@ -2555,6 +2669,7 @@ int efgp_toeplitz_destroy(efgp_toeplitz_t* op) {
     if (op->vhat_cg) pool_free(op->ctx, op->vhat_cg, (size_t)4096 * sizeof(double2));
     if (op->vhat48) pool_free(op->ctx, op->vhat48, (size_t)2304 * sizeof(double2));
     if (op->vhat_c) pool_free(op->ctx, op->vhat_c, (size_t)op->g.Ftot * sizeof(double2));
+    if (op->vhat_co) pool_free(op->ctx, op->vhat_co, (size_t)op->g_co.Ftot * sizeof(double2));
     if (op->vc3) pool_free(op->ctx, op->vc3, (size_t)op->g.Ftot * sizeof(double));
     delete op;
     return EFGP_OK;
@@ -2563,6 +2678,18 @@ int efgp_toeplitz_destroy(efgp_toeplitz_t* op) {
 int efgp_toeplitz_fft_shape(efgp_toeplitz_t* op, int64_t* shape_out) {
     EFGP_REQUIRE(op && shape_out, "efgp_toeplitz_fft_shape: null argument");
     for (int a = 0; a < op->g.d; ++a) shape_out[a] = op->g.F[a];
+    return EFGP_OK;
+}
+
+int efgp_toeplitz_cg_shape(efgp_toeplitz_t* op, int hermitian, int64_t* shape_out) {
+    EFGP_REQUIRE(op && shape_out, "efgp_toeplitz_cg_shape: null argument");
+    for (int a = 0; a < op->g.d; ++a) shape_out[a] = op->g.F[a];
+    if (op->g.d == 2 && op->persistent_ok) {
+        if (hermitian && op->h48.vhat && std::getenv("EFGP_NO_CG48") == nullptr) shape_out[0] = shape_out[1] = 48;
+        else if (op->cg64) shape_out[0] = shape_out[1] = 64;
+    } else if (op->coop_small && std::getenv("EFGP_NO_COOP_SMALL") == nullptr && std::getenv("EFGP_NO_CG_COOP") == nullptr) {
+        for (int a = 0; a < 2; ++a) shape_out[a] = op->g_co.F[a];
+    }
     return EFGP_OK;
 }
 
@@ -2641,7 +2768,8 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
                         void* x, int nbatch, double tol, int max_iter, int early_stop, int batched_semantics, int* d_iters,
                         hipStream_t stream, CoopInfo* info, int nan_on_dead, int hermitian = 0) {
     DeviceCtx* ctx = op->ctx;
-    const ToepGeom g = op->g;
+    const bool small = op->coop_small && std::getenv("EFGP_NO_COOP_SMALL") == nullptr;
+    const ToepGeom g = small ? op->g_co : op->g;
     const int F0 = (int)g.F[0], F1 = (int)g.F[1], n0 = (int)g.n[0], n1 = (int)g.n[1];
     // Hermitian systems (the caller's promise, checked by the kernel): rows k0 >= 0 only, column pairs (cg_coop2d_herm_kernel)
     const bool herm = hermitian && (n0 & 1) && (n1 & 1) && n0 >= 3 && std::getenv("EFGP_NO_CG_COOP_HERM") == nullptr;
@@ -2652,11 +2780,17 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     int G_lat = F1 / 8;      // 16 / 32 / 64 (measured at 128^2: 19.9 us per iteration with 16 workgroups, 22.7 with 32, 20.6 with 8)
     if (herm && F1 <= 256) G_lat = F1 / 16;   // half the work per system: 8 / 16 workgroups measured best at 128^2 / 256^2, 64 at 512^2
     if (const char* eg = std::getenv("EFGP_COOP_G")) G_lat = std::max(1, std::min(G_lat, std::atoi(eg)));   // experiments
-    int G_min = 1;
-    while (G_min < G_lat && ((nrow + G_min - 1) / G_min) * n1 > 8 * kLineThreads) G_min <<= 1;
-    if (const char* eg = std::getenv("EFGP_COOP_GMIN")) G_min = std::max(G_min, std::min(G_lat, std::atoi(eg)));   // experiments
+    // the workgroup counts a grid offers: G_lat halved while it stays whole (16 8 4 2 1; 12 6 3 1 on the 48 R grids)
+    auto halve = [](int Gv) { return Gv > 1 ? ((Gv & 1) ? 1 : Gv / 2) : 1; };
+    int G_min = G_lat;       // the smallest count whose rows still fit a workgroup's registers (8 vector entries per thread)
+    while (G_min > 1 && ((nrow + halve(G_min) - 1) / halve(G_min)) * n1 <= 8 * kLineThreads) G_min = halve(G_min);
+    if (const char* eg = std::getenv("EFGP_COOP_GMIN")) {                                                       // experiments
+        int Gv = G_lat;
+        while (Gv > G_min && halve(Gv) >= std::atoi(eg)) Gv = halve(Gv);
+        G_min = std::max(G_min, Gv);
+    }
     int G = G_lat;
-    while (G > G_min && (int64_t)G * nbatch > ctx->num_cu) G >>= 1;
+    while (G > G_min && (int64_t)G * nbatch > ctx->num_cu) G = halve(G);
     const int ks = ((nrow + G - 1) / G) * n1 <= 4 * kLineThreads ? 4 : 8;
     // columns per LDS pass: as many as the workgroup owns, the per-thread load registers (16) and the LDS allow -- a pass of
     // 8 columns leaves one work item per thread and stage (latency bound: 134 us per iteration of a 128^2 system on one CU
@@ -2665,6 +2799,7 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     int lpbc = 1;
     while (lpbc * 2 <= std::min(ncol / G, load_cap)) lpbc <<= 1;
     while (lpbc > 4 && ((size_t)4 * lpbc * (F0 + 1) + (size_t)F0 + (size_t)F1) * sizeof(double2) + 2048 > (size_t)ctx->max_lds) lpbc >>= 1;
+    while (lpbc > 1 && (ncol / G) % lpbc) lpbc >>= 1;           // a pass count per workgroup must be whole (48 R grids: 3 * 2^k lines)
     bool shape_ok = G <= kCoopMaxG && ((nrow + G - 1) / G) * n1 <= ks * kLineThreads && ncol % (G * lpbc) == 0;
     const int rows_wg = (nrow + G - 1) / G, cols_wg = ncol / G;
     int lines = std::min(rows_wg, kCoopLoads * kLineThreads / F1);
@@ -2702,9 +2837,9 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     ca.batched = batched_semantics;
     ca.max_iter = max_iter;
     if (!op->vhat_c) return EFGP_EUNSUPPORTED;
-    ca.vhat = op->vhat_c;
-    ca.tw0 = op->tw[0];
-    ca.tw1 = op->tw[1];
+    ca.vhat = small ? op->vhat_co : op->vhat_c;
+    ca.tw0 = small ? op->tw_co[0] : op->tw[0];
+    ca.tw1 = small ? op->tw_co[1] : op->tw[1];
     ca.b1 = pad;
     ca.b2 = pad + grid_elems;
     ca.b3 = pad + 2 * grid_elems;

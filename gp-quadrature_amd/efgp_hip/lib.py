@@ -63,6 +63,7 @@ _SIGNATURES = {
     "efgp_toeplitz_apply": (_I, [_VP, _VP, _I, _VP, _VP]),
     "efgp_toeplitz_apply_scaled": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP]),
     "efgp_toeplitz_fft_shape": (_I, [_VP, _PI64]),
+    "efgp_toeplitz_cg_shape": (_I, [_VP, _I, _PI64]),
     "efgp_cg_solve": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _VP]),
     "efgp_fft_c2c": (_I, [_I, _I, C.POINTER(C.c_longlong), C.c_longlong, _VP, _I, _I, _VP]),
     "efgp_cg_solve_hermitian": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _VP]),

@@ -215,6 +215,13 @@ class ToeplitzOp:
         check(lib().efgp_toeplitz_fft_shape(self._h, shp), "efgp_toeplitz_fft_shape")
         self.fft_shape = [int(shp[a]) for a in range(self.d)]
 
+    def cg_shape(self, hermitian=False):
+        """Circulant grid the fused CG solves of this operator run on (efgp_toeplitz_cg_shape): the smallest one the solvers'
+        transforms cover that holds 2 n - 1 per axis; `fft_shape` stays the reference's grid."""
+        shp = (C.c_int64 * 3)()
+        check(lib().efgp_toeplitz_cg_shape(self._h, int(bool(hermitian)), shp), "efgp_toeplitz_cg_shape")
+        return [int(shp[a]) for a in range(self.d)]
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             lib().efgp_toeplitz_destroy(self._h)

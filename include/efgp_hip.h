@@ -169,6 +169,11 @@ int efgp_toeplitz_apply_scaled(efgp_toeplitz_t* op, const void* x, int x_is_real
                                void* y, void* stream);
 /* FFT grid shape chosen (d host int64), for inspection (ToeplitzND.fft_shape) */
 int efgp_toeplitz_fft_shape(efgp_toeplitz_t* op, int64_t* shape_out);
+/* circulant grid the fused CG solves of this operator run on (d host int64): any F >= 2 n - 1 embeds the Toeplitz product exactly
+ * (the reference's own alternative to next_pow2: efgpnd.py:1269-1271, `_next_fast_fft_size`), so the solvers take the smallest grid
+ * their transforms cover -- 2-D: 48 x 48 (hermitian != 0, blocks <= 23 x 23) or 64 x 64 in one workgroup, 96 / 128 / 192 / 256 / 384 /
+ * 512 per axis in the cooperative launch; otherwise the reference's grid.  fft_shape and efgp_toeplitz_apply are unaffected. */
+int efgp_toeplitz_cg_shape(efgp_toeplitz_t* op, int hermitian, int64_t* shape_out);
 
 /* ---- preconditioned CG on G = D T D: replaces cg.py ConjugateGradients.solve() for the operators
  * of efgpnd.py:1572-1631 --------------------------------------------------------------------------

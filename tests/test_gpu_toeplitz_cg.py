@@ -1,5 +1,7 @@
 """GPU parity: Toeplitz mat-vec and the fused CG (C ABI) vs the oracle restatement of
 ToeplitzND (efgpnd.py:1239-1393) and cg.py:86-244."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -323,3 +325,62 @@ def test_async_solve_on_mid_size_grids():
     xg, itg, _ = cg_solve(op, ws_e.cuda(), 0.5, 0, bh.cuda(), torch.zeros_like(bh).cuda(), 1e-9, diag=dg_e.cuda(), batched=False)
     xh, lz = cg_solve_async(op, ws_e.cuda(), 0.5, 0, bh.cuda(), torch.zeros_like(bh).cuda(), 1e-9, diag=dg_e.cuda(), batched=False, hermitian=True)
     assert abs(int(lz) - itg) <= 1 and _rel(xh, xg) < 1e-7
+
+
+def _psd_system(n0, n1, seed, nb):
+    """Toeplitz vector of 2500 random points on an (n0, n1) block (positive semi-definite, as a model's), even real ws, right-hand
+    sides that are transforms of real data."""
+    g = torch.Generator().manual_seed(seed)
+    xp = torch.rand(2500, 2, generator=g, dtype=torch.float64) * 2 - 1
+    k0 = torch.arange(-(n0 - 1), n0, dtype=torch.float64)
+    k1 = torch.arange(-(n1 - 1), n1, dtype=torch.float64)
+    E0 = torch.exp(-2j * math.pi * 0.31 * k0[:, None] * xp[None, :, 0])
+    E1 = torch.exp(-2j * math.pi * 0.27 * k1[:, None] * xp[None, :, 1])
+    v = (E0 @ E1.T).contiguous()
+    w = torch.exp(-3.0 * torch.rand(n0, n1, generator=g, dtype=torch.float64))
+    ws = (0.5 * (w + w.flip(0, 1))).reshape(-1).to(torch.complex128)
+    b = torch.complex(torch.randn(nb, n0, n1, generator=g, dtype=torch.float64), torch.randn(nb, n0, n1, generator=g, dtype=torch.float64))
+    b = (0.5 * (b + b.flip(1, 2).conj())).reshape(nb, -1) * torch.logspace(-1, 1, nb, dtype=torch.float64)[:, None]
+    return v, ws, b
+
+
+@pytest.mark.parametrize("n0,n1,grid", [(41, 41, (96, 96)), (47, 47, (96, 96)), (67, 67, (192, 192)), (71, 71, (192, 192)),
+                                        (95, 95, (192, 192)), (131, 131, (384, 384)), (41, 71, (96, 192)), (67, 41, (192, 96)),
+                                        (57, 57, (128, 128)), (33, 99, (96, 256))])
+def test_cooperative_solves_on_the_smallest_grid_equal_the_power_of_two_grid(n0, n1, grid, monkeypatch):
+    """Round 4: the cooperative 2-D solves run on the smallest grid of the in-wave transforms that holds 2 n - 1 per axis -- 96, 192,
+    384 (48 R lines: `line_fft_inwave<R, MUL, 48>`) between the powers of two; the Toeplitz product is exact on any such grid
+    (efgpnd.py:1266-1271).  Against the same solves on the reference's next_pow2 grid (EFGP_NO_COOP_SMALL): iteration counts equal
+    (+- 1 in several hundred), solutions within 10 x the CG tolerance -- Hermitian kernel (single system) and general kernel (batch with per-row stopping, single system)."""
+    from efgp_hip import ToeplitzOp, cg_solve
+    nb = 5
+    v, ws, b = _psd_system(n0, n1, 3 + n0, nb)
+    sig = 25.0                                            # well conditioned: tens of iterations, counts are crisp
+    diag = (2500.0 * ws.abs().pow(2).real + sig).cuda()
+    op = ToeplitzOp(v.cuda())
+    pow2 = [1 << (2 * n - 2).bit_length() for n in (n0, n1)]
+    assert list(op.fft_shape) == pow2 and tuple(op.cg_shape()) == grid and tuple(op.cg_shape(hermitian=True)) == grid
+    runs = {}
+    for small in (True, False):
+        if not small:
+            monkeypatch.setenv("EFGP_NO_COOP_SMALL", "1")
+            assert list(op.cg_shape()) == pow2
+        herm = cg_solve(op, ws.cuda(), sig, 0, b[2].cuda(), None, 1e-8, diag=diag, batched=False, hermitian=True)
+        gen1 = cg_solve(op, ws.cuda(), sig, 0, b[1].cuda(), None, 1e-8, diag=diag, batched=False)
+        genb = cg_solve(op, ws.cuda(), sig, 0, b.cuda(), None, 1e-8, diag=diag, batched=True)
+        # A_var without a preconditioner (the variance's systems): 50 forced iterations -- on the ill-conditioned operator the
+        # rounding of two correct transforms separates the iterates along the recurrence, as it does between any two solvers
+        genv = cg_solve(op, ws.cuda(), sig, 1, b.cuda(), None, 1e-300, batched=True, max_iter=50, early_stop=False)
+        runs[small] = (herm, gen1, genb, genv)
+    monkeypatch.delenv("EFGP_NO_COOP_SMALL")
+    for a_, b_ in zip(runs[True], runs[False]):
+        # same recurrences, different rounding: a stopping index may move by one in a few hundred iterations
+        assert all(abs(p - q) <= 1 + q // 200 for p, q in zip(a_[2], b_[2])), (a_[1:], b_[1:])
+        assert _rel(a_[0], b_[0]) < 1e-5, _rel(a_[0], b_[0])          # cond x tolerance: two correct solvers on one system
+    # the TRUE residual of the small-grid solutions under the operator applied on the REFERENCE's grid (efgp_toeplitz_apply)
+    wsd = ws.cuda()
+    for x_, rhs in ((runs[True][0][0], b[2].cuda()), (runs[True][1][0], b[1].cuda())):
+        Ax = wsd * op.apply(wsd * x_) + sig * x_
+        assert float(torch.linalg.norm(Ax - rhs) / torch.linalg.norm(rhs)) < 1.05e-8
+    assert len(set(runs[True][2][2])) > 1             # per-row stopping happened in the batch
+    assert runs[True][0][1] < 2 * n0 * n1            # the preconditioned mean system converged before its iteration cap
