@@ -366,8 +366,10 @@ def launch_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: 200 timed steps of 0.3 ms behind 20 warm-up steps (60 ms in all) -- 20 steps behind 3 left the figure at the mercy of
+    # one slow launch (0.277-0.302 ms from run to run on the same code)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--global-n", type=int, default=N_PER_GPU, help="points of the GLOBAL problem, sharded over the ranks")
     ap.add_argument("--no-extras", action="store_true", help="skip the weak-scaling and north-star legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
