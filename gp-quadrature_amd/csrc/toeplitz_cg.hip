@@ -2441,6 +2441,21 @@ static int circulant(efgp_toeplitz_s* op, double2* pad, int slots, hipStream_t s
                : fft_c2c(op->ctx, op->g.d, op->g.F, slots, pad, false, stream);
 }
 
+// vhat_c = vhat rotated so that the circular convolution has its crop window at [0, n) (cooperative solve on the reference's grid)
+static bool ensure_centred_spectrum(efgp_toeplitz_s* op, hipStream_t stream) {
+    if (op->vhat_c) return true;
+    op->vhat_c = (double2*)pool_alloc(op->ctx, (size_t)op->g.Ftot * sizeof(double2));
+    if (!op->vhat_c) return false;
+    hipLaunchKernelGGL(center_spectrum_kernel, dim3((unsigned)((op->g.Ftot + 255) / 256)), dim3(256), 0, stream, op->vhat, op->tw[0],
+                       op->tw[1], (int)op->g.n[0], (int)op->g.n[1], (int)op->g.F[0], (int)op->g.F[1], op->vhat_c);
+    if (hipGetLastError() != hipSuccess) {
+        pool_free(op->ctx, op->vhat_c, (size_t)op->g.Ftot * sizeof(double2));
+        op->vhat_c = nullptr;
+        return false;
+    }
+    return true;
+}
+
 }  // namespace efgp
 
 extern "C" {
@@ -2556,18 +2571,7 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
             op->tw[a] = dtw;
         }
     }
-    if (op->lines_ok) {
-        op->vhat_c = (double2*)pool_alloc(ctx, (size_t)op->g.Ftot * sizeof(double2));
-        if (op->vhat_c) {
-            hipLaunchKernelGGL(center_spectrum_kernel, dim3((unsigned)((op->g.Ftot + 255) / 256)), dim3(256), 0, stream, op->vhat, op->tw[0],
-                               op->tw[1], (int)op->g.n[0], (int)op->g.n[1], (int)op->g.F[0], (int)op->g.F[1], op->vhat_c);
-            if (hipGetLastError() != hipSuccess) {
-                pool_free(ctx, op->vhat_c, (size_t)op->g.Ftot * sizeof(double2));
-                op->vhat_c = nullptr;
-            }
-        }
-    }
-    if (op->lines_ok && op->vhat_c && std::getenv("EFGP_NO_COOP_SMALL") == nullptr) {
+    if (op->lines_ok && std::getenv("EFGP_NO_COOP_SMALL") == nullptr) {
         static const int64_t ladder[] = {96, 128, 192, 256, 384, 512};
         op->g_co = op->g;
         op->g_co.Ftot = 1;
@@ -2612,6 +2616,9 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
             }
         }
     }
+    // the centred spectrum on the reference's grid: needed by the cooperative solve only when it runs there (no smaller grid, or
+    // EFGP_NO_COOP_SMALL later on: built on first use then)
+    if (op->lines_ok && !op->coop_small) (void)ensure_centred_spectrum(op, stream);
     if (dim == 2 && op->persistent_ok && op->g.n[0] == op->g.n[1] && op->g.F[0] == op->g.F[1] && op->g.F[0] < 64 &&
         op->Ls[0] <= 63 && std::getenv("EFGP_NO_CG64_EMBED") == nullptr && std::getenv("EFGP_NO_CG64") == nullptr) {
         op->g_cg = op->g;
@@ -2836,7 +2843,7 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     ca.early_stop = early_stop;
     ca.batched = batched_semantics;
     ca.max_iter = max_iter;
-    if (!op->vhat_c) return EFGP_EUNSUPPORTED;
+    if (!small && !ensure_centred_spectrum(op, stream)) return EFGP_EUNSUPPORTED;
     ca.vhat = small ? op->vhat_co : op->vhat_c;
     ca.tw0 = small ? op->tw_co[0] : op->tw[0];
     ca.tw1 = small ? op->tw_co[1] : op->tw[1];
