@@ -88,16 +88,49 @@ __global__ __launch_bounds__(256) void band_key_kernel(const double* __restrict_
         mx[b] = 0ull;
     }
     __syncthreads();
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < npts; n += (int64_t)gridDim.x * blockDim.x) {
-        const double2 p = reinterpret_cast<const double2*>(x)[n];
-        int b = (int)floor((p.y - lo1) * inv_h1);
-        b = b < 0 ? 0 : (b >= nbands ? nbands - 1 : b);
-        keys[n] = ((unsigned long long)b << 56) | (enc_f64(p.x) >> 8);
-        vals[n] = (int)n;
-        const unsigned long long e = enc_f64(p.y);
-        atomicAdd(&cnt[b], 1ull);
-        atomicMin(&mn[b], e);
-        atomicMax(&mx[b], e);
+    // wave-uniform trip count: every lane stays in the loop (the wave-level reduction below shuffles across all 64 lanes)
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < npts; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = base + threadIdx.x;
+        const bool valid = n < npts;
+        int b = -1;
+        unsigned long long e = 0ull;
+        if (valid) {
+            const double2 p = reinterpret_cast<const double2*>(x)[n];
+            b = (int)floor((p.y - lo1) * inv_h1);
+            b = b < 0 ? 0 : (b >= nbands ? nbands - 1 : b);
+            keys[n] = ((unsigned long long)b << 56) | (enc_f64(p.x) >> 8);
+            vals[n] = (int)n;
+            e = enc_f64(p.y);
+        }
+        if (nbands >= 64) {                      // many bands: the lanes of a wave rarely meet on an address
+            if (valid) {
+                atomicAdd(&cnt[b], 1ull);
+                atomicMin(&mn[b], e);
+                atomicMax(&mx[b], e);
+            }
+        } else {
+            // few bands (8-16 at N = 1e6): 256 threads on 3 x nbands LDS addresses serialise -- 231 us of this 1e6-point pass
+            // (rocprofv3, round 4).  One lane per DISTINCT band of the wave adds the wave's count / min / max for it.
+            unsigned long long todo = __ballot(valid);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int bb = __shfl(b, leader, 64);
+                const bool mine = b == bb;
+                const unsigned long long m = __ballot(mine);
+                unsigned long long lo_ = mine ? e : ~0ull, hi_ = mine ? e : 0ull;
+                for (int off = 32; off > 0; off >>= 1) {
+                    const unsigned long long l2 = __shfl_xor(lo_, off, 64), h2 = __shfl_xor(hi_, off, 64);
+                    lo_ = l2 < lo_ ? l2 : lo_;
+                    hi_ = h2 > hi_ ? h2 : hi_;
+                }
+                if ((int)(threadIdx.x & 63) == leader) {
+                    atomicAdd(&cnt[bb], (unsigned long long)__popcll(m));
+                    atomicMin(&mn[bb], lo_);
+                    atomicMax(&mx[bb], hi_);
+                }
+                todo &= ~m;
+            }
+        }
     }
     __syncthreads();
     for (int b = threadIdx.x; b < nbands; b += blockDim.x) {
@@ -129,7 +162,14 @@ __global__ __launch_bounds__(256) void values_max_kernel(const double* __restric
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         m = fmax(m, isfinite(y[i]) ? fabs(y[i]) : INFINITY);            // non-finite targets poison the fit (see fixed_scale_write)
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+    // one atomic per WORKGROUP: 8192 wave atomics on one address were 80 of this pass's 95 us at N = 1e6
+    __shared__ double wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+        if (m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+    }
 }
 
 static void free_level(SortedLevel* l) {
@@ -362,7 +402,7 @@ int efgp_points_attach_values(efgp_points_t* pts, const double* y, void* stream_
         }
         pts->pair_scale_ready = false;
         EFGP_HIP_CHECK(hipMemsetAsync(pts->d_values_max, 0, 8, stream));
-        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((pts->npts + 255) / 256, 2048));
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((pts->npts + 255) / 256, 1024));
         hipLaunchKernelGGL(values_max_kernel, dim3(blocks), dim3(256), 0, stream, y, pts->npts, pts->d_values_max);
         EFGP_HIP_CHECK(hipGetLastError());
     }
