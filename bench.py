@@ -49,6 +49,7 @@ N_PER_GPU = 1_000_000
 DIM = 2
 LS, VAR, SIG2, EPS = 0.2, 2.0, 0.2, 1e-4
 NUFFT_TOL, CG_TOL = 1e-7, 1e-4
+WARMUP_DEFAULT = 20            # + a floor of 0.5 s of warm-up steps when left at this value (see main)
 
 
 def synth(N, d, seed, device):
@@ -369,7 +370,7 @@ def main():
     # defaults: 200 timed steps of 0.3 ms behind 20 warm-up steps (60 ms in all) -- 20 steps behind 3 left the figure at the mercy of
     # one slow launch (0.277-0.302 ms from run to run on the same code)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=WARMUP_DEFAULT)
     ap.add_argument("--global-n", type=int, default=N_PER_GPU, help="points of the GLOBAL problem, sharded over the ranks")
     ap.add_argument("--no-extras", action="store_true", help="skip the weak-scaling and north-star legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -427,8 +428,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    # Warm-up: W steps, and when W was left at its default also at least 0.5 s of them.  A fresh process stalls two or three times for
+    # 35-60 ms of HOST time during its first ~0.25 s of stepping (tools/r4/first_process_steps.py, cpu_burn_probe.py: `import torch`
+    # alone burns 4 CPU-seconds in 0.8 s and gets the cgroup throttled; one-off runtime pool growth follows) -- with the device-bound
+    # step at 0.28 ms a single such stall inside a 56-ms timed region reads as 0.46-0.53 ms per step.
+    t_w = time.perf_counter()
+    warm_done = 0
+    # (several ranks: every step holds a collective, so all ranks must take the SAME number of steps -- a fixed 1500 instead of a clock)
+    warm_steps = 1500 if (distributed and args.warmup == WARMUP_DEFAULT) else args.warmup
+    while warm_done < warm_steps or (not distributed and args.warmup == WARMUP_DEFAULT and time.perf_counter() - t_w < 0.5):
         step()
+        warm_done += 1
+        if warm_done % 64 == 0:
+            torch.cuda.synchronize(dev)             # the time floor is wall time of EXECUTED steps, not of enqueued ones
     barrier()
     # inside the timed region only the roofline's kernel (the fused spread) carries HIP events: every timed launch puts two
     # event records into the stream, and with all timers on they cost the 0.3-ms step ~10 % (measured: 0.331 vs 0.291 ms)
@@ -460,7 +472,7 @@ def main():
     if args.main_only:
         if rank == 0:
             print(json.dumps({"metric": "GP-fits/sec (main-only profiling run)", "value": fits_per_s,
-                              "ms_per_step": ms_per_step, "steps": args.steps, "warmup": args.warmup, "n_gpus": world}))
+                              "ms_per_step": ms_per_step, "steps": args.steps, "warmup": warm_done, "n_gpus": world}))
         if distributed:
             dist.barrier()
             dist.destroy_process_group()
@@ -592,7 +604,7 @@ def main():
             "metric": "GP-fits/sec (fit + posterior mean at the N training points), N=1e6 d=2 SE kernel",
             "value": fits_per_s,
             "unit": "GP fits/s of the global N=1e6 problem (whole job; the points are sharded over the GPUs)",
-            "n_gpus": world, "rccl_ranks": world if distributed else 0, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": world if distributed else 0, "steps": args.steps, "warmup": warm_done,
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D squared-exponential l=0.2 var=2 sigma2=0.2, eps=1e-4, global N=1e6 synthetic "
