@@ -1918,7 +1918,7 @@ __global__ __launch_bounds__(kInterpThreads) void interp_real_halo_kernel(Interp
 // ds_read2_b64 (8-byte alignment): twice the LDS cycles per byte (MI355X_MICROARCH section LDS), and the gather is
 // LDS-bound (PMC, round 1).  No processing order is needed: points are streamed as the caller holds them, so x
 // loads and result stores stay coalesced and no per-plan ordering pass exists.
-template <int W, bool PF>
+template <int W>
 __global__ __launch_bounds__(kInterpThreads) void interp_real2_pair_kernel(InterpArgs a) {
     extern __shared__ double lds[];
     constexpr int WP = (W + 1) / 2;                  // 16-byte pairs per stencil row
@@ -1936,17 +1936,11 @@ __global__ __launch_bounds__(kInterpThreads) void interp_real2_pair_kernel(Inter
     }
     __syncthreads();
     double* out = reinterpret_cast<double*>(a.out) + (int64_t)batch * a.npts;
-    // the coordinates of the NEXT trip are requested before this trip's stencil work (round 4): a workgroup's waves leave the fill
-    // barrier together, so without it every trip began with the whole CU waiting on one HBM round trip (4 trips at N = 1e6)
-    const int64_t stride = (int64_t)gridDim.x * kInterpThreads;
-    int64_t n = (int64_t)blockIdx.x * kInterpThreads + threadIdx.x;
-    double2 xy_next = (PF && n < a.npts) ? reinterpret_cast<const double2*>(a.x)[n] : make_double2(0.0, 0.0);
-    for (; n < a.npts; n += stride) {
+    for (int64_t n = (int64_t)blockIdx.x * kInterpThreads + threadIdx.x; n < a.npts; n += (int64_t)gridDim.x * kInterpThreads) {
         double v0[W], v1[W], v2[W];
         int f0 = 0, f1 = 0, f2 = 0;
         {
-            const double2 xy = PF ? xy_next : reinterpret_cast<const double2*>(a.x)[n];
-            if (PF && n + stride < a.npts) xy_next = reinterpret_cast<const double2*>(a.x)[n + stride];
+            const double2 xy = reinterpret_cast<const double2*>(a.x)[n];
             double Xw[3] = {0.0, 0.0, 0.0};
             Xw[0] = fold(a.g.scale[0] * (xy.x - a.g.xcen[0]), (double)nf0);
             Xw[1] = fold(a.g.scale[1] * (xy.y - a.g.xcen[1]), (double)nf1);
@@ -2408,11 +2402,10 @@ static size_t interp_pair_lds_bytes(int nf0, int nf1, int W) {
 }
 
 static hipError_t launch_interp_pair(int W, dim3 grid, size_t lds_bytes, hipStream_t s, const InterpArgs& a) {
-    const bool pf = !(std::getenv("EFGP_GATHER_PREFETCH") && std::atoi(std::getenv("EFGP_GATHER_PREFETCH")) == 0);
     switch (W) {
 #define EFGP_CASE(w_)                                                                                               \
     case w_: {                                                                                                      \
-        auto k = pf ? interp_real2_pair_kernel<w_, true> : interp_real2_pair_kernel<w_, false>;                     \
+        auto k = interp_real2_pair_kernel<w_>;                                                                      \
         if (lds_bytes > 65536) {                                                                                    \
             hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             if (e != hipSuccess) return e;                                                                          \
