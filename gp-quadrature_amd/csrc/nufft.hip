@@ -2658,6 +2658,23 @@ static SortedLevel* pick_level(efgp_nufft_s* plan, const WindowSet* w, const Gri
         if (per_run < (forced ? 1.0 : (hb == 1 ? 192.0 : 24.0))) continue;
         nb = n;
         cells = hb;
+        if (hb == 8) {
+            // A level costs a sort of the N points (2 ms at N = 1e6) and 28 B per point.  A gradient step makes two plans on one
+            // model -- the Toeplitz box (4 m + 1 modes) and the probe box (mtot modes) on a grid half as fine -- whose coarsest
+            // levels differ by a factor two: the probe plan takes the pair plan's level when it exists (bands 2-4 cells high instead
+            // of 4-8: a few more run ends per band, no second sort; round 4: the layout-building step 4.3 -> 2.4 ms).
+            bool have = false;
+            for (const SortedLevel* l : pts->levels) have = have || l->nbands == n;
+            for (int f = 2; !have && f <= 4; f *= 2) {
+                const double per_run_f = (double)plan->npts / ((double)(n * f) * std::max(1.0, span[0]));
+                if (n * f > kMaxBands || per_run_f < 24.0) break;
+                for (const SortedLevel* l : pts->levels)
+                    if (l->nbands == n * f) {
+                        nb = n * f;
+                        have = true;
+                    }
+            }
+        }
         break;
     }
     if (!nb) return nullptr;
