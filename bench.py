@@ -589,7 +589,7 @@ def main():
         spread_avg_s = (spread_ms / max(spread_n, 1)) * 1e-3
         achieved = spread_bytes / spread_avg_s / 1e9 if spread_n else None
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r3_pmc_hbm_n1000000.json")
+        tpath = os.path.join(ROOT, "profiles", "r4_pmc_hbm_n1000000.json")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
