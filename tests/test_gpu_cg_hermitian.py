@@ -341,6 +341,7 @@ def test_smallest_circulant_grid_48_equals_64(mtot, precond, tol, monkeypatch):
     centre = vd[tuple((s - 1) // 2 for s in vd.shape)].real
     op = ToeplitzOp(vd)
     assert tuple(op.fft_shape) == ((64, 64) if mtot >= 17 else tuple(op.fft_shape))      # the reference's grid is what is reported
+    assert op.cg_shape(hermitian=True) == ([48, 48] if mtot <= 23 else [64, 64]) and op.cg_shape() == [64, 64]
     beta, lazy = cg_solve_mean_async(op, ws.cuda(), 0.25, centre if precond else None, fy.cuda(), tol)
     it48 = int(lazy)
     monkeypatch.setenv("EFGP_NO_CG48", "1")
