@@ -606,7 +606,12 @@ def main():
             "unit": "GP fits/s of the global N=1e6 problem (whole job; the points are sharded over the GPUs)",
             "n_gpus": world, "rccl_ranks": world if distributed else 0, "steps": args.steps, "warmup": warm_done,
             "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong",
+            "scaling_note": "strong scaling of the metric's global N = 1e6: only the two N-scale launches shard; the mean solve (one "
+                            "M-sized system, ~70 % of the one-GPU step) is replicated, so the curve is capped near 1.2 x at 8 GPUs by "
+                            "construction (scaling_model, from the one-GPU timers); weak_scaling and north_star_n1e7 carry the cases "
+                            "that gain",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D squared-exponential l=0.2 var=2 sigma2=0.2, eps=1e-4, global N=1e6 synthetic "
                                    "(BASELINE configs[1] at the metric's N=1e6), points sharded over the GPUs",
                        "n_per_gpu": N, "global_n": NG, "d": DIM, "mtot": mtot, "M": mtot ** DIM,

@@ -32,8 +32,42 @@ def compute_device(*tensors, device=None):
     return torch.device("cuda", idx)
 
 
+# The wrappers below run a dozen times per fit / gradient step, and the step had become HOST-bound (round 4: 300 us of kernels in a
+# 430-us gradient step): `torch.cuda.current_stream(dev)` builds a Stream object (5.7 us) and `torch.cuda.device(dev)` resolves its
+# argument through `_get_device_index` (2.7 us, twice per wrapper) -- ~25 such calls per step.  Both have direct C entry points.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_exchange = getattr(torch._C, "_cuda_exchangeDevice", None)
+_maybe_exchange = getattr(torch._C, "_cuda_maybeExchangeDevice", None) or _exchange
+
+
 def _stream(dev):
+    if _raw_stream is not None and dev.index is not None:
+        return C.c_void_p(_raw_stream(dev.index))
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class _on:
+    """`with _on(dev):` is `with torch.cuda.device(dev):` without the argument resolution and object churn."""
+    __slots__ = ("idx", "prev", "ctx")
+
+    def __init__(self, dev):
+        self.idx = dev.index if (_exchange is not None and getattr(dev, "index", None) is not None) else -1
+        self.prev = -1
+        self.ctx = None
+
+    def __enter__(self):
+        if self.idx >= 0:
+            self.prev = _exchange(self.idx)
+        else:
+            self.ctx = torch.cuda.device(self.idx if self.idx >= 0 else None)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.idx >= 0:
+            _maybe_exchange(self.prev)
+            return False
+        return self.ctx.__exit__(*exc)
 
 
 def _ptr(t):
@@ -56,7 +90,7 @@ class PointSet:
         self.npts, self.dim = x.shape
         self.values = None
         self._h = C.c_void_p()
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             check(lib().efgp_points_create(C.byref(self._h), self.dev.index, self.dim, self.npts, _ptr(x), _stream(self.dev)),
                   "efgp_points_create")
         if values is not None:
@@ -65,7 +99,7 @@ class PointSet:
     def attach_values(self, y):
         assert y.is_cuda and y.dtype == _RD and y.is_contiguous() and y.numel() == self.npts
         self.values = y
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             check(lib().efgp_points_attach_values(self._h, _ptr(y), _stream(self.dev)), "efgp_points_attach_values")
 
     def bounds(self):
@@ -130,7 +164,7 @@ class NufftPlan:
         cc = cc.to(device=self.dev, dtype=_CD if is_c else _RD).contiguous()
         B = cc.shape[0]
         out = torch.empty((B,) + tuple(int(m) for m in n_modes), dtype=_CD, device=self.dev)
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             check(lib().efgp_nufft_type1(self._h, _ptr(cc), int(is_c), B, _i64(n_modes), isign, int(modeord),
                                          _ptr(out), _stream(self.dev)), "efgp_nufft_type1")
         return out if batched else out[0]
@@ -138,7 +172,7 @@ class NufftPlan:
     def type1_rademacher(self, seed, nbatch, n_modes, index_offset=0, modeord=0):
         """F* Z for Z[b,n] = +-1 generated in the kernel from (seed, b, n + index_offset) -> (B, *n_modes)."""
         out = torch.empty((int(nbatch),) + tuple(int(m) for m in n_modes), dtype=_CD, device=self.dev)
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             check(lib().efgp_nufft_type1_rademacher(self._h, int(seed) & (2 ** 64 - 1), int(index_offset), int(nbatch),
                                                     _i64(n_modes), int(modeord), _ptr(out), _stream(self.dev)),
                   "efgp_nufft_type1_rademacher")
@@ -157,14 +191,14 @@ class NufftPlan:
         # one buffer, two views: the sharded fit all-reduces both results in place with a single collective
         flat = torch.empty(My + Mo, dtype=_CD, device=self.dev)
         out_y, out_o = flat[:My].view(shape_y), flat[My:].view(shape_o)
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             check(lib().efgp_nufft_type1_pair(self._h, _ptr(yy), _i64(n_modes_y), _ptr(out_y), _i64(n_modes_one),
                                               _ptr(out_o), _stream(self.dev)), "efgp_nufft_type1_pair")
         return out_y, out_o
 
     def type1_ones(self, n_modes):
         out_o = torch.empty(tuple(int(m) for m in n_modes), dtype=_CD, device=self.dev)
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             check(lib().efgp_nufft_type1_pair(self._h, None, None, None, _i64(n_modes), _ptr(out_o),
                                               _stream(self.dev)), "efgp_nufft_type1_pair")
         return out_o
@@ -180,7 +214,7 @@ class NufftPlan:
         ff = f.reshape(-1, M).to(device=self.dev, dtype=_CD).contiguous()
         B = ff.shape[0]
         out = torch.empty((B, self.npts), dtype=_RD if real_only else _CD, device=self.dev)
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             if mode_scale is None:
                 check(lib().efgp_nufft_type2(self._h, _ptr(ff), B, _i64(n_modes), isign, int(modeord), _ptr(out),
                                              int(bool(real_only)), _stream(self.dev)), "efgp_nufft_type2")
@@ -208,7 +242,7 @@ class ToeplitzOp:
         for n in self.ns:
             self.size *= n
         self._h = C.c_void_p()
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             check(lib().efgp_toeplitz_create(C.byref(self._h), self.dev.index, self.d, _i64(self.Ls), _ptr(self.v),
                                              int(bool(force_pow2)), _stream(self.dev)), "efgp_toeplitz_create")
         shp = (C.c_int64 * 3)()
@@ -237,7 +271,7 @@ class ToeplitzOp:
         """u (..., size) complex on the device -> same shape."""
         uu = u.reshape(-1, self.size).to(device=self.dev, dtype=_CD).contiguous()
         out = torch.empty_like(uu)
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             check(lib().efgp_toeplitz_apply(self._h, _ptr(uu), uu.shape[0], _ptr(out), _stream(self.dev)),
                   "efgp_toeplitz_apply")
         return out.reshape(u.shape)
@@ -251,7 +285,7 @@ class ToeplitzOp:
         assert res.is_contiguous() and res.dtype == _CD and res.numel() == uu.numel()
         for dgl in (pre, post):
             assert dgl is None or (dgl.is_cuda and dgl.dtype == _CD and dgl.is_contiguous() and dgl.numel() == self.size)
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             check(lib().efgp_toeplitz_apply_scaled(self._h, _ptr(uu), int(real), uu.shape[0], _ptr(pre) if pre is not None else None,
                                                    _ptr(post) if post is not None else None, _ptr(res), _stream(self.dev)),
                   "efgp_toeplitz_apply_scaled")
@@ -269,7 +303,7 @@ def gradient_prepare(ws, fy, v_center, sigmasq, want_diag=True, want_rhs=True):
     ff = fy.reshape(-1).to(dtype=_CD).contiguous() if want_rhs else None
     if want_diag:
         assert v_center.is_cuda and v_center.dtype == _CD and v_center.numel() == 1
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib().efgp_gradient_prepare(dev.index, M, _ptr(ws), _ptr(ff) if ff is not None else None,
                                           _ptr(v_center) if want_diag else None, float(sigmasq), _ptr(diag) if want_diag else None,
                                           _ptr(rhs) if want_rhs else None, _stream(dev)), "efgp_gradient_prepare")
@@ -289,7 +323,7 @@ def gradient_assemble(fy, tg, ws, beta, dprime, fz, v, beta_all, *, variance_idx
     assert beta_all.numel() == (K + 1) * T * M and (K == 0 or fz.numel() == T * M)
     out = torch.empty(3 * (H + 1) + 1, dtype=_RD, device=dev)
     tix = (C.c_int * max(1, K))(*[int(i) for i in trace_idx])
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib().efgp_gradient_assemble(dev.index, M, T, H, -1 if variance_idx is None else int(variance_idx), K, tix,
                                            _ptr(fy), _ptr(tg), _ptr(ws), _ptr(beta), _ptr(dprime) if H else None,
                                            _ptr(fz) if K else None, _ptr(v), _ptr(beta_all), float(sigmasq), float(n_obs), float(yy),
@@ -329,7 +363,7 @@ def cg_solve(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=Tru
     B = bb.shape[0]
     iters = C.c_int(0)
     rows = (C.c_int * B)()
-    with torch.cuda.device(dev):
+    with _on(dev):
         # hermitian: the synchronous entry keeps the promise too (3-D grids carry the planes k0 >= 0 only)
         fn = lib().efgp_cg_solve_hermitian if hermitian else lib().efgp_cg_solve
         check(fn(op._h, _ptr(wsd), float(sigmasq), int(variant), _ptr(dg) if dg is not None else None,
@@ -416,7 +450,7 @@ def cg_solve_async(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_st
     B = bb.shape[0]
     mi = int(max_iter) if max_iter is not None else 2 * op.size
     rows_dev = torch.empty(B, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         fn = lib().efgp_cg_solve_hermitian_async if hermitian else lib().efgp_cg_solve_async
         rc = fn(op._h, _ptr(wsd), float(sigmasq), int(variant), _ptr(dg) if dg is not None else None, _ptr(bb), _ptr(x), B,
                 float(tol), mi, int(bool(early_stop)), int(bool(batched)), _ptr(rows_dev), _stream(dev))
@@ -447,7 +481,7 @@ def cg_solve_mean_async(op, ws, sigmasq, diag_scale, fy, tol, max_iter=None, ear
             raise ValueError("diag_scale must hold one value")
     mi = int(max_iter) if max_iter is not None else 2 * op.size
     rows_dev = torch.empty(1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib().efgp_cg_solve_mean_async(op._h, _ptr(wsd), float(sigmasq), _ptr(ds) if ds is not None else None, _ptr(ff),
                                             _ptr(x), float(tol), mi, int(bool(early_stop)), _ptr(rows_dev), _stream(dev))
     if rc == EFGP_EUNSUPPORTED:
@@ -469,7 +503,7 @@ def lanczos(op, ws, sigmasq, variant, z, steps):
     beta = torch.zeros((P, int(steps)), dtype=_RD, device=dev)
     norm2 = torch.empty(P, dtype=_RD, device=dev)
     taken = torch.empty(P, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib().efgp_lanczos(op._h, _ptr(wsd), float(sigmasq), int(variant), _ptr(zz), P, int(steps), _ptr(alpha), _ptr(beta),
                                 _ptr(norm2), _ptr(taken), _stream(dev))
     if rc == EFGP_EUNSUPPORTED:
@@ -485,7 +519,7 @@ def lag_sums(gamma, eta, mtot, dim):
     gg = gamma.reshape(-1, M).to(_CD).contiguous()
     ee = eta.reshape(-1, M).to(device=dev, dtype=_RD).contiguous()
     out = torch.empty((2 * int(mtot) - 1,) * int(dim), dtype=_CD, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib().efgp_lag_sums(dev.index, int(dim), int(mtot), _ptr(gg), _ptr(ee), gg.shape[0], _ptr(out), _stream(dev)),
               "efgp_lag_sums")
     return out
@@ -498,7 +532,7 @@ def variance_rhs(x_new, h, mtot, ws):
     B, d = xn.shape
     wsd = ws.to(_CD).contiguous()
     out = torch.empty((B, wsd.numel()), dtype=_CD, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib().efgp_variance_rhs(dev.index, d, int(mtot), float(h), _ptr(xn), B, _ptr(wsd), _ptr(out), _stream(dev)),
               "efgp_variance_rhs")
     return out
@@ -512,7 +546,7 @@ def variance_contract(x_new, h, mtot, ws, gamma):
     wsd = ws.to(_CD).contiguous()
     gg = gamma.reshape(B, -1).to(_CD).contiguous()
     out = torch.empty(B, dtype=_RD, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib().efgp_variance_contract(dev.index, d, int(mtot), float(h), _ptr(xn), B, _ptr(wsd), _ptr(gg), _ptr(out),
                                            _stream(dev)), "efgp_variance_contract")
     return out
@@ -532,26 +566,26 @@ class RcclComm:
         assert len(unique_id) == 128
         self.dev, self.rank, self.world = dev, int(rank), int(world)
         self._h = C.c_void_p()
-        with torch.cuda.device(dev):
+        with _on(dev):
             check(lib().efgp_comm_init(C.byref(self._h), dev.index, self.rank, self.world, C.c_char_p(unique_id)), "efgp_comm_init")
 
     def all_reduce_sum_(self, t):
         buf = torch.view_as_real(t) if t.is_complex() else t
         assert buf.is_cuda and buf.dtype == _RD and buf.is_contiguous()
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             check(lib().efgp_comm_allreduce_sum(self._h, _ptr(buf), buf.numel(), _stream(self.dev)), "efgp_comm_allreduce_sum")
         return t
 
     def all_reduce_minmax_(self, t, take_max):
         assert t.is_cuda and t.dtype == _RD and t.is_contiguous()
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             check(lib().efgp_comm_allreduce_minmax(self._h, _ptr(t), t.numel(), int(bool(take_max)), _stream(self.dev)),
                   "efgp_comm_allreduce_minmax")
         return t
 
     def broadcast_(self, t, root=0):
         assert t.is_cuda and t.is_contiguous()
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             check(lib().efgp_comm_broadcast(self._h, _ptr(t), t.numel() * t.element_size(), int(root), _stream(self.dev)),
                   "efgp_comm_broadcast")
         return t
@@ -574,7 +608,7 @@ def vdot_real(a, b):
     aa = a.reshape(-1).to(_CD if a.is_complex() else _RD).contiguous()
     bb = b.reshape(-1).to(device=dev, dtype=_CD if b.is_complex() else _RD).contiguous()
     out = C.c_double(0.0)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib().efgp_vdot_real(dev.index, _ptr(aa), int(aa.is_complex()), _ptr(bb), int(bb.is_complex()),
                                    aa.numel(), C.byref(out), _stream(dev)), "efgp_vdot_real")
     return float(out.value)
@@ -583,7 +617,7 @@ def vdot_real(a, b):
 def rademacher_fill(dev, seed, nbatch, npts, index_offset=0):
     """The +-1 probes `NufftPlan.type1_rademacher` uses, materialised as a (nbatch, npts) float64 tensor."""
     out = torch.empty((int(nbatch), int(npts)), dtype=_RD, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib().efgp_rademacher_fill(dev.index, int(seed) & (2 ** 64 - 1), int(index_offset), int(nbatch), int(npts),
                                          _ptr(out), _stream(dev)), "efgp_rademacher_fill")
     return out

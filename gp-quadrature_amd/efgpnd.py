@@ -417,11 +417,13 @@ class _Grid:
         dev = torch.device(dev)
         ws_d = torch.empty(self.M, dtype=torch.complex128, device=dev)
         dp_d = torch.empty((self.M, 2), dtype=torch.complex128, device=dev) if want_grad else None
-        with torch.cuda.device(dev):
-            rc = lib().efgp_spectral_weights(dev.index if dev.index is not None else torch.cuda.current_device(), kc[0], int(self.d),
+        from efgp_hip.ops import _on, _stream
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        with _on(dev):
+            rc = lib().efgp_spectral_weights(dev.index, kc[0], int(self.d),
                                              float(kc[1]), float(ell), float(var), float(kc[2]), float(self.h), int(self.mtot),
-                                             ws_d.data_ptr(), dp_d.data_ptr() if want_grad else None,
-                                             torch.cuda.current_stream(dev).cuda_stream)
+                                             ws_d.data_ptr(), dp_d.data_ptr() if want_grad else None, _stream(dev))
         return (ws_d, dp_d) if rc == 0 else None
 
 
