@@ -2688,6 +2688,11 @@ int efgp_toeplitz_fft_shape(efgp_toeplitz_t* op, int64_t* shape_out) {
     return EFGP_OK;
 }
 
+int efgp_toeplitz_single_launch_solves(efgp_toeplitz_t* op) {
+    EFGP_REQUIRE(op, "efgp_toeplitz_single_launch_solves: null argument");
+    return (op->persistent_ok && std::getenv("EFGP_NO_PERSISTENT_CG") == nullptr) ? 1 : 0;
+}
+
 int efgp_toeplitz_cg_shape(efgp_toeplitz_t* op, int hermitian, int64_t* shape_out) {
     EFGP_REQUIRE(op && shape_out, "efgp_toeplitz_cg_shape: null argument");
     for (int a = 0; a < op->g.d; ++a) shape_out[a] = op->g.F[a];

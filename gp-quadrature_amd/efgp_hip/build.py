@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
-SOURCES = ["es_kernel.cpp", "grid_host.cpp", "common.cpp", "nufft.hip", "spread_mfma.hip", "points_layout.hip", "small_dft.hip", "variance_ops.hip", "gradient_ops.hip", "comm.cpp", "toeplitz_cg.hip", "cg_persistent.hip", "line_fft.hip"]
+SOURCES = ["es_kernel.cpp", "grid_host.cpp", "common.cpp", "nufft.hip", "spread_mfma.hip", "points_layout.hip", "small_dft.hip", "variance_ops.hip", "gradient_ops.hip", "gradient_step.cpp", "comm.cpp", "toeplitz_cg.hip", "cg_persistent.hip", "line_fft.hip"]
 HEADERS = ["es_kernel.hpp", "common.hpp", "toeplitz_cg.hpp", "nufft_dev.hpp", "points_layout.hpp", "spread_mfma.hpp", "small_dft.hpp", "line_fft.hpp", os.path.join("..", "..", "include", "efgp_hip.h")]
 TARGET = os.path.join(HERE, "libefgp_hip.so")
 

@@ -64,6 +64,7 @@ _SIGNATURES = {
     "efgp_toeplitz_apply_scaled": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP]),
     "efgp_toeplitz_fft_shape": (_I, [_VP, _PI64]),
     "efgp_toeplitz_cg_shape": (_I, [_VP, _I, _PI64]),
+    "efgp_toeplitz_single_launch_solves": (_I, [_VP]),
     "efgp_cg_solve": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _VP]),
     "efgp_fft_c2c": (_I, [_I, _I, C.POINTER(C.c_longlong), C.c_longlong, _VP, _I, _I, _VP]),
     "efgp_cg_solve_hermitian": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _VP]),
@@ -73,6 +74,8 @@ _SIGNATURES = {
     "efgp_spectral_weights": (_I, [_I, _I, _I, _D, _D, _D, _D, _D, _I, _VP, _VP, _VP]),
     "efgp_gradient_prepare": (_I, [_I, _I64, _VP, _VP, _VP, _D, _VP, _VP, _VP]),
     "efgp_gradient_assemble": (_I, [_I, _I64, _I, _I, _I, _I, C.POINTER(_I), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _D, _D, _D, _D, _VP, _VP]),
+    "efgp_gradient_step": (_I, [_VP, _I, _I, _I64, _VP, _VP, _D, _I, _I, _D, _D, _D, _D, _D, _D, _D, _D, _I, _I, C.c_uint64, C.c_uint64,
+                           _I, _I, _I, _I, C.POINTER(_I), _VP, _D, _D, _VP, _VP, _VP, _VP, _VP]),
     "efgp_cg_solve_hermitian_async": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, _VP, _VP]),
     "efgp_cg_solve_mean_async": (_I, [_VP, _VP, _D, _VP, _VP, _VP, _D, _I, _I, _VP, _VP]),
     "efgp_cg_record_history": (_I, [_VP, _I]),

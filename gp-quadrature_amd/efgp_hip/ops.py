@@ -48,9 +48,10 @@ def _stream(dev):
 
 class _on:
     """`with _on(dev):` is `with torch.cuda.device(dev):` without the argument resolution and object churn."""
-    __slots__ = ("idx", "prev", "ctx")
+    __slots__ = ("idx", "prev", "ctx", "_dev")
 
     def __init__(self, dev):
+        self._dev = dev
         self.idx = dev.index if (_exchange is not None and getattr(dev, "index", None) is not None) else -1
         self.prev = -1
         self.ctx = None
@@ -59,7 +60,7 @@ class _on:
         if self.idx >= 0:
             self.prev = _exchange(self.idx)
         else:
-            self.ctx = torch.cuda.device(self.idx if self.idx >= 0 else None)
+            self.ctx = torch.cuda.device(self._dev)
             self.ctx.__enter__()
         return self
 
@@ -72,6 +73,14 @@ class _on:
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr())
+
+
+def _dc(t, dev, dtype):
+    """`t.to(device=dev, dtype=dtype).contiguous()`, returning `t` itself when it already is all that: the no-op conversions cost
+    ~2 us each and a step makes some thirty of them."""
+    if t.dtype is dtype and t.device == dev and t.is_contiguous():
+        return t
+    return t.to(device=dev, dtype=dtype).contiguous()
 
 
 def _i64(vals):
@@ -180,7 +189,7 @@ class NufftPlan:
 
     def type1_pair(self, y, n_modes_y, n_modes_one):
         """One pass over the points: (F* y on n_modes_y, F* 1 on n_modes_one)."""
-        yy = y.to(device=self.dev, dtype=_RD).contiguous()
+        yy = _dc(y, self.dev, _RD)
         shape_y, shape_o = tuple(int(m) for m in n_modes_y), tuple(int(m) for m in n_modes_one)
         My = 1
         for m in shape_y:
@@ -211,7 +220,7 @@ class NufftPlan:
             M *= int(m)
         if batched is None:
             batched = not (f.ndim == 1 or tuple(f.shape) == tuple(int(m) for m in n_modes))
-        ff = f.reshape(-1, M).to(device=self.dev, dtype=_CD).contiguous()
+        ff = _dc(f.reshape(-1, M), self.dev, _CD)
         B = ff.shape[0]
         out = torch.empty((B, self.npts), dtype=_RD if real_only else _CD, device=self.dev)
         with _on(self.dev):
@@ -219,7 +228,7 @@ class NufftPlan:
                 check(lib().efgp_nufft_type2(self._h, _ptr(ff), B, _i64(n_modes), isign, int(modeord), _ptr(out),
                                              int(bool(real_only)), _stream(self.dev)), "efgp_nufft_type2")
             else:
-                sc = mode_scale.reshape(-1).to(device=self.dev, dtype=_CD).contiguous()
+                sc = _dc(mode_scale.reshape(-1), self.dev, _CD)
                 if sc.numel() != M:
                     raise ValueError(f"mode_scale has {sc.numel()} entries, the mode box has {M}")
                 check(lib().efgp_nufft_type2_scaled(self._h, _ptr(ff), _ptr(sc), B, _i64(n_modes), isign, int(modeord),
@@ -269,7 +278,7 @@ class ToeplitzOp:
 
     def apply(self, u):
         """u (..., size) complex on the device -> same shape."""
-        uu = u.reshape(-1, self.size).to(device=self.dev, dtype=_CD).contiguous()
+        uu = _dc(u.reshape(-1, self.size), self.dev, _CD)
         out = torch.empty_like(uu)
         with _on(self.dev):
             check(lib().efgp_toeplitz_apply(self._h, _ptr(uu), uu.shape[0], _ptr(out), _stream(self.dev)),
@@ -335,7 +344,7 @@ def _start_vector(x0, bb, op, dev):
     """The solver's in/out buffer: a copy of x0, or zeros when x0 is None (one fill instead of a fill and a copy)."""
     if x0 is None:
         return torch.zeros(bb.shape, dtype=_CD, device=dev)
-    return x0.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous().clone()
+    return _dc(x0.reshape(-1, op.size), dev, _CD).clone()
 
 
 def cg_solve(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=True, diag=None, batched=None, hermitian=False):
@@ -356,10 +365,10 @@ def cg_solve(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_stop=Tru
                 # fall through to the synchronous solver, which re-solves dead systems through the multi-launch iteration
                 if "cooperative CG" not in str(err):
                     raise
-    bb = b.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous()
+    bb = _dc(b.reshape(-1, op.size), dev, _CD)
     x = _start_vector(x0, bb, op, dev)
-    wsd = ws.to(device=dev, dtype=_CD).contiguous()
-    dg = diag.to(device=dev, dtype=_RD).contiguous() if diag is not None else None
+    wsd = _dc(ws, dev, _CD)
+    dg = _dc(diag, dev, _RD) if diag is not None else None
     B = bb.shape[0]
     iters = C.c_int(0)
     rows = (C.c_int * B)()
@@ -443,10 +452,10 @@ def cg_solve_async(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_st
     dev = op.dev
     if batched is None:
         batched = b.ndim > 1
-    bb = b.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous()
+    bb = _dc(b.reshape(-1, op.size), dev, _CD)
     x = _start_vector(x0, bb, op, dev)
-    wsd = ws.to(device=dev, dtype=_CD).contiguous()
-    dg = diag.to(device=dev, dtype=_RD).contiguous() if diag is not None else None
+    wsd = _dc(ws, dev, _CD)
+    dg = _dc(diag, dev, _RD) if diag is not None else None
     B = bb.shape[0]
     mi = int(max_iter) if max_iter is not None else 2 * op.size
     rows_dev = torch.empty(B, dtype=torch.int32, device=dev)
@@ -469,10 +478,10 @@ def cg_solve_mean_async(op, ws, sigmasq, diag_scale, fy, tol, max_iter=None, ear
     None for no preconditioner.  Returns (beta, LazyIterations) or None when the grid does not fit the kernel."""
     from .lib import EFGP_EUNSUPPORTED
     dev = op.dev
-    ff = fy.reshape(-1).to(device=dev, dtype=_CD).contiguous()
+    ff = _dc(fy.reshape(-1), dev, _CD)
     if ff.numel() != op.size:
         raise ValueError(f"fy has {ff.numel()} entries, the operator has {op.size}")
-    wsd = ws.reshape(-1).to(device=dev, dtype=_CD).contiguous()
+    wsd = _dc(ws.reshape(-1), dev, _CD)
     x = torch.empty(op.size, dtype=_CD, device=dev)
     ds = None
     if diag_scale is not None:
@@ -496,9 +505,9 @@ def lanczos(op, ws, sigmasq, variant, z, steps):
     tensors -- nothing is read back -- or None when the grid does not fit the persistent kernel."""
     from .lib import EFGP_EUNSUPPORTED
     dev = op.dev
-    zz = z.reshape(-1, op.size).to(device=dev, dtype=_CD).contiguous()
+    zz = _dc(z.reshape(-1, op.size), dev, _CD)
     P = zz.shape[0]
-    wsd = ws.to(device=dev, dtype=_CD).contiguous()
+    wsd = _dc(ws, dev, _CD)
     alpha = torch.zeros((P, int(steps)), dtype=_RD, device=dev)
     beta = torch.zeros((P, int(steps)), dtype=_RD, device=dev)
     norm2 = torch.empty(P, dtype=_RD, device=dev)
@@ -517,7 +526,7 @@ def lag_sums(gamma, eta, mtot, dim):
     dev = gamma.device
     M = int(mtot) ** int(dim)
     gg = gamma.reshape(-1, M).to(_CD).contiguous()
-    ee = eta.reshape(-1, M).to(device=dev, dtype=_RD).contiguous()
+    ee = _dc(eta.reshape(-1, M), dev, _RD)
     out = torch.empty((2 * int(mtot) - 1,) * int(dim), dtype=_CD, device=dev)
     with _on(dev):
         check(lib().efgp_lag_sums(dev.index, int(dim), int(mtot), _ptr(gg), _ptr(ee), gg.shape[0], _ptr(out), _stream(dev)),
@@ -528,7 +537,7 @@ def lag_sums(gamma, eta, mtot, dim):
 def variance_rhs(x_new, h, mtot, ws):
     """rhs[b, k] = ws[k] conj(f_k(x*_b)) for the 'regular' variance solves (efgp_variance_rhs)."""
     dev = ws.device
-    xn = x_new.to(device=dev, dtype=_RD).contiguous()
+    xn = _dc(x_new, dev, _RD)
     B, d = xn.shape
     wsd = ws.to(_CD).contiguous()
     out = torch.empty((B, wsd.numel()), dtype=_CD, device=dev)
@@ -541,7 +550,7 @@ def variance_rhs(x_new, h, mtot, ws):
 def variance_contract(x_new, h, mtot, ws, gamma):
     """s^2[b] = max(0, Re sum_k f_k(x*_b) ws[k] gamma[b, k]) (efgp_variance_contract)."""
     dev = ws.device
-    xn = x_new.to(device=dev, dtype=_RD).contiguous()
+    xn = _dc(x_new, dev, _RD)
     B, d = xn.shape
     wsd = ws.to(_CD).contiguous()
     gg = gamma.reshape(B, -1).to(_CD).contiguous()
@@ -612,6 +621,36 @@ def vdot_real(a, b):
         check(lib().efgp_vdot_real(dev.index, _ptr(aa), int(aa.is_complex()), _ptr(bb), int(bb.is_complex()),
                                    aa.numel(), C.byref(out), _stream(dev)), "efgp_vdot_real")
     return float(out.value)
+
+
+def gradient_step(xd, yd, points, *, h, mtot, kconst, lengthscale, variance, sigmasq, tol_pair, tol_probe, cg_tol, early_stop,
+                  nprobes, probe_seed, v_seed, use_mean_pc, use_trace_pc, variance_idx, trace_idx, beta0, n_obs, yy):
+    """One hyper-gradient step of the adjoint estimator in ONE library call (efgp_gradient_step; csrc/gradient_step.cpp).
+    kconst = (kind, nu, c0) of utils.kernels.kernel_constants.  Returns (out_vec, beta, mean LazyIterations, trace
+    LazyIterations) -- all device-resident, nothing read back -- or None when the grid's solves are not single launches."""
+    from .lib import EFGP_EUNSUPPORTED
+    dev = xd.device
+    npts, d = xd.shape
+    M = int(mtot) ** d
+    K = len(trace_idx)
+    R = (K + 1) * int(nprobes)
+    out = torch.empty(3 * 3 + 1, dtype=_RD, device=dev)
+    beta = torch.empty(M, dtype=_CD, device=dev)
+    its = torch.empty(1 + R, dtype=torch.int32, device=dev)
+    tix = (C.c_int * max(1, K))(*[int(i) for i in trace_idx])
+    b0 = _dc(beta0.reshape(-1), dev, _CD) if beta0 is not None else None
+    with _on(dev):
+        rc = lib().efgp_gradient_step(points._h if points is not None else None, dev.index, int(d), int(npts), _ptr(xd), _ptr(yd),
+                                      float(h), int(mtot), int(kconst[0]), float(kconst[1]), float(lengthscale), float(variance),
+                                      float(kconst[2]), float(sigmasq), float(tol_pair), float(tol_probe), float(cg_tol),
+                                      int(bool(early_stop)), int(nprobes), int(probe_seed) & (2 ** 64 - 1), int(v_seed) & (2 ** 64 - 1),
+                                      int(bool(use_mean_pc)), int(bool(use_trace_pc)), -1 if variance_idx is None else int(variance_idx),
+                                      K, tix, _ptr(b0) if b0 is not None else None, float(n_obs), float(yy), _ptr(beta), _ptr(out),
+                                      _ptr(its), _ptr(its[1:]), _stream(dev))
+    if rc == EFGP_EUNSUPPORTED:
+        return None
+    check(rc, "efgp_gradient_step")
+    return out, beta, LazyIterations(its[:1], False, 2 * M), LazyIterations(its[1:], True, 2 * M)
 
 
 def rademacher_fill(dev, seed, nbatch, npts, index_offset=0):

@@ -345,7 +345,10 @@ def _upload(t: torch.Tensor, dev: torch.device) -> torch.Tensor:
 class _Grid:
     """Frequency grid and weights for the current hyper-parameters (host scalars + device vectors)."""
 
-    def __init__(self, kernel, eps, L, d, dev, want_grad=False):
+    def __init__(self, kernel, eps, L, d, dev, want_grad=False, defer_weights=False):
+        """defer_weights=True: only the grid (h, mtot) is set up; the caller enqueues the N-scale pass over the points -- which
+        needs nothing else -- and calls `make_weights` behind it (the gradient step waits for its result on the host every step,
+        so what the host does before the first big launch is dead time on the device: ~35 us of a 0.4-ms step)."""
         xis_1d, h, mtot = get_xis(kernel_obj=kernel, eps=eps, L=L, use_integral=True, l2scaled=False)
         self.h = float(h)
         self.mtot = int(mtot)
@@ -364,6 +367,16 @@ class _Grid:
         async_ok = F ** d <= 4096 or bool(os.environ.get("EFGP_ASYNC_UPLOAD_ALL"))
         up = _upload if async_ok else (lambda t, dv: t.to(dv))
         self.dprime = None
+        self.ws = None
+        self._weights_args = (kernel, want_grad, dev, up)
+        if not defer_weights:
+            self.make_weights()
+
+    def make_weights(self):
+        if self.ws is not None:
+            return
+        kernel, want_grad, dev, up = self._weights_args
+        d = self.d
         # Built-in kernels: ws (and the hyper-derivatives) in ONE C call on the host (efgp_spectral_weights_host) instead of
         # meshgrid + stack + spectral_density + sqrt + casts, ~10 torch CPU ops whose dispatch (60-150 us per fit) the 0.3-ms
         # step had started to wait for; 3-D grids too (torch's own CPU ops go multi-threaded and slow above 32768 elements)
@@ -403,16 +416,10 @@ class _Grid:
         """(ws, dprime) as device tensors from ONE launch (efgp_spectral_weights) for the built-in kernels, else None."""
         if os.environ.get("EFGP_NO_NATIVE_GRID") or self.M > (1 << 24) or torch.device(dev).type != "cuda":
             return None
-        from utils.kernels import kernel_constants
-        if tuple(getattr(kernel, "hypers", ())) != ("lengthscale", "variance") or not hasattr(kernel, "get_hypers"):
+        bk = _builtin_kernel_constants(kernel)
+        if bk is None:
             return None
-        try:
-            ell, var = kernel.get_hypers()
-            kc = kernel_constants(kernel, ell, var)
-        except Exception:
-            return None
-        if kc is None:
-            return None
+        kc, ell, var = bk
         from efgp_hip.lib import lib
         dev = torch.device(dev)
         ws_d = torch.empty(self.M, dtype=torch.complex128, device=dev)
@@ -425,6 +432,53 @@ class _Grid:
                                              float(kc[1]), float(ell), float(var), float(kc[2]), float(self.h), int(self.mtot),
                                              ws_d.data_ptr(), dp_d.data_ptr() if want_grad else None, _stream(dev))
         return (ws_d, dp_d) if rc == 0 else None
+
+
+def _builtin_kernel_constants(kernel):
+    """((kind, nu, c0), lengthscale, variance) for the kernels efgp_spectral_weights evaluates itself, else None."""
+    from utils.kernels import kernel_constants
+    if tuple(getattr(kernel, "hypers", ())) != ("lengthscale", "variance") or not hasattr(kernel, "get_hypers"):
+        return None
+    try:
+        ell, var = kernel.get_hypers()
+        kc = kernel_constants(kernel, ell, var)
+    except Exception:
+        return None
+    return None if kc is None else (kc, float(ell), float(var))
+
+
+_NO_ONE_CALL_STEP = set()          # (device, d, mtot) whose solves are not single launches: efgp_gradient_step said so once
+
+
+def _gradient_one_call(kernel, grid, xd, yd, points, sig, N, cg_tol, early_stopping, mean_cg_init, use_mean_pc, use_trace_pc, tight,
+                       nufft_eps, T, trace_idx, variance_idx, probe_seed, y_norm_sq, dev):
+    """The whole adjoint-estimator step in one library call (efgp_hip.gradient_step) when it applies: built-in kernel, one GPU,
+    generated probes, a circulant grid whose solves are single launches.  Returns what `_gradient_tail_native` returns, or None
+    (nothing enqueued that matters) and the caller drives the entry points itself."""
+    key = (dev.index, grid.d, grid.mtot)
+    F = 1 << (2 * grid.mtot - 2).bit_length()
+    if key in _NO_ONE_CALL_STEP or F ** grid.d > 4096 or os.environ.get("EFGP_NO_GRADIENT_STEP") or os.environ.get("EFGP_NO_NATIVE_GRID"):
+        return None
+    kc = _builtin_kernel_constants(kernel)
+    if kc is None or variance_idx != 1 or trace_idx != [0]:
+        return None
+    from efgp_hip.ops import gradient_step
+    warm = mean_cg_init is not None and tuple(mean_cg_init.shape) == (grid.M,)
+    # the same draws from torch's generator, in the same order, as the entry-by-entry sequence
+    if probe_seed is None:
+        probe_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    v_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    yy = float(y_norm_sq) if y_norm_sq is not None else float(vdot_real(yd, yd))
+    res = gradient_step(xd, yd, points, h=grid.h, mtot=grid.mtot, kconst=kc[0], lengthscale=kc[1], variance=kc[2], sigmasq=sig,
+                        tol_pair=tight, tol_probe=max(tight, float(nufft_eps)) if nufft_eps else tight, cg_tol=cg_tol,
+                        early_stop=early_stopping, nprobes=T, probe_seed=probe_seed, v_seed=v_seed, use_mean_pc=use_mean_pc,
+                        use_trace_pc=use_trace_pc, variance_idx=variance_idx, trace_idx=trace_idx,
+                        beta0=mean_cg_init.detach() if warm else None, n_obs=N, yy=yy)
+    if res is None:
+        _NO_ONE_CALL_STEP.add(key)
+        return None
+    out, beta, mean_iters, trace_iters = res
+    return out, out[:3], out[3:6], out[6:9], out[9], beta, mean_iters, trace_iters, 2 * T, warm
 
 
 def _domain_length(xd: torch.Tensor, shards: PointShards) -> float:
@@ -518,6 +572,52 @@ def efgpnd_gradient_batched(
         tic[0] = now
         ranges.lap(name)
 
+    def finish():
+        """Diagnostics, the optional log marginal likelihood and the returned gradient (reads the enclosing step's results)."""
+        if stats_out is not None:
+            stats_out.update({
+                # iteration counts of the asynchronous solves stay on the device until somebody reads them (int(...), comparison,
+                # formatting all do): two blocking device-to-host copies per step otherwise
+                "mean_cg_iters": mean_iters,
+                "trace_cg_iters": trace_iters,
+                "trace_num_rhs": int(n_rhs),
+                "feature_count": int(M),
+                "mtot": int(grid.mtot),
+                "trace_samples": int(trace_samples),
+                "mean_cg_warm_start_used": bool(warm),
+                "mean_cg_preconditioned": bool(use_mean_cg_preconditioner),
+                "trace_cg_preconditioned": bool(use_trace_cg_preconditioner),
+                "stage_sec": dict(stages),
+            })
+            stats_out["mean_beta"] = beta_raw.to(out_device)
+            if fused:
+                # grad | term1 | term2 | y.alpha live in one device vector: ONE read-back serves the diagnostics and the caller's
+                # host copy of the gradient (EFGPND.compute_gradients)
+                nh_ = int(term1.numel())
+                host_out = out_vec.cpu()
+                stats_out["term1"] = host_out[nh_:2 * nh_].clone()
+                stats_out["term2"] = host_out[2 * nh_:3 * nh_].clone()
+                stats_out["grad_host"] = host_out[:nh_].clone()
+            else:
+                stats_out["term1"] = term1.detach().cpu()
+                stats_out["term2"] = term2.detach().cpu()
+
+        log_marginal = None
+        if compute_log_marginal:
+            det_term = logdet_slq(ws, sig, top, probes=log_marginal_probes, steps=log_marginal_steps,
+                                  dtype=torch.float64, device=dev, n=N, probe_vectors=log_marginal_probe_vectors)
+            log_marginal = torch.tensor(-0.5 * float(y_alpha) - 0.5 * det_term - 0.5 * N * math.log(TWO_PI), dtype=rdtype)
+            lap("9_log_marginal_likelihood")
+
+        if do_profiling:
+            print("\n===== stage timings for efgpnd_gradient_batched (seconds) =====")
+            for k_, v_ in stages.items():
+                print(f"  {k_:28s} {v_:.6f}")
+
+        ranges.close()
+        g_out = grad.to(device=out_device, dtype=rdtype)
+        return (g_out, log_marginal) if compute_log_marginal else g_out
+
     # 0) book keeping -------------------------------------------------------------------------
     dev = compute_device(x, device=device)
     shards = shards or PointShards(enabled=False)
@@ -536,8 +636,8 @@ def efgpnd_gradient_batched(
     lap("0_book_keeping")
 
     # 1) frequency grid -----------------------------------------------------------------------
-    grid = _Grid(kernel, eps, L, d, dev, want_grad=True)
-    ws, Dp, M = grid.ws, grid.dprime, grid.M
+    grid = _Grid(kernel, eps, L, d, dev, want_grad=True, defer_weights=True)
+    M = grid.M
     lap("1_frequency_grid_setup")
 
     # 2) NUFFT plan ---------------------------------------------------------------------------
@@ -547,12 +647,31 @@ def efgpnd_gradient_batched(
     tight = min(float(nufft_eps), _CONV_TOL) if nufft_eps else _CONV_TOL
     if points is not None and (points.x.data_ptr() != xd.data_ptr() or points.npts != N_local):
         points = None
+    # Everything from here to the assembled gradient in ONE library call when the step is the common one (adjoint estimator, built-in
+    # kernel, one GPU, generated probes, single-launch solves): the ~15 entry points cost more host time driven from Python than
+    # their kernels take on the device (csrc/gradient_step.cpp).  Stage timers then carry the whole call under "4_solve_cg".
+    one_call = None
+    if (adjoint and not pointwise_alpha and not shards.active and probes_Z is None and probes_V is None and not do_profiling
+            and not compute_log_marginal and os.environ.get("EFGP_NO_FUSED_GRADIENT") is None and dev.type == "cuda"):
+        one_call = _gradient_one_call(kernel, grid, xd, yd, points, sig, N, cg_tol, early_stopping, mean_cg_init,
+                                      use_mean_cg_preconditioner, use_trace_cg_preconditioner, tight, nufft_eps, int(trace_samples),
+                                      trace_idx, variance_idx, probe_seed, y_norm_sq, dev)
+    if one_call is not None:
+        fused = True
+        for name in ("2_nufft_setup", "3_toeplitz_setup"):
+            lap(name)
+        (out_vec, grad, term1, term2, y_alpha, beta_raw, mean_iters, trace_iters, n_rhs, warm) = one_call
+        for name in ("4_solve_cg", "5_compute_term2", "6_monte_carlo_trace", "7_batch_cg_solve", "7.5_compute_alpha", "8_gradient_calculation"):
+            lap(name)
+        return finish()
     plan = NufftPlan(xd, grid.h, tight, points=points)
     plan_p = plan if (not nufft_eps or float(nufft_eps) <= tight) else NufftPlan(xd, grid.h, float(nufft_eps), points=points)
     lap("2_nufft_setup")
 
     # 3) Toeplitz operator, Jacobi diagonal (F*y rides in the same pass over the points) --------
     Fy, v = _normal_equations(plan, yd, grid, shards)
+    grid.make_weights()                      # behind the pass over the points: the device is busy while the host sets them up
+    ws, Dp = grid.ws, grid.dprime
     top = ToeplitzOp(v)
     # The M-scale tail in native launches when the estimator is the adjoint one: prepare | solve | T g | probes, two scaled
     # Toeplitz products | batched solve | assemble -- about 35 launches per step instead of 118 (the step was bound by the host
@@ -686,49 +805,7 @@ def efgpnd_gradient_batched(
 
         n_rhs = int(B_all.shape[0])
 
-    if stats_out is not None:
-        stats_out.update({
-            # iteration counts of the asynchronous solves stay on the device until somebody reads them (int(...), comparison,
-            # formatting all do): two blocking device-to-host copies per step otherwise
-            "mean_cg_iters": mean_iters,
-            "trace_cg_iters": trace_iters,
-            "trace_num_rhs": int(n_rhs),
-            "feature_count": int(M),
-            "mtot": int(grid.mtot),
-            "trace_samples": int(trace_samples),
-            "mean_cg_warm_start_used": bool(warm),
-            "mean_cg_preconditioned": bool(use_mean_cg_preconditioner),
-            "trace_cg_preconditioned": bool(use_trace_cg_preconditioner),
-            "stage_sec": dict(stages),
-        })
-        stats_out["mean_beta"] = beta_raw.to(out_device)
-        if fused:
-            # grad | term1 | term2 | y.alpha live in one device vector: ONE read-back serves the diagnostics and the caller's
-            # host copy of the gradient (EFGPND.compute_gradients)
-            nh_ = int(term1.numel())
-            host_out = out_vec.cpu()
-            stats_out["term1"] = host_out[nh_:2 * nh_].clone()
-            stats_out["term2"] = host_out[2 * nh_:3 * nh_].clone()
-            stats_out["grad_host"] = host_out[:nh_].clone()
-        else:
-            stats_out["term1"] = term1.detach().cpu()
-            stats_out["term2"] = term2.detach().cpu()
-
-    log_marginal = None
-    if compute_log_marginal:
-        det_term = logdet_slq(ws, sig, top, probes=log_marginal_probes, steps=log_marginal_steps,
-                              dtype=torch.float64, device=dev, n=N, probe_vectors=log_marginal_probe_vectors)
-        log_marginal = torch.tensor(-0.5 * float(y_alpha) - 0.5 * det_term - 0.5 * N * math.log(TWO_PI), dtype=rdtype)
-        lap("9_log_marginal_likelihood")
-
-    if do_profiling:
-        print("\n===== stage timings for efgpnd_gradient_batched (seconds) =====")
-        for k_, v_ in stages.items():
-            print(f"  {k_:28s} {v_:.6f}")
-
-    ranges.close()
-    grad = grad.to(device=out_device, dtype=rdtype)
-    return (grad, log_marginal) if compute_log_marginal else grad
+    return finish()
 
 
 def _gradient_tail_native(kernel, grid, top, Fy, v, sig, N, N_local, cg_tol, early_stopping, mean_cg_init, use_mean_pc, use_trace_pc,

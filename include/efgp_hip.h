@@ -174,6 +174,9 @@ int efgp_toeplitz_fft_shape(efgp_toeplitz_t* op, int64_t* shape_out);
  * their transforms cover -- 2-D: 48 x 48 (hermitian != 0, blocks <= 23 x 23) or 64 x 64 in one workgroup, 96 / 128 / 192 / 256 / 384 /
  * 512 per axis in the cooperative launch; otherwise the reference's grid.  fft_shape and efgp_toeplitz_apply are unaffected. */
 int efgp_toeplitz_cg_shape(efgp_toeplitz_t* op, int hermitian, int64_t* shape_out);
+/* 1 when every fused solve on this operator is ONE asynchronous launch with no grid barrier (the persistent kernels: circulant
+ * grid within one workgroup), 0 otherwise (cooperative / multi-launch iterations, whose callers read row counts back). */
+int efgp_toeplitz_single_launch_solves(efgp_toeplitz_t* op);
 
 /* ---- preconditioned CG on G = D T D: replaces cg.py ConjugateGradients.solve() for the operators
  * of efgpnd.py:1572-1631 --------------------------------------------------------------------------
@@ -244,6 +247,28 @@ int efgp_gradient_assemble(int device, int64_t nmodes, int nprobes, int n_kernel
                            const int* trace_idx, const void* fy, const void* tg, const void* ws, const void* beta, const void* dprime,
                            const void* fz, const double* v, const void* beta_all, double sigmasq, double n_obs, double yy, double variance,
                            double* out, void* stream);
+
+/* One whole hyper-gradient step of the adjoint estimator in one call: replaces the body of efgpnd_gradient_batched
+ * (efgpnd.py:95-262) for the built-in kernels on one GPU -- efgp_spectral_weights | plans | efgp_nufft_type1_pair |
+ * efgp_toeplitz_create | efgp_gradient_prepare | efgp_cg_solve_hermitian_async | T g | efgp_nufft_type1_rademacher |
+ * efgp_toeplitz_apply_scaled x (n_trace + 1) | efgp_rademacher_fill | efgp_cg_solve_async | efgp_gradient_assemble, enqueued
+ * back to back on `stream` with temporaries from the device's block pool (same kernels, same order, same arithmetic as driving
+ * those entry points one by one).  Nothing is read back.
+ *   points: layout of the model's points (y attached) or NULL (then x (npts, dim) is used directly); y: npts DEVICE doubles;
+ *   h, mtot: the quadrature grid (efgp_quadrature_grid); kind, nu, lengthscale, variance, c0: as efgp_spectral_weights;
+ *   tol_pair / tol_probe: NUFFT tolerances of the (F*y, Toeplitz vector) pass and of the probe transforms;
+ *   probe_seed / v_seed: counters of the data-space / feature-space +-1 probes; trace_idx: HOST array;
+ *   beta0: warm start of the mean solve ((mtot^dim) complex, DEVICE) or NULL for zero;
+ *   beta_out: (mtot^dim) complex mean coefficients; out_vec: 3 (2 + 1) + 1 doubles as efgp_gradient_assemble;
+ *   mean_iters_dev: 1 int, trace_rows_dev: (n_trace + 1) nprobes ints (iteration counts, DEVICE).
+ * EFGP_EUNSUPPORTED when the grid's solves are not single launches (see efgp_toeplitz_single_launch_solves): the caller
+ * then drives the entry points itself. */
+int efgp_gradient_step(efgp_points_t* points, int device, int dim, int64_t npts, const double* x, const double* y, double h, int mtot,
+                       int kind, double nu, double lengthscale, double variance, double c0, double sigmasq, double tol_pair,
+                       double tol_probe, double cg_tol, int early_stop, int nprobes, uint64_t probe_seed, uint64_t v_seed,
+                       int use_mean_pc, int use_trace_pc, int variance_idx, int n_trace, const int* trace_idx, const void* beta0,
+                       double n_obs, double yy, void* beta_out, double* out_vec, int* mean_iters_dev, int* trace_rows_dev,
+                       void* stream);
 
 /* efgp_cg_solve_async for systems whose vectors are Fourier coefficients of REAL functions on the symmetric mode grid:
  * every right-hand side and start vector satisfies u[-k] = conj u[k], ws is real and even, the Toeplitz vector comes

@@ -1,0 +1,118 @@
+"""GPU parity of the one-call hyper-gradient step (efgp_gradient_step, csrc/gradient_step.cpp).
+
+Reference: efgpnd_gradient_batched, efgpnd.py:17-317.  The call enqueues the same library entry points, in the same order and
+on the same seeds, as this package's entry-by-entry sequence (efgpnd.py::_gradient_tail_native, EFGP_NO_GRADIENT_STEP=1): the
+results must agree to what the entry-by-entry sequence reproduces of ITSELF from run to run (the spreader accumulates with
+floating-point atomics: two runs of the same sequence differ by ~4e-9 relative in the gradient, 1e-11 in the mean coefficients;
+tools/r4/step_determinism.py) -- far inside the NUFFT tolerance.  The entry-by-entry sequence is the one the golden tests pin
+against the reference's fixtures.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(d, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(N, d, generator=g, dtype=torch.float64).cuda()
+    y = (torch.sin(3 * x.sum(1)) + 0.3 * torch.randn(N, generator=g, dtype=torch.float64).cuda()).contiguous()
+    return x, y
+
+
+def _kernels():
+    from kernels.squared_exponential import SquaredExponential
+    from kernels.matern import Matern
+    return {"se2": (lambda: SquaredExponential(dimension=2, init_lengthscale=0.1, init_variance=1.0), 2, 20000, 1e-4),
+            "se2_small": (lambda: SquaredExponential(dimension=2, init_lengthscale=0.3, init_variance=0.8), 2, 3000, 1e-3),
+            "matern2": (lambda: Matern(dimension=2, nu=1.5, init_lengthscale=0.3, init_variance=1.3), 2, 20000, 1e-4),
+            "se1": (lambda: SquaredExponential(dimension=1, init_lengthscale=0.05, init_variance=0.7), 1, 5000, 1e-4),
+            "se3": (lambda: SquaredExponential(dimension=3, init_lengthscale=0.6, init_variance=0.7), 3, 5000, 1e-2)}
+
+
+
+@pytest.mark.parametrize("case", ["se2", "se2_small", "matern2", "se1", "se3"])
+@pytest.mark.parametrize("warm", [False, True])
+def test_one_call_equals_entry_by_entry(case, warm, monkeypatch):
+    from efgpnd import efgpnd_gradient_batched
+    import efgp_hip.ops as ops
+    make, d, N, eps = _kernels()[case]
+    x, y = _problem(d, N, 3)
+    sig = torch.tensor(0.09, dtype=torch.float64)
+    calls = []
+    real = ops.gradient_step
+
+    def spy(*a, **k):
+        out = real(*a, **k)
+        calls.append(out is not None)
+        return out
+
+    monkeypatch.setattr(ops, "gradient_step", spy)
+    outs = []
+    for mode in ("one_call", "entries"):
+        if mode == "entries":
+            monkeypatch.setenv("EFGP_NO_GRADIENT_STEP", "1")
+        kern = make()
+        st0 = {}
+        efgpnd_gradient_batched(x, y, sig, kern, eps, 2, stats_out=st0, probe_seed=3)
+        init = st0["mean_beta"] * 0.9 if warm else None
+        torch.manual_seed(17)                                   # the feature-space probes' seed comes from torch's generator
+        st = {}
+        # CG to its floor: at a loose tolerance a stopping index that moves by one (noise-level differences) moves the result by ~cg_tol
+        gr = efgpnd_gradient_batched(x, y, sig, kern, eps, 5, stats_out=st, mean_cg_init=init, nufft_eps=1e-5, cg_tol=1e-11)
+        outs.append((gr.cpu(), st["term1"], st["term2"], st["mean_beta"].cpu(), int(st["mean_cg_iters"]), int(st["trace_cg_iters"]),
+                     int(st["trace_num_rhs"]), bool(st["mean_cg_warm_start_used"]), int(st["feature_count"])))
+    monkeypatch.delenv("EFGP_NO_GRADIENT_STEP")
+    a, b = outs
+    mtot = round(a[8] ** (1.0 / d))
+    covered = (1 << (2 * mtot - 2).bit_length()) ** d <= 4096   # circulant grid within one workgroup: single-launch solves
+    assert covered or case not in ("se2", "se2_small", "se1")
+    assert (calls and all(calls)) if covered else not any(calls), "one-call step taken / not taken on the wrong grid"
+    assert a[6:] == b[6:]
+    assert abs(a[4] - b[4]) <= 1 and abs(a[5] - b[5]) <= 1      # a residual that sits on the tolerance may stop one pass apart
+    assert a[7] == warm
+    for q, bound in enumerate((1e-7, 1e-7, 1e-7, 1e-9)):        # run-to-run spread of the sequence itself: 4e-9 / 1e-11
+        assert float((a[q] - b[q]).abs().max()) <= bound * float(b[q].abs().max()), (case, q)
+
+
+def test_grids_beyond_single_launch_solves_fall_back():
+    """A 2-D grid past 64 x 64 (cooperative solves): efgp_gradient_step is not attempted / refuses, the entry-by-entry sequence
+    runs and the gradient is the same as with the one-call step switched off."""
+    import os
+    from efgpnd import efgpnd_gradient_batched
+    from kernels.squared_exponential import SquaredExponential
+    x, y = _problem(2, 20000, 5)
+    kern = SquaredExponential(dimension=2, init_lengthscale=0.03, init_variance=1.0)
+    sig = torch.tensor(0.09, dtype=torch.float64)
+    st = {}
+    torch.manual_seed(1)
+    g1 = efgpnd_gradient_batched(x, y, sig, kern, 1e-4, 3, stats_out=st, probe_seed=9, cg_tol=1e-11)
+    assert st["mtot"] > 33
+    os.environ["EFGP_NO_GRADIENT_STEP"] = "1"
+    try:
+        torch.manual_seed(1)
+        g2 = efgpnd_gradient_batched(x, y, sig, kern, 1e-4, 3, probe_seed=9, cg_tol=1e-11)
+    finally:
+        del os.environ["EFGP_NO_GRADIENT_STEP"]
+    assert float((g1 - g2).abs().max()) <= 1e-7 * float(g2.abs().max())
+
+
+def test_model_training_steps_identical(monkeypatch):
+    """Five Adam steps of EFGPND.optimize_hyperparameters with and without the one-call step: same hyper-parameter trajectory
+    to 1e-6 (five steps of noise-level differences; the model's cached layout, y attachment and warm starts all go through the call)."""
+    from efgpnd import EFGPND
+    from kernels.squared_exponential import SquaredExponential
+    x, y = _problem(2, 30000, 7)
+    traj = []
+    for mode in ("one_call", "entries"):
+        if mode == "entries":
+            monkeypatch.setenv("EFGP_NO_GRADIENT_STEP", "1")
+        torch.manual_seed(0)
+        kern = SquaredExponential(dimension=2, init_lengthscale=0.2, init_variance=1.0)
+        model = EFGPND(x, y, kern, sigmasq=0.09, eps=1e-3, estimate_params=False)
+        model.optimize_hyperparameters(max_iters=5, lr=0.1, trace_samples=5, cg_tol=1e-11)
+        log = model.training_log
+        traj.append(torch.tensor([log["lengthscale"], log["variance"], log["sigmasq"]], dtype=torch.float64))
+        assert len(set(log["lengthscale"])) > 3                 # the hyper-parameters really moved (mtot changes along the way)
+    monkeypatch.delenv("EFGP_NO_GRADIENT_STEP")
+    assert float((traj[0] - traj[1]).abs().max()) <= 1e-6 * float(traj[1].abs().max())
