@@ -70,6 +70,7 @@ struct Args {
     const double* diag_scale;   // when diag is null and this is not: diagonal = (*diag_scale) * |ws|^2 + sigmasq (device scalar)
     int b_times_ws;          // right-hand side is ws .* b (the fit's D F*y, efgpnd.py:792)
     int zero_x0;             // x0 = 0: x is output only and the initial operator application is skipped (A 0 = 0)
+    const double2* x0;       // start vectors (read once, before x is written; normally x itself: in place)
     const double2* vhat;     // [prod F] (unpadded row-major), already divided by prod F
     double sigmasq;
     int variant;
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_kernel(Args a) {
     for (int s = 0; s < kSlots; ++s) {
         const int t = threadIdx.x + s * kThreads;
         if (t < M) {
-            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x[base + t];
+            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x0[base + t];
             wsv[s] = a.ws[t];
             dg[s] = jacobi_entry(a, wsv[s], t);
             off_in[s] = grid_offset(g, t, 0);
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(kThreads) void cg_persistent_2d64_kernel(Args a) {
     for (int s = 0; s < KS; ++s) {
         const int t = tid + s * kThreads;
         if (t < M) {
-            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x[base + t];
+            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x0[base + t];
             wsv[s] = a.ws[t];
             dg[s] = jacobi_entry(a, wsv[s], t);
             const int i0 = t / n, i1 = t - i0 * n;
@@ -1035,7 +1036,7 @@ __global__ __launch_bounds__(h64::kThreadsH) void cg_herm64_kernel(Args a) {
         idx[s] = ok[s] ? (k0 + h) * n + (k1 + h) : 0;
         double ws_im = 0.0;
         if (ok[s]) {
-            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x[base + idx[s]];
+            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x0[base + idx[s]];
             const double2 w = a.ws[idx[s]], wm = a.ws[M - 1 - idx[s]];
             wsr[s] = w.x;
             ws_im = w.y * w.y + (w.x - wm.x) * (w.x - wm.x) + wm.y * wm.y;
@@ -1389,7 +1390,7 @@ __global__ __launch_bounds__(h48::kThreadsH) void cg_herm48_kernel(Args a) {
         idx[s] = ok[s] ? (k0 + h) * n + (k1 + h) : 0;
         double ws_im = 0.0;
         if (ok[s]) {
-            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x[base + idx[s]];
+            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x0[base + idx[s]];
             const double2 w = a.ws[idx[s]], wm = a.ws[M - 1 - idx[s]];
             wsr[s] = w.x;
             ws_im = w.y * w.y + (w.x - wm.x) * (w.x - wm.x) + wm.y * wm.y;
@@ -1676,7 +1677,7 @@ __global__ __launch_bounds__(64) void cg_line1d_kernel(Args a) {
     for (int s = 0; s < KS; ++s) {
         const int t = lane + 64 * s;
         if (t < M) {
-            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x[base + t];
+            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x0[base + t];
             wsv[s] = a.ws[t];
             dg[s] = jacobi_entry(a, wsv[s], t);
         } else {
@@ -2056,6 +2057,7 @@ struct ApplyArgs {
     const double2* tw;       // exp(-2 pi i q / 64)
     const double2* vhat;     // [64][64], already divided by 4096
     const double2* pre;
+    int pre_stride;          // entries between consecutive elements of pre (a column of an (M, H) array: H)
     const double2* post;
     const void* x;
     int x_is_real;
@@ -2095,7 +2097,7 @@ __global__ __launch_bounds__(kThreads) void toeplitz_apply_2d64_kernel(ApplyArgs
         const int t = tid + s * kThreads;
         if (t < M) {
             double2 u = a.x_is_real ? make_double2(((const double*)a.x)[base + t], 0.0) : ((const double2*)a.x)[base + t];
-            if (a.pre) u = cmulp(a.pre[t], u);
+            if (a.pre) u = cmulp(a.pre[(int64_t)t * a.pre_stride], u);
             const int i0 = t / n, i1 = t - i0 * n;
             bufA[i0 * LD + i1] = u;
         }
@@ -2180,7 +2182,7 @@ bool toeplitz_apply_fused_eligible(const ToepGeom& g) {
 }
 
 int toeplitz_apply_fused_launch(const ToepGeom& g, const double2* tw64, const double2* vhat, const double2* pre, const double2* post,
-                                const void* x, int x_is_real, double2* y, int rows, hipStream_t stream) {
+                                const void* x, int x_is_real, double2* y, int rows, hipStream_t stream, int pre_stride) {
     using namespace pcg;
     bool& attr = per_device_flag("apply_2d64");
     if (!attr) {
@@ -2198,6 +2200,7 @@ int toeplitz_apply_fused_launch(const ToepGeom& g, const double2* tw64, const do
     a.tw = tw64;
     a.vhat = vhat;
     a.pre = pre;
+    a.pre_stride = pre_stride;
     a.post = post;
     a.x = x;
     a.x_is_real = x_is_real;
@@ -2261,7 +2264,7 @@ int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, con
                          const double* diag, double sigmasq, int variant, double tol, int early_stop, int batched,
                          int max_iter, const double2* b, double2* x, int rows, int* d_iters, hipStream_t stream,
                          const double* diag_scale, int b_times_ws, int zero_x0, const LanczosOut* lz, int hermitian,
-                         const Herm48Operands* h48) {
+                         const Herm48Operands* h48, const double2* x0) {
     using namespace pcg;
     Args a;
     Geom& g = a.g;
@@ -2416,6 +2419,7 @@ int persistent_cg_launch(const ToepGeom& tg, const double2* const* twiddles, con
     a.diag_scale = diag_scale;
     a.b_times_ws = b_times_ws;
     a.zero_x0 = zero_x0;
+    a.x0 = x0 ? x0 : x;
     a.vhat = vhat;
     a.sigmasq = sigmasq;
     a.variant = variant;

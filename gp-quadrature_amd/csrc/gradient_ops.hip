@@ -14,6 +14,7 @@
 //   variance entries from the noise entries as the reference does (:170-176, :254-258).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -45,11 +46,12 @@ struct Args {
     double* partial;           // [blocks][kQPad]
 };
 
-__global__ __launch_bounds__(kThreads) void partial_kernel(Args a) {
+template <int THREADS>
+__device__ __forceinline__ void partial_body(const Args& a) {
     double acc[kQ];
 #pragma unroll
     for (int q = 0; q < kQ; ++q) acc[q] = 0.0;
-    for (int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x; m < a.M; m += (int64_t)gridDim.x * kThreads) {
+    for (int64_t m = (int64_t)blockIdx.x * THREADS + threadIdx.x; m < a.M; m += (int64_t)gridDim.x * THREADS) {
         const double2 fy = a.fy[m], tg = a.tg[m], w = a.ws[m], be = a.beta[m];
         const double2 g = make_double2(w.x * be.x - w.y * be.y, w.x * be.y + w.y * be.x);
         const double far = (fy.x - tg.x) / a.sig, fai = (fy.y - tg.y) / a.sig;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(kThreads) void partial_kernel(Args a) {
             acc[kMaxH + 2 + kMaxK] += a.v[o] * a.beta_n[o].x;
         }
     }
-    __shared__ double red[kThreads / 64][kQPad];
+    __shared__ double red[THREADS / 64][kQPad];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int q = 0; q < kQ; ++q) {
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(kThreads) void partial_kernel(Args a) {
     if (threadIdx.x < kQ) {
         double v = 0.0;
 #pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) v += red[w][threadIdx.x];
+        for (int w = 0; w < THREADS / 64; ++w) v += red[w][threadIdx.x];
         a.partial[(int64_t)blockIdx.x * kQPad + threadIdx.x] = v;
     }
 }
@@ -109,7 +111,7 @@ struct FinishArgs {
     double* out;               // grad[H+1] | term1[H+1] | term2[H+1] | y.alpha
 };
 
-__global__ __launch_bounds__(64) void finish_kernel(FinishArgs a) {
+__device__ __forceinline__ void finish_body(const FinishArgs& a) {
     __shared__ double sum[kQPad];
     if (threadIdx.x < kQ) {
         double v = 0.0;
@@ -139,6 +141,18 @@ __global__ __launch_bounds__(64) void finish_kernel(FinishArgs a) {
     }
     for (int i = 0; i < nh; ++i) grad[i] = 0.5 * (term1[i] - term2[i]);
     a.out[3 * nh] = y_alpha;
+}
+
+__global__ __launch_bounds__(kThreads) void partial_kernel(Args a) { partial_body<kThreads>(a); }
+__global__ __launch_bounds__(64) void finish_kernel(FinishArgs a) { finish_body(a); }
+// Small mode grids (the partial sums fit one workgroup's loop): both steps in ONE launch -- a dependent launch costs ~5 us, the
+// sums of M = 529 entries a fraction of that.  Same arithmetic; the order of the partial sums is that of a one-block launch.
+constexpr int kSmallThreads = 1024;
+__global__ __launch_bounds__(kSmallThreads) void assemble_small_kernel(Args a, FinishArgs f) {
+    partial_body<kSmallThreads>(a);
+    __threadfence_block();
+    __syncthreads();
+    finish_body(f);
 }
 
 __global__ __launch_bounds__(256) void prepare_kernel(int64_t M, const double2* __restrict__ ws, const double2* __restrict__ fy,
@@ -218,10 +232,13 @@ int efgp_gradient_assemble(int device, int64_t nmodes, int nprobes, int n_kernel
     a.beta_n = (const double2*)beta_all + (int64_t)n_trace * nprobes * nmodes;
     a.sig = sigmasq;
     a.partial = partial;
-    hipLaunchKernelGGL(partial_kernel, dim3(blocks), dim3(kThreads), 0, stream, a);
-    EFGP_HIP_CHECK(hipGetLastError());
+    const bool small = nmodes <= 4096 && std::getenv("EFGP_ASSEMBLE_TWO_LAUNCHES") == nullptr;
+    if (!small) {
+        hipLaunchKernelGGL(partial_kernel, dim3(blocks), dim3(kThreads), 0, stream, a);
+        EFGP_HIP_CHECK(hipGetLastError());
+    }
     FinishArgs f;
-    f.blocks = blocks;
+    f.blocks = small ? 1 : blocks;
     f.T = nprobes;
     f.H = n_kernel_hypers;
     f.K = n_trace;
@@ -233,7 +250,8 @@ int efgp_gradient_assemble(int device, int64_t nmodes, int nprobes, int n_kernel
     f.yy = yy;
     f.variance = variance;
     f.out = out;
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(64), 0, stream, f);
+    if (small) hipLaunchKernelGGL(assemble_small_kernel, dim3(1), dim3(kSmallThreads), 0, stream, a, f);
+    else hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(64), 0, stream, f);
     EFGP_HIP_CHECK(hipGetLastError());
     return EFGP_OK;
 }

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "toeplitz_cg.hpp"
 
 using namespace efgp;
 
@@ -69,14 +70,12 @@ extern "C" int efgp_gradient_step(efgp_points_t* points, int device, int dim, in
     }
     // ---- one pooled block for every temporary ----------------------------------------------------------------------------
     Carver cv;
-    auto layout = [&](Carver& c, double2*& ws, double2*& dp, double2*& fy, double2*& v, double*& diag, double2*& rhs, double2*& tg,
+    auto layout = [&](Carver& c, double2*& ws, double2*& dp, double2*& fy, double2*& v, double2*& tg,
                       double2*& fz, double2*& dcol, double*& V, double2*& ball, double2*& betaall) {
         ws = c.take<double2>(M);
         dp = c.take<double2>(2 * M);
         fy = c.take<double2>(M);
         v = c.take<double2>(Lv);
-        diag = c.take<double>(M);
-        rhs = c.take<double2>(M);
         tg = c.take<double2>(M);
         fz = c.take<double2>((size_t)T * M);
         dcol = c.take<double2>(M);
@@ -84,14 +83,14 @@ extern "C" int efgp_gradient_step(efgp_points_t* points, int device, int dim, in
         ball = c.take<double2>((size_t)R * M);
         betaall = c.take<double2>((size_t)R * M);
     };
-    double2 *ws, *dp, *fy, *v, *rhs, *tg, *fz, *dcol, *ball, *betaall;
-    double *diag, *V;
-    layout(cv, ws, dp, fy, v, diag, rhs, tg, fz, dcol, V, ball, betaall);
+    double2 *ws, *dp, *fy, *v, *tg, *fz, *dcol, *ball, *betaall;
+    double* V;
+    layout(cv, ws, dp, fy, v, tg, fz, dcol, V, ball, betaall);
     const size_t bytes = cv.off;
     char* block = (char*)pool_alloc(ctx, bytes);
     if (!block) return EFGP_ENOMEM;
     cv = Carver{block, 0};
-    layout(cv, ws, dp, fy, v, diag, rhs, tg, fz, dcol, V, ball, betaall);
+    layout(cv, ws, dp, fy, v, tg, fz, dcol, V, ball, betaall);
 
     // EFGP_STEP_TRACE=1: host time of every entry of the sequence (where the call's enqueue time goes), printed per call
     static const bool trace = std::getenv("EFGP_STEP_TRACE") != nullptr;
@@ -141,37 +140,37 @@ extern "C" int efgp_gradient_step(efgp_points_t* points, int device, int dim, in
         set_error("efgp_gradient_step: the grid's solves are not single launches");
         return done(EFGP_EUNSUPPORTED);
     }
-    // 4) Jacobi diagonal, rhs = D F*y, mean solve, T g (:128-153)
+    // 4) mean solve and T g (:128-153).  The Jacobi diagonal v[0] |ws|^2 + sigma^2 and the right-hand side D F*y are formed inside
+    // the solve kernels from the centre of the Toeplitz vector (a device scalar) and F*y: no launch of their own.
     int64_t centre = 0;
     for (int a = 0; a < dim; ++a) centre = centre * (4 * m + 1) + 2 * m;
-    const bool want_diag = use_mean_pc || use_trace_pc;
-    STEP(efgp_gradient_prepare(device, M, ws, fy, v + centre, sigmasq, want_diag ? diag : nullptr, rhs, stream));
-    if (beta0) {
-        if (hipMemcpyAsync(beta_out, beta0, (size_t)M * sizeof(double2), hipMemcpyDeviceToDevice, stream) != hipSuccess) return done(EFGP_EHIP);
-    } else if (hipMemsetAsync(beta_out, 0, (size_t)M * sizeof(double2), stream) != hipSuccess) {
-        return done(EFGP_EHIP);
-    }
+    const double* dscale = reinterpret_cast<const double*>(v + centre);          // Re v[0]
     const int max_iter = (int)std::min<int64_t>(2 * M, 2000000000);
-    STEP(efgp_cg_solve_hermitian_async(top, ws, sigmasq, 0, use_mean_pc ? diag : nullptr, rhs, beta_out, 1, cg_tol, max_iter, early_stop, 0,
-                                       mean_iters_dev, stream));
+    STEP(efgp_internal_cg_single_launch(top, ws, sigmasq, 0, nullptr, use_mean_pc ? dscale : nullptr, fy, /*b_times_ws*/ 1, beta_out,
+                                        /*zero_x0*/ beta0 ? 0 : 1, 1, cg_tol, max_iter, early_stop, 0, mean_iters_dev, stream, /*hermitian*/ 1,
+                                        /*x0: the warm start is read where it lies*/ beta0));
     STEP(efgp_toeplitz_apply_scaled(top, beta_out, 0, 1, ws, nullptr, tg, stream));
     // 6) probes and the right-hand sides of the trace systems (:179-203)
     if (K > 0) {
         STEP(efgp_nufft_type1_rademacher(plan_p, probe_seed, 0, T, shape_y, 0, fz, stream));
         for (int s = 0; s < K; ++s) {
-            // D'_i as a contiguous diagonal: column trace_idx[s] of the (M, H) array
-            if (hipMemcpy2DAsync(dcol, sizeof(double2), dp + trace_idx[s], (size_t)H * sizeof(double2), sizeof(double2), (size_t)M,
-                                 hipMemcpyDeviceToDevice, stream) != hipSuccess)
-                return done(EFGP_EHIP);
-            STEP(efgp_toeplitz_apply_scaled(top, fz, 0, T, dcol, ws, ball + (size_t)s * T * M, stream));
+            // D'_i rides in the zero-padding as a diagonal read at stride H: column trace_idx[s] of the (M, H) array
+            rc = efgp_internal_apply_scaled(top, fz, 0, T, dp + trace_idx[s], H, ws, ball + (size_t)s * T * M, stream);
+            if (rc == EFGP_EUNSUPPORTED) {          // grids without the single-launch product: a contiguous copy of the column
+                if (hipMemcpy2DAsync(dcol, sizeof(double2), dp + trace_idx[s], (size_t)H * sizeof(double2), sizeof(double2), (size_t)M,
+                                     hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                    return done(EFGP_EHIP);
+                rc = efgp_toeplitz_apply_scaled(top, fz, 0, T, dcol, ws, ball + (size_t)s * T * M, stream);
+            }
+            if (rc != EFGP_OK) return done(rc);
+            mark("apply_scaled(F*Z, pre = D'_i, post = ws)");
         }
     }
     STEP(efgp_rademacher_fill(device, v_seed, 0, T, M, V, stream));
     STEP(efgp_toeplitz_apply_scaled(top, V, 1, T, ws, ws, ball + (size_t)K * T * M, stream));
-    // 7) batched CG from zero (:205-236)
-    if (hipMemsetAsync(betaall, 0, (size_t)R * M * sizeof(double2), stream) != hipSuccess) return done(EFGP_EHIP);
-    STEP(efgp_cg_solve_async(top, ws, sigmasq, 0, use_trace_pc ? diag : nullptr, ball, betaall, R, cg_tol, max_iter, early_stop, 1,
-                             trace_rows_dev, stream));
+    // 7) batched CG from zero (:205-236): the kernel starts from x = 0 itself
+    STEP(efgp_internal_cg_single_launch(top, ws, sigmasq, 0, nullptr, use_trace_pc ? dscale : nullptr, ball, 0, betaall, /*zero_x0*/ 1, R,
+                                        cg_tol, max_iter, early_stop, 1, trace_rows_dev, stream, /*hermitian*/ 0, nullptr));
     // 7.5 / 8) inner products and the final algebra (:155-176, :238-262)
     STEP(efgp_gradient_assemble(device, M, T, H, variance_idx, K, trace_idx, fy, tg, ws, beta_out, dp, K > 0 ? fz : nullptr, V, betaall,
                                 sigmasq, n_obs, yy, variance, out_vec, stream));

@@ -760,6 +760,13 @@ __global__ __launch_bounds__(kSpreadThreads) void tile_class_order_kernel(TileGe
     }
 }
 
+// Extent of SLOT_SLABS known to be zero after a pass over its first acc_bytes (which the converting kernel cleared again): a
+// pass SMALLER than what was known to be zero leaves the tail zero too -- the pair pass (2 channels on the 96 / 128 grid) and the
+// probe pass (T channels on the 48 / 64 grid) of a gradient step alternate, and neither needs a memset launch.
+static inline size_t zero_extent_after(size_t acc_bytes, size_t known_zero_before, bool same_buffer) {
+    return std::max(acc_bytes, same_buffer ? known_zero_before : (size_t)0);
+}
+
 struct TileSpreadArgs {
     TileGeom t;
     const double* xs;         // tile-sorted coordinates
@@ -2927,8 +2934,19 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
             hipLaunchKernelGGL(maxabs_kernel, dim3(blocks), dim3(1024), 0, stream, c, nvals, d_cmax,
                                (unsigned int*)(misc + 48), job);
         } else {
-            hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream, job.floor_bound, job.ones_channel, job.per,
-                               job.scale, job.sum_bits);
+            // generated +-1 probes / implicit ones: the block depends on (floor, N, bit budget) only -- constant for the layout
+            efgp_points_s* pts = plan->points;
+            if (floor_bound == 1.0 && job.ones_channel == 0) {
+                if (!pts->d_fixed_scale) EFGP_HIP_CHECK(hipMalloc((void**)&pts->d_fixed_scale, 64));
+                d_scale = pts->d_fixed_scale;
+                job.scale = d_scale;
+                if (scale_out) *scale_out = d_scale;
+            }
+            if (job.scale != pts->d_fixed_scale || !pts->fixed_scale_ready) {
+                hipLaunchKernelGGL(fixed_scale_kernel, dim3(1), dim3(64), 0, stream, job.floor_bound, job.ones_channel, job.per,
+                                   job.scale, job.sum_bits);
+                if (job.scale == pts->d_fixed_scale) pts->fixed_scale_ready = true;
+            }
         }
         EFGP_HIP_CHECK(hipGetLastError());
         int rc = spread_mfma_launch(ctx, lvl, band_cells, ys, src, g, w->p.w, w->d_coef, w->p.degree, channels, nbatch, gacc, d_scale, stream);
@@ -2937,12 +2955,12 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
             rc = g2m_launch(ctx, g, req, (long long*)gacc, nullptr, d_scale, channels, nbatch, isign, (unsigned int*)(misc + 40),
                             (long long)(acc_bytes / sizeof(long long)), stream);
             if (rc != EFGP_OK) return rc;
-            ctx->slabs_zero_bytes = acc_bytes;
+            ctx->slabs_zero_bytes = zero_extent_after(acc_bytes, known_zero, slabs_before == (const void*)gacc);
             *fine_out = nullptr;
             return EFGP_OK;
         }
         const FftAccSource accsrc{(long long*)gacc, channels, g.cells, (const double*)d_scale, 1};     // converted (and cleared) by whoever reads it
-        ctx->slabs_zero_bytes = acc_bytes;
+        ctx->slabs_zero_bytes = zero_extent_after(acc_bytes, known_zero, slabs_before == (const void*)gacc);
         return transform_fine(plan, g, fine, nbatch, isign, stream, req, scale_out ? *scale_out : nullptr, fine_out, &accsrc);
     }
     // 2-D with many points per fine-grid cell: register accumulation over base-cell-sorted points
@@ -3059,7 +3077,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
             return EFGP_EHIP;
         }
         const FftAccSource accsrc{gacc, channels, g.cells, (const double*)d_scale, 1};     // converted (and cleared) by whoever reads it
-        ctx->slabs_zero_bytes = acc_bytes;
+        ctx->slabs_zero_bytes = zero_extent_after(acc_bytes, known_zero, slabs_before == (const void*)gacc);
         return transform_fine(plan, g, fine, nbatch, isign, stream, req, scale_out ? *scale_out : nullptr, fine_out, &accsrc);
     }
     int nwg = 1;

@@ -375,6 +375,7 @@ int efgp_points_destroy(efgp_points_t* pts) {
     (void)hipDeviceSynchronize();
     for (SortedLevel* l : pts->levels) free_level(l);
     if (pts->d_values_max) (void)hipFree(pts->d_values_max);
+    if (pts->d_fixed_scale) (void)hipFree(pts->d_fixed_scale);
     delete pts;
     return EFGP_OK;
 }

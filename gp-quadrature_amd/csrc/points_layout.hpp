@@ -48,6 +48,8 @@ struct efgp_points_s {
     unsigned long long* d_values_max = nullptr;   // device word: max|values| as an ordered bit pattern (set by attach)
     double* d_pair_scale = nullptr;               // fixed-point scale block of the (values, ones) pass (nufft.hip fills it once)
     bool pair_scale_ready = false;
+    double* d_fixed_scale = nullptr;              // scale block of passes whose strengths are +-1 / implicit ones (depends on npts only;
+    bool fixed_scale_ready = false;               //  nufft.hip fills it once per layout: one launch less per probe transform)
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};   // bounding box
     efgp::DeviceCtx* ctx = nullptr;
     std::vector<efgp::SortedLevel*> levels;

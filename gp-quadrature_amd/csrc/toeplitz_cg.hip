@@ -2764,6 +2764,39 @@ int efgp_toeplitz_apply_scaled(efgp_toeplitz_t* op, const void* x, int x_is_real
     return EFGP_OK;
 }
 
+int efgp_internal_apply_scaled(efgp_toeplitz_s* op, const void* x, int x_is_real, int nbatch, const void* pre, int pre_stride,
+                               const void* post, void* y, hipStream_t stream) {
+    if (pre == nullptr || pre_stride == 1) return efgp_toeplitz_apply_scaled(op, x, x_is_real, nbatch, pre, post, y, stream);
+    EFGP_REQUIRE(op && x && y && nbatch >= 1 && x != y && pre_stride >= 1, "efgp_internal_apply_scaled: bad argument");
+    DeviceGuard guard(op->device);
+    const ToepGeom* gq;
+    const double2* const* twq;
+    const double2* vq;
+    cg_operands(op, &gq, &twq, &vq);
+    if (!toeplitz_apply_fused_eligible(*gq)) return EFGP_EUNSUPPORTED;
+    return toeplitz_apply_fused_launch(*gq, twq[0], vq, (const double2*)pre, (const double2*)post, x, x_is_real, (double2*)y, nbatch, stream,
+                                       pre_stride);
+}
+
+int efgp_internal_cg_single_launch(efgp_toeplitz_s* op, const void* ws, double sigmasq, int variant, const double* diag,
+                                   const double* diag_scale, const void* b, int b_times_ws, void* x, int zero_x0, int nbatch, double tol,
+                                   int max_iter, int early_stop, int batched_semantics, int* row_iters_dev, hipStream_t stream,
+                                   int hermitian, const void* x0) {
+    EFGP_REQUIRE(op && ws && b && x && row_iters_dev && nbatch >= 1, "efgp_internal_cg_single_launch: bad argument");
+    EFGP_REQUIRE(batched_semantics || nbatch == 1, "efgp_internal_cg_single_launch: single-system semantics need nbatch == 1");
+    if (!op->persistent_ok || std::getenv("EFGP_NO_PERSISTENT_CG") != nullptr) return EFGP_EUNSUPPORTED;
+    DeviceGuard guard(op->device);
+    if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * op->g.M, 2000000000);
+    KernelTimer timer("cg_persistent", stream);
+    const ToepGeom* gq;
+    const double2* const* twq;
+    const double2* vq;
+    cg_operands(op, &gq, &twq, &vq);
+    return persistent_cg_launch(*gq, twq, vq, (const double2*)ws, diag, sigmasq, variant, tol, early_stop, batched_semantics, max_iter,
+                                (const double2*)b, (double2*)x, nbatch, row_iters_dev, stream, diag ? nullptr : diag_scale, b_times_ws, zero_x0,
+                                nullptr, hermitian, op->h48.vhat ? &op->h48 : nullptr, (const double2*)x0);
+}
+
 // Enqueues the cooperative solve of `nbatch` systems on a 2-D 128^2..512^2 grid (cg_coop2d_kernel).  Few systems: G = 32-64
 // workgroups per system (latency); many systems (variance / trace probes): as few workgroups per system as the registers
 // allow, G = 1 when the mode block has <= 2048 entries -- no grid barrier, one system per CU (throughput).  Iteration counts

@@ -36,7 +36,8 @@ int persistent_cg_launch(const ToepGeom& g, const double2* const* twiddles, cons
                          int max_iter, const double2* b, double2* x, int rows, int* d_iters, hipStream_t stream,
                          const double* diag_scale = nullptr, int b_times_ws = 0, int zero_x0 = 0, const LanczosOut* lz = nullptr,
                          int hermitian = 0 /* b, x0 and the Toeplitz vector are coefficient arrays of real functions */,
-                         const Herm48Operands* h48 = nullptr /* 2-D blocks <= 23 x 23: Hermitian solves run on the 48 x 48 grid */);
+                         const Herm48Operands* h48 = nullptr /* 2-D blocks <= 23 x 23: Hermitian solves run on the 48 x 48 grid */,
+                         const double2* x0 = nullptr /* start vectors when they are not in x (read before x is written) */);
 
 // spectrum of the Toeplitz vector on the 64 x 64 circulant grid in one launch (cg_persistent.hip)
 bool toeplitz_vhat_fused_eligible(const ToepGeom& g);
@@ -50,6 +51,24 @@ int fft2d64_batch_launch(const void* src, int src_is_real, int64_t src_stride, i
 // y[row] = post .* T(pre .* x[row]) on the 64 x 64 circulant grid in one launch (cg_persistent.hip)
 bool toeplitz_apply_fused_eligible(const ToepGeom& g);
 int toeplitz_apply_fused_launch(const ToepGeom& g, const double2* tw64, const double2* vhat, const double2* pre, const double2* post,
-                                const void* x, int x_is_real, double2* y, int rows, hipStream_t stream);
+                                const void* x, int x_is_real, double2* y, int rows, hipStream_t stream, int pre_stride = 1);
 
 }  // namespace efgp
+
+// Internal entry points for callers inside the library (gradient_step.cpp): the exported solves / products with the optional
+// operands of the persistent kernels that the C ABI does not expose.
+struct efgp_toeplitz_s;
+extern "C" {
+// (C linkage like their exported siblings, hidden: not part of the ABI)
+// efgp_toeplitz_apply_scaled with `pre` read at a stride (a column of a row-major (M, H) array: stride H).  Returns
+// EFGP_EUNSUPPORTED -- nothing enqueued -- when pre_stride != 1 and the grid has no single-launch product.
+__attribute__((visibility("hidden"))) int efgp_internal_apply_scaled(efgp_toeplitz_s* op, const void* x, int x_is_real, int nbatch, const void* pre, int pre_stride,
+                               const void* post, void* y, hipStream_t stream);
+// efgp_cg_solve_async / efgp_cg_solve_hermitian_async on a grid of the persistent kernels with: diag_scale (device scalar; Jacobi
+// diagonal (*diag_scale) |ws|^2 + sigmasq formed in the kernel, used when diag is null), b_times_ws (right-hand side ws .* b),
+// zero_x0 (x is output only), x0 (start vectors kept apart from x: no copy; NULL = in place).  EFGP_EUNSUPPORTED on every other grid.
+__attribute__((visibility("hidden"))) int efgp_internal_cg_single_launch(efgp_toeplitz_s* op, const void* ws, double sigmasq, int variant, const double* diag,
+                                   const double* diag_scale, const void* b, int b_times_ws, void* x, int zero_x0, int nbatch, double tol,
+                                   int max_iter, int early_stop, int batched_semantics, int* row_iters_dev, hipStream_t stream,
+                                   int hermitian, const void* x0);
+}  // extern "C"

@@ -242,7 +242,7 @@ int efgp_gradient_prepare(int device, int64_t nmodes, const void* ws, const void
  * probes (may be NULL when n_trace = 0); v: (T, M) real feature-space probes; beta_all: ((n_trace + 1) T, M) complex
  * solves; trace_idx: HOST array of n_trace hyper indices; variance_idx: index of the variance hyper or -1.
  * n_kernel_hypers, n_trace <= 4.  Two launches: per-workgroup partial sums, then one workgroup adds them in a fixed
- * order (reproducible) and does the scalar algebra. */
+ * order (reproducible) and does the scalar algebra; ONE launch (a single workgroup does both) when nmodes <= 4096. */
 int efgp_gradient_assemble(int device, int64_t nmodes, int nprobes, int n_kernel_hypers, int variance_idx, int n_trace,
                            const int* trace_idx, const void* fy, const void* tg, const void* ws, const void* beta, const void* dprime,
                            const void* fz, const double* v, const void* beta_all, double sigmasq, double n_obs, double yy, double variance,

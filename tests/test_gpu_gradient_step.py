@@ -71,7 +71,9 @@ def test_one_call_equals_entry_by_entry(case, warm, monkeypatch):
     assert a[6:] == b[6:]
     assert abs(a[4] - b[4]) <= 1 and abs(a[5] - b[5]) <= 1      # a residual that sits on the tolerance may stop one pass apart
     assert a[7] == warm
-    for q, bound in enumerate((1e-7, 1e-7, 1e-7, 1e-9)):        # run-to-run spread of the sequence itself: 4e-9 / 1e-11
+    # run-to-run spread of the sequence itself: 4e-9 (gradient) / 1e-11 (beta) in 2-D; 5e-10 in beta on the 3-D case, whose mean
+    # solve runs into its iteration cap (tools/r4/step_determinism.py, step_determinism3d.py)
+    for q, bound in enumerate((1e-7, 1e-7, 1e-7, 2e-8)):
         assert float((a[q] - b[q]).abs().max()) <= bound * float(b[q].abs().max()), (case, q)
 
 
