@@ -15,6 +15,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <utility>
 #include <vector>
 
 #include <cstdlib>
@@ -1077,6 +1081,9 @@ struct CoopArgs {
     ToepGeom g;
     const double2* ws;
     const double* diag;
+    const double* diag_scale;  // when diag is null and this is not: Jacobi diagonal (*diag_scale) |ws|^2 + sigmasq (device scalar)
+    int b_times_ws;           // right-hand side is ws .* b (the fit's D F*y, efgpnd.py:792)
+    int zero_x0;              // x0 = 0: x is output only, the initial operator application is skipped (A 0 = 0)
     double sigmasq;
     int variant;
     double tol;
@@ -1084,7 +1091,7 @@ struct CoopArgs {
     int batched;
     int max_iter;
     const double2* b;         // [systems][M]
-    double2* x;               // in: x0, out: solution
+    double2* x;               // in: x0 (unless zero_x0), out: solution
     const double2* vhat;
     const double2* tw0;
     const double2* tw1;
@@ -1108,6 +1115,14 @@ struct CoopArgs {
     int dbg;                  // EFGP_COOP_DBG=2: cycle counters per phase (workgroup 0 of system 0)
     double* stamps;
 };
+
+// Jacobi diagonal entry t of the cooperative kernels: explicit array, or scale |ws_t|^2 + sigmasq with the two roundings of the
+// reference's torch expression (efgpnd.py:795-799; pcg::jacobi_entry), or 1
+__device__ __forceinline__ double coop_jacobi(const CoopArgs& a, double2 w, int64_t t) {
+    if (a.diag) return a.diag[t];
+    if (a.diag_scale) return __dadd_rn(__dmul_rn(*a.diag_scale, __dadd_rn(__dmul_rn(w.x, w.x), __dmul_rn(w.y, w.y))), a.sigmasq);
+    return 1.0;
+}
 
 // SOLO (G == 1): the intermediate grids are private to the workgroup -- ordinary cached accesses, no grid barrier
 template <bool SOLO>
@@ -1208,9 +1223,9 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
         lcol[s] = ok[s] ? e - lrow[s] * n1 : 0;
         if (ok[s]) {
             const int t = r0 * n1 + e;
-            xv[s] = a.x[base + e];
+            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x[base + e];
             wsv[s] = a.ws[t];
-            dg[s] = a.diag ? a.diag[t] : 1.0;
+            dg[s] = coop_jacobi(a, wsv[s], t);
         } else {
             xv[s] = wsv[s] = make_double2(0.0, 0.0);
             dg[s] = 1.0;
@@ -1376,16 +1391,23 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
         }
     };
 
+    const bool precond = a.diag != nullptr || a.diag_scale != nullptr;
     double2 Ap[KS];
     double uAu = 0.0;
-    if (!apply(xv, Ap, uAu)) return dead();
+    if (a.zero_x0) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) Ap[s] = make_double2(0.0, 0.0);
+    } else if (!apply(xv, Ap, uAu)) {
+        return dead();
+    }
     double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         if (ok[s]) {
-            const double2 bv = a.b[base + tid + s * kLineThreads];
+            double2 bv = a.b[base + tid + s * kLineThreads];
+            if (a.b_times_ws) bv = cmul(wsv[s], bv);
             rv[s] = make_double2(bv.x - Ap[s].x, bv.y - Ap[s].y);
-            pv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            pv[s] = precond ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
             acc[0] += rv[s].x * pv[s].x + rv[s].y * pv[s].y;
             acc[1] += bv.x * bv.x + bv.y * bv.y;
         }
@@ -1407,7 +1429,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
             xv[s].y += alpha * pv[s].y;
             rv[s].x -= alpha * Ap[s].x;
             rv[s].y -= alpha * Ap[s].y;
-            zv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            zv[s] = precond ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
             acc[0] += rv[s].x * rv[s].x + rv[s].y * rv[s].y;
             acc[1] += rv[s].x * zv[s].x + rv[s].y * zv[s].y;
         }
@@ -1518,11 +1540,11 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
         tix[s] = (h0 + k0) * n1 + lcol;
         wgt[s] = k0 == 0 ? 1.0 : 2.0;
         if (ok[s]) {
-            xv[s] = a.x[base + tix[s]];
+            xv[s] = a.zero_x0 ? make_double2(0.0, 0.0) : a.x[base + tix[s]];
             const double2 w = a.ws[tix[s]], wm = a.ws[M - 1 - tix[s]];
             wsr[s] = w.x;
             ws_bad += w.y * w.y + (w.x - wm.x) * (w.x - wm.x) + wm.y * wm.y;
-            dg[s] = a.diag ? a.diag[tix[s]] : 1.0;
+            dg[s] = coop_jacobi(a, w, tix[s]);
         } else {
             xv[s] = make_double2(0.0, 0.0);
             wsr[s] = 0.0;
@@ -1705,7 +1727,11 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
         bv[s] = make_double2(0.0, 0.0);
         if (ok[s]) {
             bv[s] = a.b[base + tix[s]];
-            const double2 bm = a.b[base + M - 1 - tix[s]];
+            double2 bm = a.b[base + M - 1 - tix[s]];
+            if (a.b_times_ws) {                     // ws is real and even here (anything else trips ws_bad above)
+                bv[s] = make_double2(wsr[s] * bv[s].x, wsr[s] * bv[s].y);
+                bm = make_double2(wsr[s] * bm.x, wsr[s] * bm.y);
+            }
             acc[0] += (bv[s].x - bm.x) * (bv[s].x - bm.x) + (bv[s].y + bm.y) * (bv[s].y + bm.y);
             acc[1] += wgt[s] * (bv[s].x * bv[s].x + bv[s].y * bv[s].y);
         }
@@ -1719,8 +1745,12 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
         return;
     }
     // r_0 = b - A x_0: one plain operator application (R | barrier | C | barrier | Ri)
+    const bool precond = a.diag != nullptr || a.diag_scale != nullptr;
     double2 Ap[KS];
-    {
+    if (a.zero_x0) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) Ap[s] = make_double2(0.0, 0.0);
+    } else {
         double cs = 0.0;
         phase_rows(xv);
         if (!sync_grid()) return dead();
@@ -1732,7 +1762,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         rv[s] = ok[s] ? make_double2(bv[s].x - Ap[s].x, bv[s].y - Ap[s].y) : make_double2(0.0, 0.0);
-        zv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+        zv[s] = precond ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
     }
     const double bn = sqrt(bb);
     const double den = bn > 0.0 ? bn : 1.0;
@@ -1787,7 +1817,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
             xv[s].y += alpha * pv[s].y;
             rv[s].x -= alpha * Ap[s].x;
             rv[s].y -= alpha * Ap[s].y;
-            zv[s] = a.diag ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
+            zv[s] = precond ? make_double2(rv[s].x / dg[s], rv[s].y / dg[s]) : rv[s];
         }
         ++it;
     }
@@ -2811,7 +2841,8 @@ struct CoopInfo {
 };
 static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int variant, const double* precond_diag, const void* b,
                         void* x, int nbatch, double tol, int max_iter, int early_stop, int batched_semantics, int* d_iters,
-                        hipStream_t stream, CoopInfo* info, int nan_on_dead, int hermitian = 0) {
+                        hipStream_t stream, CoopInfo* info, int nan_on_dead, int hermitian = 0, const double* diag_scale = nullptr,
+                        int b_times_ws = 0, int zero_x0 = 0) {
     DeviceCtx* ctx = op->ctx;
     const bool small = op->coop_small && std::getenv("EFGP_NO_COOP_SMALL") == nullptr;
     const ToepGeom g = small ? op->g_co : op->g;
@@ -2875,6 +2906,9 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     ca.g = g;
     ca.ws = (const double2*)ws;
     ca.diag = precond_diag;
+    ca.diag_scale = precond_diag ? nullptr : diag_scale;
+    ca.b_times_ws = b_times_ws;
+    ca.zero_x0 = zero_x0;
     ca.sigmasq = sigmasq;
     ca.variant = variant;
     ca.tol = tol;
@@ -2907,14 +2941,34 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     ca.stamps = (double*)(scb + off_status + 64);
     if (ca.dbg == 2) EFGP_HIP_CHECK(hipMemsetAsync(ca.stamps, 0, 128, stream));
     auto launch = [&](auto kern, int nsys) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        // the hand-rolled grid barrier needs every workgroup of a launch resident: at most one workgroup per CU is asked for
-        // (G * nsys <= num_cu above), so it is enough that ONE fits a CU with these registers and this much LDS
-        int fit = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, kern, kLineThreads, lds);
-        if (e != hipSuccess) return e;
-        if (fit < 1) return hipErrorLaunchOutOfResources;
+        // attribute and occupancy query once per (device, kernel, LDS size): both are host round trips into the runtime.  The
+        // attribute is a per-kernel maximum: it is only ever raised.
+        static std::mutex mu;
+        static std::map<std::pair<int, const void*>, size_t> attr_set;
+        static std::map<std::tuple<int, const void*, size_t>, bool> fits;
+        bool raise_attr, known;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = attr_set.find(std::make_pair(op->device, (const void*)kern));
+            raise_attr = it == attr_set.end() || it->second < lds;
+            known = fits.count(std::make_tuple(op->device, (const void*)kern, lds)) != 0;
+        }
+        if (raise_attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            std::lock_guard<std::mutex> lk(mu);
+            attr_set[std::make_pair(op->device, (const void*)kern)] = lds;
+        }
+        if (!known) {
+            // the hand-rolled grid barrier needs every workgroup of a launch resident: at most one workgroup per CU is asked for
+            // (G * nsys <= num_cu above), so it is enough that ONE fits a CU with these registers and this much LDS
+            int fit = 0;
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, kern, kLineThreads, lds);
+            if (e != hipSuccess) return e;
+            if (fit < 1) return hipErrorLaunchOutOfResources;
+            std::lock_guard<std::mutex> lk(mu);
+            fits[std::make_tuple(op->device, (const void*)kern, lds)] = true;
+        }
         hipLaunchKernelGGL(kern, dim3(G, nsys), dim3(kLineThreads), lds, stream, ca);
         return hipGetLastError();
     };
@@ -2926,10 +2980,15 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
             ca.x = (double2*)x + (int64_t)s0 * g.M;
             ca.iters = d_iters + s0;
             ca.hist = s0 == 0 ? cg_history().buf : nullptr;
-            EFGP_HIP_CHECK(hipMemsetAsync(scb + off_bar, 0, (size_t)per * 64, stream));
             // the status word is cleared before EVERY launch: a dead barrier in one slab of systems must not make the later
-            // slabs give up at their first poll (the per-system iteration counts carry the -3 of the slab that died)
-            EFGP_HIP_CHECK(hipMemsetAsync(scb + off_status, test_dead ? 1 : 0, 64, stream));
+            // slabs give up at their first poll (the per-system iteration counts carry the -3 of the slab that died).  It sits
+            // right behind the arrival counters: one fill for both
+            if (!test_dead) {
+                EFGP_HIP_CHECK(hipMemsetAsync(scb + off_bar, 0, (size_t)per * 64 + 64, stream));
+            } else {
+                EFGP_HIP_CHECK(hipMemsetAsync(scb + off_bar, 0, (size_t)per * 64, stream));
+                EFGP_HIP_CHECK(hipMemsetAsync(scb + off_status, 1, 64, stream));
+            }
             hipError_t e;
             if (herm) {
                 if (G == 1 && ks == 8) e = launch(cg_coop2d_herm_kernel<8, true>, nsys);
@@ -3474,25 +3533,32 @@ static int cg_solve_impl(efgp_toeplitz_t* op, const void* ws, double sigmasq, in
 
 static int cg_solve_async_impl(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
                                const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop,
-                               int batched_semantics, int* row_iters_dev, void* stream_, int hermitian);
+                               int batched_semantics, int* row_iters_dev, void* stream_, int hermitian, int zero_x0);
 
 int efgp_cg_solve_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
                         const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop,
                         int batched_semantics, int* row_iters_dev, void* stream_) {
     return cg_solve_async_impl(op, ws, sigmasq, variant, precond_diag, b, x, nbatch, tol, max_iter, early_stop, batched_semantics,
-                               row_iters_dev, stream_, 0);
+                               row_iters_dev, stream_, 0, 0);
 }
 
 int efgp_cg_solve_hermitian_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
                                   const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop,
                                   int batched_semantics, int* row_iters_dev, void* stream_) {
     return cg_solve_async_impl(op, ws, sigmasq, variant, precond_diag, b, x, nbatch, tol, max_iter, early_stop, batched_semantics,
-                               row_iters_dev, stream_, 1);
+                               row_iters_dev, stream_, 1, 0);
+}
+
+int efgp_cg_solve_from_zero_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
+                                  const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop, int batched_semantics,
+                                  int hermitian, int* row_iters_dev, void* stream_) {
+    return cg_solve_async_impl(op, ws, sigmasq, variant, precond_diag, b, x, nbatch, tol, max_iter, early_stop, batched_semantics,
+                               row_iters_dev, stream_, hermitian ? 1 : 0, 1);
 }
 
 static int cg_solve_async_impl(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
                                const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop,
-                               int batched_semantics, int* row_iters_dev, void* stream_, int hermitian) {
+                               int batched_semantics, int* row_iters_dev, void* stream_, int hermitian, int zero_x0) {
     EFGP_REQUIRE(op && ws && b && x && row_iters_dev, "efgp_cg_solve_async: null argument");
     EFGP_REQUIRE(nbatch >= 1, "efgp_cg_solve_async: nbatch must be >= 1");
     EFGP_REQUIRE(variant == 0 || variant == 1, "efgp_cg_solve_async: variant must be 0 or 1");
@@ -3506,7 +3572,7 @@ static int cg_solve_async_impl(efgp_toeplitz_t* op, const void* ws, double sigma
             DeviceGuard guard_c(op->device);
             if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * op->g.M, 2000000000);
             return coop_enqueue(op, ws, sigmasq, variant, precond_diag, b, x, nbatch, tol, max_iter, early_stop, batched_semantics,
-                                row_iters_dev, stream_c, nullptr, /*nan_on_dead*/ 1, hermitian);
+                                row_iters_dev, stream_c, nullptr, /*nan_on_dead*/ 1, hermitian, nullptr, 0, zero_x0);
         }
         set_error("efgp_cg_solve_async: grid does not fit the persistent kernel");
         return EFGP_EUNSUPPORTED;
@@ -3521,7 +3587,7 @@ static int cg_solve_async_impl(efgp_toeplitz_t* op, const void* ws, double sigma
     cg_operands(op, &gq, &twq, &vq);
     return persistent_cg_launch(*gq, twq, vq, (const double2*)ws, precond_diag, sigmasq,
                                 variant, tol, early_stop, batched_semantics, max_iter, (const double2*)b, (double2*)x, nbatch,
-                                row_iters_dev, stream, nullptr, 0, 0, nullptr, hermitian, op->h48.vhat ? &op->h48 : nullptr);
+                                row_iters_dev, stream, nullptr, 0, zero_x0, nullptr, hermitian, op->h48.vhat ? &op->h48 : nullptr);
 }
 
 int efgp_lanczos(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const void* z, int nprobes, int steps,
@@ -3549,6 +3615,14 @@ int efgp_cg_solve_mean_async(efgp_toeplitz_t* op, const void* ws, double sigmasq
                              void* x, double tol, int max_iter, int early_stop, int* iters_dev, void* stream_) {
     EFGP_REQUIRE(op && ws && fy && x && iters_dev, "efgp_cg_solve_mean_async: null argument");
     if (!op->persistent_ok || std::getenv("EFGP_NO_PERSISTENT_CG") != nullptr) {
+        // 2-D 128^2..512^2: the cooperative launch forms the right-hand side, the diagonal and the zero start itself as well (no
+        // prepare launch, no fill, no initial operator application); a dead grid barrier leaves iters = -3 and NaN
+        if (op->lines_ok && std::getenv("EFGP_NO_CG_COOP") == nullptr && std::getenv("EFGP_NO_CG_LINES") == nullptr) {
+            DeviceGuard guard_c(op->device);
+            if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * op->g.M, 2000000000);
+            return coop_enqueue(op, ws, sigmasq, 0, nullptr, fy, x, 1, tol, max_iter, early_stop, 0, iters_dev, (hipStream_t)stream_, nullptr,
+                                /*nan_on_dead*/ 1, /*hermitian*/ 1, diag_scale_dev, /*b_times_ws*/ 1, /*zero_x0*/ 1);
+        }
         set_error("efgp_cg_solve_mean_async: grid does not fit the persistent kernel");
         return EFGP_EUNSUPPORTED;
     }

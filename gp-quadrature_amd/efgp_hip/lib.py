@@ -77,6 +77,7 @@ _SIGNATURES = {
     "efgp_gradient_step": (_I, [_VP, _I, _I, _I64, _VP, _VP, _D, _I, _I, _D, _D, _D, _D, _D, _D, _D, _D, _I, _I, C.c_uint64, C.c_uint64,
                            _I, _I, _I, _I, C.POINTER(_I), _VP, _D, _D, _VP, _VP, _VP, _VP, _VP]),
     "efgp_cg_solve_hermitian_async": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, _VP, _VP]),
+    "efgp_cg_solve_from_zero_async": (_I, [_VP, _VP, _D, _I, _VP, _VP, _VP, _I, _D, _I, _I, _I, _I, _VP, _VP]),
     "efgp_cg_solve_mean_async": (_I, [_VP, _VP, _D, _VP, _VP, _VP, _D, _I, _I, _VP, _VP]),
     "efgp_cg_record_history": (_I, [_VP, _I]),
     "efgp_lanczos": (_I, [_VP, _VP, _D, _I, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP]),

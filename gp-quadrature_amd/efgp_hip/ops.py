@@ -453,16 +453,24 @@ def cg_solve_async(op, ws, sigmasq, variant, b, x0, tol, max_iter=None, early_st
     if batched is None:
         batched = b.ndim > 1
     bb = _dc(b.reshape(-1, op.size), dev, _CD)
-    x = _start_vector(x0, bb, op, dev)
     wsd = _dc(ws, dev, _CD)
     dg = _dc(diag, dev, _RD) if diag is not None else None
     B = bb.shape[0]
     mi = int(max_iter) if max_iter is not None else 2 * op.size
     rows_dev = torch.empty(B, dtype=torch.int32, device=dev)
-    with _on(dev):
-        fn = lib().efgp_cg_solve_hermitian_async if hermitian else lib().efgp_cg_solve_async
-        rc = fn(op._h, _ptr(wsd), float(sigmasq), int(variant), _ptr(dg) if dg is not None else None, _ptr(bb), _ptr(x), B,
-                float(tol), mi, int(bool(early_stop)), int(bool(batched)), _ptr(rows_dev), _stream(dev))
+    if x0 is None:
+        # from zero: the kernels start from x = 0 themselves (no fill launch, no initial operator application)
+        x = torch.empty(bb.shape, dtype=_CD, device=dev)
+        with _on(dev):
+            rc = lib().efgp_cg_solve_from_zero_async(op._h, _ptr(wsd), float(sigmasq), int(variant), _ptr(dg) if dg is not None else None,
+                                                     _ptr(bb), _ptr(x), B, float(tol), mi, int(bool(early_stop)), int(bool(batched)),
+                                                     int(bool(hermitian)), _ptr(rows_dev), _stream(dev))
+    else:
+        x = _start_vector(x0, bb, op, dev)
+        with _on(dev):
+            fn = lib().efgp_cg_solve_hermitian_async if hermitian else lib().efgp_cg_solve_async
+            rc = fn(op._h, _ptr(wsd), float(sigmasq), int(variant), _ptr(dg) if dg is not None else None, _ptr(bb), _ptr(x), B,
+                    float(tol), mi, int(bool(early_stop)), int(bool(batched)), _ptr(rows_dev), _stream(dev))
     if rc == EFGP_EUNSUPPORTED:
         return None
     check(rc, "efgp_cg_solve_async")

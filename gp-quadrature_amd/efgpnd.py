@@ -1352,7 +1352,6 @@ class EFGPND(nn.Module):
                 res = cg_solve(toeplitz._op, grid.ws, sig, 0, rhs, b0, tol, early_stop=True, diag=diag, batched=False,
                                hermitian=True)[:2]      # 3-D grids: the planes k0 >= 0 only (efgp_cg_solve_hermitian)
         beta, iters = res
-
         self._beta = beta.to(cdtype) if cdtype != torch.complex128 else beta
         self._xis = (grid, rdtype)                 # the (M, d) node tensor is built when somebody asks for it (property below)
         self._ws = grid.ws.to(cdtype) if cdtype != torch.complex128 else grid.ws
@@ -1362,6 +1361,23 @@ class EFGPND(nn.Module):
         self._last_fit_stats = dict(mean_cg_iters=iters, mtot=grid.mtot, feature_count=grid.M, h=grid.h)
         self._fitted = True
         self._update_param_cache()
+        if d == 2 and prod(int(f) for f in toeplitz._op.fft_shape) > 4096 and not isinstance(iters, int):
+            # cooperative launch (128^2..512^2): a grid barrier that could not get its workgroups resident together leaves -3 in the
+            # count and NaN in beta.  Nothing downstream reads the count before using beta, so it is read HERE -- last, behind the
+            # host's own bookkeeping, which thereby still overlaps the solve -- and a dead solve goes through the synchronous
+            # multi-launch iteration.
+            try:
+                iters.rows
+            except RuntimeError as err:
+                if "cooperative CG" not in str(err):
+                    raise
+                cidx = _center_flat(v)
+                diag, rhs = gradient_prepare(grid.ws, Fy, v.reshape(-1)[cidx:cidx + 1], sig, want_diag=use_precond)
+                beta, iters = cg_solve(toeplitz._op, grid.ws, sig, 0, rhs, None, tol, early_stop=True, diag=diag, batched=False,
+                                       hermitian=True)[:2]
+                self._beta = beta.to(cdtype) if cdtype != torch.complex128 else beta
+                self._fit_state["beta"] = beta
+                self._last_fit_stats["mean_cg_iters"] = iters
 
     @property
     def _xis(self):

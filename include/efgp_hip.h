@@ -282,6 +282,14 @@ int efgp_cg_solve_hermitian_async(efgp_toeplitz_t* op, const void* ws, double si
                                   const double* precond_diag, const void* b, void* x, int nbatch, double tol,
                                   int max_iter, int early_stop, int batched_semantics, int* row_iters_dev, void* stream);
 
+/* efgp_cg_solve_async / efgp_cg_solve_hermitian_async (hermitian != 0) from the start vector ZERO: x is output only -- no fill
+ * by the caller -- and the initial operator application (A 0 = 0) is skipped: one launch and, on the cooperative 128^2..512^2
+ * grids, one operator application less per solve.  The reference's solves of the variance and of the trace estimator all start
+ * from zero (cg.py:86-101 with x0 = None; efgpnd.py:205-236). */
+int efgp_cg_solve_from_zero_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, int variant, const double* precond_diag,
+                                  const void* b, void* x, int nbatch, double tol, int max_iter, int early_stop, int batched_semantics,
+                                  int hermitian, int* row_iters_dev, void* stream);
+
 /* efgp_cg_solve (synchronous, every grid) under the same promise as efgp_cg_solve_hermitian_async.  On 3-D circulant grids of
  * 64..256 per dimension (odd mtot) the multi-launch iteration then carries the planes k0 >= 0 only: half the lines in every
  * pass, two real columns per complex transform along dim 0, a REAL centred spectrum (cg3h_* kernels; BASELINE configs[4]:
@@ -309,7 +317,9 @@ int efgp_fft_c2c(int device, int rank, const long long* n, long long batch, void
  * CONTRACT: fy is the type-1 transform of REAL strengths (fy[-k] = conj fy[k]), ws is real and even and the operator's
  * Toeplitz vector comes from real weights -- true for every EFGP model (efgpnd.py:786-790).  On the 64 x 64 circulant
  * grid the solve then runs on real transforms (half the lines, see efgp_cg_solve_hermitian_async); an input that breaks
- * the contract is refused: iters_dev[0] = -2 and beta = NaN. */
+ * the contract is refused: iters_dev[0] = -2 and beta = NaN.  2-D grids of 128..512 per dimension: the cooperative launch of
+ * efgp_cg_solve_hermitian_async with the same in-kernel right-hand side, diagonal and zero start (iters_dev[0] = -3 and NaN
+ * when its grid barrier could not get the workgroups resident together: solve again through efgp_cg_solve). */
 int efgp_cg_solve_mean_async(efgp_toeplitz_t* op, const void* ws, double sigmasq, const double* diag_scale_dev, const void* fy,
                              void* x, double tol, int max_iter, int early_stop, int* iters_dev, void* stream);
 

@@ -97,3 +97,31 @@ def test_stochastic_variance_survives_a_dead_grid_barrier(monkeypatch):
     monkeypatch.delenv("EFGP_COOP_TEST_DEAD")
     assert torch.isfinite(var_dead).all()
     assert float((var_dead - var_ok).abs().max()) < 1e-6 * float(var_ok.abs().max())
+
+
+def test_fit_survives_a_dead_grid_barrier(monkeypatch):
+    """The fit's mean solve on a 128 x 128 circulant grid is ONE cooperative launch (efgp_cg_solve_mean_async: right-hand side,
+    Jacobi diagonal and zero start formed in the kernel; reference: efgpnd.py:786-813).  A dead grid barrier leaves -3 and NaN;
+    the fit reads the count once and re-solves through the multi-launch iteration: same coefficients, same iteration count."""
+    from efgpnd import EFGPND
+    from kernels.matern import Matern
+    g = torch.Generator().manual_seed(5)
+    N = 3000
+    x = torch.rand(N, 2, dtype=torch.float64, generator=g)
+    y = torch.sin(5 * x[:, 0]) * torch.cos(3 * x[:, 1]) + 0.1 * torch.randn(N, dtype=torch.float64, generator=g)
+
+    def fit():
+        kern = Matern(dimension=2, nu=2.5, init_lengthscale=0.1, init_variance=1.0)
+        model = EFGPND(x.cuda(), y.cuda(), kern, sigmasq=0.1, eps=1e-3, nufft_eps=1e-8, estimate_params=False,
+                       opts={"cg_tolerance": 1e-8, "mean_cg_warm_start": False})
+        model.fit()
+        assert tuple(model._toeplitz.fft_shape) == (128, 128)
+        return model._beta.clone(), int(model.last_fit_stats["mean_cg_iters"])
+
+    beta_ok, it_ok = fit()
+    monkeypatch.setenv("EFGP_COOP_TEST_DEAD", "1")
+    beta_dead, it_dead = fit()
+    monkeypatch.delenv("EFGP_COOP_TEST_DEAD")
+    assert torch.isfinite(torch.view_as_real(beta_dead)).all()
+    assert abs(it_dead - it_ok) <= 1
+    assert float((beta_dead - beta_ok).abs().max()) < 1e-7 * float(beta_ok.abs().max())
