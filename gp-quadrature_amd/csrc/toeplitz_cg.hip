@@ -2398,6 +2398,11 @@ struct efgp_toeplitz_s {
     bool coop_small = false;
     ToepGeom g_co;
     double2* vhat_co = nullptr;  // centred spectrum on g_co
+    // ... and the spectrum on the reference's grid (`vhat`) is then made on first use (ensure_reference_spectrum) from a copy of
+    // the Toeplitz vector: a fit only runs the cooperative solve, which never reads it (pad | two transform passes per operator)
+    bool vhat_ready = true;
+    double2* v_keep = nullptr;
+    size_t v_keep_bytes = 0;
     double2* tw_co[2] = {nullptr, nullptr};
     double* vc3 = nullptr;       // lines3_ok grids: REAL centred spectrum of the Hermitian 3-D iteration, built on first use
     ToepGeom g_cg;
@@ -2452,6 +2457,27 @@ static dim3 grid_for(int64_t work, int rows, int threads, int cap = 1024) {
     return dim3(blocks, rows);
 }
 
+// vhat = FFT(zero-padded v) / Ftot on the reference's grid, made on first use when the operator was created with a smaller
+// cooperative grid (efgp_toeplitz_create)
+static int ensure_reference_spectrum(efgp_toeplitz_s* op, hipStream_t stream) {
+    if (op->vhat_ready) return EFGP_OK;
+    ToepGeom gv = op->g;
+    gv.M = 1;
+    for (int a = 0; a < 3; ++a) {
+        gv.n[a] = op->Ls[a];
+        gv.M *= gv.n[a];
+    }
+    hipLaunchKernelGGL(pad_scale_kernel, grid_for(op->g.Ftot, 1, kVecThreads), dim3(kVecThreads), 0, stream, gv, (const double2*)op->v_keep,
+                       gv.M, (const double2*)nullptr, (const int*)nullptr, (const int*)nullptr, op->vhat, 1.0 / (double)op->g.Ftot);
+    EFGP_HIP_CHECK(hipGetLastError());
+    int rc = fft_c2c(op->ctx, op->g.d, op->g.F, 1, op->vhat, true, stream);
+    if (rc != EFGP_OK) return rc;
+    op->vhat_ready = true;
+    pool_free(op->ctx, op->v_keep, op->v_keep_bytes);        // stream-ordered reuse: the pad launch above read it on this stream
+    op->v_keep = nullptr;
+    return EFGP_OK;
+}
+
 // pad = FFT^-1( FFT(pad) .* vhat ) for `slots` rows
 static int circulant(efgp_toeplitz_s* op, double2* pad, int slots, hipStream_t stream) {
     // in-house transforms know the padding: the input is non-zero on [0, n) per axis, the product is read on [n - 1, 2 n - 1)
@@ -2461,8 +2487,10 @@ static int circulant(efgp_toeplitz_s* op, double2* pad, int slots, hipStream_t s
         cnt[a] = a < op->g.d ? op->g.n[a] : 1;
         lo_out[a] = a < op->g.d ? std::min(op->g.n[a] - 1, op->g.F[a] - op->g.n[a]) : 0;
     }
-    int rc = own ? own_fft_exec_windowed(op->ctx, op->g.d, op->g.F, slots, pad, true, lo_in, cnt, false, stream)
-                 : fft_c2c(op->ctx, op->g.d, op->g.F, slots, pad, true, stream);
+    int rc = ensure_reference_spectrum(op, stream);
+    if (rc != EFGP_OK) return rc;
+    rc = own ? own_fft_exec_windowed(op->ctx, op->g.d, op->g.F, slots, pad, true, lo_in, cnt, false, stream)
+             : fft_c2c(op->ctx, op->g.d, op->g.F, slots, pad, true, stream);
     if (rc != EFGP_OK) return rc;
     hipLaunchKernelGGL(spectral_mul_kernel, grid_for(op->g.Ftot, slots, kVecThreads), dim3(kVecThreads), 0, stream,
                        op->g.Ftot, (const double2*)op->vhat, pad);
@@ -2474,6 +2502,7 @@ static int circulant(efgp_toeplitz_s* op, double2* pad, int slots, hipStream_t s
 // vhat_c = vhat rotated so that the circular convolution has its crop window at [0, n) (cooperative solve on the reference's grid)
 static bool ensure_centred_spectrum(efgp_toeplitz_s* op, hipStream_t stream) {
     if (op->vhat_c) return true;
+    if (ensure_reference_spectrum(op, stream) != EFGP_OK) return false;
     op->vhat_c = (double2*)pool_alloc(op->ctx, (size_t)op->g.Ftot * sizeof(double2));
     if (!op->vhat_c) return false;
     hipLaunchKernelGGL(center_spectrum_kernel, dim3((unsigned)((op->g.Ftot + 255) / 256)), dim3(256), 0, stream, op->vhat, op->tw[0],
@@ -2536,7 +2565,27 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
         if (op->vhat48) op->h48.tw = tw48;
     }
     bool made48 = false;
-    if (toeplitz_vhat_fused_eligible(op->g)) {
+    // 2-D grids of the cooperative solve (128..512 per axis): when a smaller cooperative grid exists (made below) nothing on the
+    // fit path reads the reference grid's spectrum -- keep a copy of v and make it on first use
+    bool defer_ref = dim == 2 && std::getenv("EFGP_NO_COOP_SMALL") == nullptr && std::getenv("EFGP_EAGER_REF_SPECTRUM") == nullptr;
+    for (int a = 0; a < dim && defer_ref; ++a) {
+        const int64_t F = op->g.F[a];
+        defer_ref = F >= 128 && F <= 512 && (F & (F - 1)) == 0;
+    }
+    if (defer_ref) {
+        op->v_keep_bytes = (size_t)gv.M * sizeof(double2);
+        op->v_keep = (double2*)pool_alloc(ctx, op->v_keep_bytes);
+        defer_ref = op->v_keep != nullptr &&
+                    hipMemcpyAsync(op->v_keep, v, op->v_keep_bytes, hipMemcpyDeviceToDevice, stream) == hipSuccess;
+        if (!defer_ref && op->v_keep) {
+            pool_free(ctx, op->v_keep, op->v_keep_bytes);
+            op->v_keep = nullptr;
+        }
+        op->vhat_ready = !defer_ref;
+    }
+    if (defer_ref) {
+        // nothing now
+    } else if (toeplitz_vhat_fused_eligible(op->g)) {
         if (op->vhat48) {
             rc = toeplitz_vhat_pair_launch((const double2*)v, (int)op->Ls[0], (int)op->Ls[1], op->vhat, op->vhat48, stream);
             made48 = rc == EFGP_OK;
@@ -2648,6 +2697,13 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
     }
     // the centred spectrum on the reference's grid: needed by the cooperative solve only when it runs there (no smaller grid, or
     // EFGP_NO_COOP_SMALL later on: built on first use then)
+    if (!op->vhat_ready && !op->coop_small) {
+        rc = ensure_reference_spectrum(op, stream);
+        if (rc != EFGP_OK) {
+            efgp_toeplitz_destroy(op);
+            return rc;
+        }
+    }
     if (op->lines_ok && !op->coop_small) (void)ensure_centred_spectrum(op, stream);
     if (dim == 2 && op->persistent_ok && op->g.n[0] == op->g.n[1] && op->g.F[0] == op->g.F[1] && op->g.F[0] < 64 &&
         op->Ls[0] <= 63 && std::getenv("EFGP_NO_CG64_EMBED") == nullptr && std::getenv("EFGP_NO_CG64") == nullptr) {
@@ -2707,6 +2763,7 @@ int efgp_toeplitz_destroy(efgp_toeplitz_t* op) {
     if (op->vhat48) pool_free(op->ctx, op->vhat48, (size_t)2304 * sizeof(double2));
     if (op->vhat_c) pool_free(op->ctx, op->vhat_c, (size_t)op->g.Ftot * sizeof(double2));
     if (op->vhat_co) pool_free(op->ctx, op->vhat_co, (size_t)op->g_co.Ftot * sizeof(double2));
+    if (op->v_keep) pool_free(op->ctx, op->v_keep, op->v_keep_bytes);
     if (op->vc3) pool_free(op->ctx, op->vc3, (size_t)op->g.Ftot * sizeof(double));
     delete op;
     return EFGP_OK;
@@ -3240,6 +3297,8 @@ static int cg_solve_impl(efgp_toeplitz_t* op, const void* ws, double sigmasq, in
         LineArgs la;
         size_t lds_rows = 0, lds_cols = 0;
         if (use_lines) {
+            rc = ensure_reference_spectrum(op, stream);
+            if (rc != EFGP_OK) return rc;
             la.vhat = op->vhat;
             la.tw0 = op->tw[0];
             la.tw1 = op->tw[1];
