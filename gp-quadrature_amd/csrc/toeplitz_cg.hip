@@ -2912,6 +2912,7 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     // workgroup per CU), never fewer than the registers need (8 vector entries per thread)
     int G_lat = F1 / 8;      // 16 / 32 / 64 (measured at 128^2: 19.9 us per iteration with 16 workgroups, 22.7 with 32, 20.6 with 8)
     if (herm && F1 <= 256) G_lat = F1 / 16;   // half the work per system: 8 / 16 workgroups measured best at 128^2 / 256^2, 64 at 512^2
+    if (const char* ed = std::getenv("EFGP_COOP_GDIV")) G_lat = std::max(1, F1 / std::max(1, std::atoi(ed)));  // experiments: G = F1 / div
     if (const char* eg = std::getenv("EFGP_COOP_G")) G_lat = std::max(1, std::min(G_lat, std::atoi(eg)));   // experiments
     // the workgroup counts a grid offers: G_lat halved while it stays whole (16 8 4 2 1; 12 6 3 1 on the 48 R grids)
     auto halve = [](int Gv) { return Gv > 1 ? ((Gv & 1) ? 1 : Gv / 2) : 1; };
