@@ -1214,7 +1214,7 @@ class EFGPND(nn.Module):
         else:
             for name, value in self.kernel.iter_hypers():
                 self._cached_params[name] = float(value)
-        self._cached_params["sigmasq"] = float(self.sigmasq.detach())
+        self._cached_params["sigmasq"] = self._gp_params.host_pos()[-1]
         return self
 
     def _params_changed(self):
@@ -1285,7 +1285,7 @@ class EFGPND(nn.Module):
         stats: Dict = {}
         dd = self._device_data()
         res = efgpnd_gradient_batched(
-            dd["x"], dd["y"], sigmasq=self._gp_params.sig2, kernel=self.kernel, eps=self.eps,
+            dd["x"], dd["y"], sigmasq=self._gp_params.host_pos()[-1], kernel=self.kernel, eps=self.eps,
             trace_samples=trace_samples, do_profiling=do_profiling, nufft_eps=nufft_eps, cg_tol=cg_tol,
             noise_floor=noise_floor, stats_out=stats,
             mean_cg_init=self._last_gradient_beta if warm else None,
@@ -1301,10 +1301,10 @@ class EFGPND(nn.Module):
         if grads.ndim == 0:
             grads = grads.unsqueeze(0)
         raw = self._gp_params.raw
-        pos = self._gp_params.pos.detach()
+        pos = raw.detach().exp()                         # = pos, without recording the exp for autograd
         if grad_host is not None and raw.device.type == "cpu":
             grads = grad_host
-        raw_grad = (grads.detach().to(device=raw.device, dtype=raw.dtype) * pos).clone()   # chain rule d/dlog
+        raw_grad = grads.detach().to(device=raw.device, dtype=raw.dtype) * pos               # chain rule d/dlog
         if apply_gradients:
             with torch.no_grad():
                 raw.grad = raw_grad.detach().clone()
@@ -1321,7 +1321,7 @@ class EFGPND(nn.Module):
         dd = self._device_data()
         dev, xd, yd = dd["dev"], dd["x"], dd["y"]
         d = xd.shape[1]
-        sig = float(self._gp_params.sig2.detach())
+        sig = self._gp_params.host_pos()[-1]
         rdtype = self.x.dtype
         cdtype = _cmplx(rdtype)
 

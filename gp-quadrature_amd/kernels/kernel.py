@@ -52,7 +52,7 @@ class Kernel:
         ref = self._gp_params_ref
         if ref is None:
             return tuple(self._params_dict[name] for name in self.hypers)
-        vals = ref.raw.detach().exp().tolist()
+        vals = ref.host_pos() if hasattr(ref, "host_pos") else ref.raw.detach().exp().tolist()
         return tuple(float(vals[ref.hypers_names.index(name)]) for name in self.hypers)
 
     def set_hyper(self, name, value):

@@ -28,6 +28,18 @@ class GPParams(nn.Module):
     def pos(self):
         return self.raw.exp()
 
+    def host_pos(self):
+        """exp(raw) as Python floats -- the values `pos[i].item()` gives, rounded as torch rounds them in raw's dtype -- from ONE
+        read of the parameter vector: the tuple is kept and handed out again as long as raw holds the same numbers (checked by
+        value on every call: in-place writes through `.data` do not move a version counter).  A fit or gradient step asks for the
+        hyper-parameters four or five times; each exp + item on the tracked parameter costs 5-10 us of host time."""
+        now = self.raw.detach().tolist()
+        kept = self.__dict__.get("_host_pos")
+        if kept is None or kept[0] != now:
+            kept = (now, tuple(float(v) for v in self.raw.detach().exp().tolist()))
+            self.__dict__["_host_pos"] = kept
+        return kept[1]
+
     @property
     def sig2(self):
         return self.pos[-1]
