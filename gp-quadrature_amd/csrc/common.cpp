@@ -61,6 +61,26 @@ DeviceCtx* device_ctx(int device) {
     return raw;
 }
 
+void stream_handover(int device, hipStream_t stream) {
+    DeviceCtx* ctx = device_ctx(device);
+    if (!ctx) return;
+    if (ctx->last_stream_set && ctx->last_stream == stream) return;
+    if (ctx->last_stream_set && std::getenv("EFGP_NO_STREAM_HANDOVER") == nullptr) {      // (the switch is for the test that shows the race)
+        bool ordered = false;
+        if (!ctx->handover_event && hipEventCreateWithFlags(&ctx->handover_event, hipEventDisableTiming) != hipSuccess)
+            ctx->handover_event = nullptr;
+        if (ctx->handover_event && hipEventRecord(ctx->handover_event, ctx->last_stream) == hipSuccess &&
+            hipStreamWaitEvent(stream, ctx->handover_event, 0) == hipSuccess)
+            ordered = true;
+        if (!ordered) {                       // e.g. the previous stream no longer exists
+            (void)hipGetLastError();
+            (void)hipDeviceSynchronize();
+        }
+    }
+    ctx->last_stream = stream;
+    ctx->last_stream_set = true;
+}
+
 void* scratch(DeviceCtx* ctx, Slot slot, size_t bytes) {
     if (bytes == 0) bytes = 256;
     if (slot == SLOT_SLABS) ctx->slabs_zero_bytes = 0;      // callers that rely on it re-establish it themselves
@@ -219,6 +239,7 @@ void release_ctx(int device) {
         }
         if (c->aux_event) (void)hipEventDestroy(c->aux_event);
         if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+        if (c->handover_event) (void)hipEventDestroy(c->handover_event);
         for (auto& kv : c->pool)
             for (void* p : kv.second) (void)hipFree(p);
         for (auto& kv : c->twiddles) (void)hipFree(kv.second);

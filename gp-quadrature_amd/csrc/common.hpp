@@ -93,6 +93,10 @@ struct DeviceCtx {
     // side stream for hipGraph capture (capture is not allowed on the legacy default stream torch usually hands us)
     hipStream_t aux_stream = nullptr;
     hipEvent_t aux_event = nullptr;
+    // the stream the context's work was last enqueued on, and the event of a hand-over to another one (stream_handover)
+    hipStream_t last_stream = nullptr;
+    bool last_stream_set = false;
+    hipEvent_t handover_event = nullptr;
     // ring of pinned staging slots for small host -> device uploads that must not drain the stream (upload_small)
     static constexpr int kUploadSlots = 8;
     static constexpr size_t kUploadSlotBytes = size_t(64) << 10;
@@ -146,6 +150,12 @@ struct KernelTimer {     // RAII: records start at construction, stop at destruc
     hipStream_t stream = nullptr;
 };
 
+// A device context is single-stream at any moment (shared scratch, pooled blocks reused in stream order, caches): a caller that
+// comes in on ANOTHER stream than the context's last one is ordered behind everything queued on that one (an event recorded
+// there, awaited here; a device-wide wait when that fails) instead of racing with it.  Nothing happens while the stream stays
+// the same.  Host threads are not serialised: one thread per device at a time, as before.
+void stream_handover(int device, hipStream_t stream);
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;
@@ -153,6 +163,10 @@ struct DeviceGuard {
         if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
         if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
         target = dev;
+    }
+    // entry points that enqueue work: the guard also hands the context over to the caller's stream
+    DeviceGuard(int dev, hipStream_t stream) : DeviceGuard(dev) {
+        if (ok) stream_handover(dev, stream);
     }
     ~DeviceGuard() {
         if (ok && prev >= 0 && prev != target) (void)hipSetDevice(prev);

@@ -183,7 +183,7 @@ int efgp_gradient_prepare(int device, int64_t nmodes, const void* ws, const void
     EFGP_REQUIRE(!rhs || fy, "efgp_gradient_prepare: rhs wanted but fy is null");
     EFGP_REQUIRE(!diag || v_center, "efgp_gradient_prepare: diag wanted but v_center is null");
     if (!device_ctx(device)) return EFGP_EHIP;
-    DeviceGuard guard(device);
+    DeviceGuard guard(device, (hipStream_t)stream_);
     const unsigned blocks = (unsigned)std::min<int64_t>(1024, (nmodes + 255) / 256);
     hipLaunchKernelGGL(grad::prepare_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, nmodes, (const double2*)ws, (const double2*)fy,
                        (const double2*)v_center, sigmasq, diag, (double2*)rhs);
@@ -210,7 +210,7 @@ int efgp_gradient_assemble(int device, int64_t nmodes, int nprobes, int n_kernel
                      "efgp_gradient_assemble: bad trace_idx[%d] = %d", s, trace_idx[s]);
     DeviceCtx* ctx = device_ctx(device);
     if (!ctx) return EFGP_EHIP;
-    DeviceGuard guard(device);
+    DeviceGuard guard(device, (hipStream_t)stream_);
     hipStream_t stream = (hipStream_t)stream_;
     const int blocks = (int)std::min<int64_t>(kMaxBlocks, (nmodes + kThreads - 1) / kThreads);
     double* partial = (double*)scratch(ctx, SLOT_MISC, (size_t)kMaxBlocks * kQPad * sizeof(double));

@@ -51,7 +51,7 @@ extern "C" int efgp_gradient_step(efgp_points_t* points, int device, int dim, in
     DeviceCtx* ctx = device_ctx(device);
     if (!ctx) return EFGP_EHIP;
     hipStream_t stream = (hipStream_t)stream_;
-    DeviceGuard guard(device);
+    DeviceGuard guard(device, stream);
     const int T = nprobes, K = n_trace, R = (K + 1) * T;
     const int m = (mtot - 1) / 2;
     int64_t M = 1, Lv = 1, cells = 1;

@@ -438,7 +438,7 @@ int fft_c2c(DeviceCtx* ctx, int rank, const int64_t* n, int64_t batch, double2* 
 extern "C" int efgp_fft_c2c(int device, int rank, const long long* n, long long batch, void* data, int forward, int use_rocfft, void* stream_) {
     using namespace efgp;
     EFGP_REQUIRE(rank >= 1 && rank <= 3 && n && data && batch >= 1, "efgp_fft_c2c: bad argument");
-    DeviceGuard guard(device);
+    DeviceGuard guard(device, (hipStream_t)stream_);
     DeviceCtx* ctx = device_ctx(device);
     if (!ctx) return EFGP_EHIP;
     int64_t nn[3];

@@ -3317,7 +3317,7 @@ int efgp_nufft_type1(efgp_nufft_t* plan, const void* c, int c_is_complex, int nb
     for (int a = 0; a < plan->dim; ++a) EFGP_REQUIRE(n_modes[a] >= 1, "efgp_nufft_type1: n_modes[%d] < 1", a);
     EFGP_REQUIRE(isign == 1 || isign == -1, "efgp_nufft_type1: isign must be +-1");
     hipStream_t stream = (hipStream_t)stream_;
-    DeviceGuard guard(plan->device);
+    DeviceGuard guard(plan->device, (hipStream_t)stream_);
     WindowSet* w = nullptr;
     int rc = get_window(plan, n_modes, stream, &w);
     if (rc != EFGP_OK) return rc;
@@ -3340,7 +3340,7 @@ int efgp_nufft_type1_rademacher(efgp_nufft_t* plan, uint64_t seed, int64_t index
     EFGP_REQUIRE(nbatch >= 1, "efgp_nufft_type1_rademacher: nbatch must be >= 1");
     for (int a = 0; a < plan->dim; ++a) EFGP_REQUIRE(n_modes[a] >= 1, "efgp_nufft_type1_rademacher: n_modes[%d] < 1", a);
     hipStream_t stream = (hipStream_t)stream_;
-    DeviceGuard guard(plan->device);
+    DeviceGuard guard(plan->device, (hipStream_t)stream_);
     WindowSet* w = nullptr;
     int rc = get_window(plan, n_modes, stream, &w);
     if (rc != EFGP_OK) return rc;
@@ -3360,7 +3360,7 @@ int efgp_rademacher_fill(int device, uint64_t seed, int64_t index_offset, int nb
     EFGP_REQUIRE(nbatch >= 1 && npts >= 0, "efgp_rademacher_fill: bad sizes");
     if (npts == 0) return EFGP_OK;
     if (!device_ctx(device)) return EFGP_EHIP;
-    DeviceGuard guard(device);
+    DeviceGuard guard(device, (hipStream_t)stream_);
     hipStream_t stream = (hipStream_t)stream_;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((npts + 255) / 256, 4096));
     hipLaunchKernelGGL(rademacher_fill_kernel, dim3(blocks, nbatch), dim3(256), 0, stream, (unsigned long long)seed, npts, index_offset,
@@ -3376,7 +3376,7 @@ int efgp_nufft_type1_pair(efgp_nufft_t* plan, const double* y, const int64_t* n_
     EFGP_REQUIRE(!out_y || (y && n_modes_y), "efgp_nufft_type1_pair: y / n_modes_y missing");
     EFGP_REQUIRE(!out_ones || n_modes_one, "efgp_nufft_type1_pair: n_modes_one missing");
     hipStream_t stream = (hipStream_t)stream_;
-    DeviceGuard guard(plan->device);
+    DeviceGuard guard(plan->device, (hipStream_t)stream_);
     // one fine grid sized for the larger box serves both
     int64_t box[3] = {1, 1, 1};
     for (int a = 0; a < plan->dim; ++a) {
@@ -3465,7 +3465,7 @@ static int type2_impl(efgp_nufft_t* plan, const void* f, const void* mode_scale,
     EFGP_REQUIRE(isign == 1 || isign == -1, "efgp_nufft_type2: isign must be +-1");
     if (plan->npts == 0) return EFGP_OK;
     hipStream_t stream = (hipStream_t)stream_;
-    DeviceGuard guard(plan->device);
+    DeviceGuard guard(plan->device, (hipStream_t)stream_);
     DeviceCtx* ctx = plan->ctx;
     WindowSet* w = nullptr;
     int rc = get_window(plan, n_modes, stream, &w);

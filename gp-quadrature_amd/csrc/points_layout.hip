@@ -329,7 +329,7 @@ int efgp_points_create(efgp_points_t** out, int device, int dim, int64_t npts, c
     EFGP_REQUIRE(npts == 0 || x, "efgp_points_create: null x");
     DeviceCtx* ctx = device_ctx(device);
     if (!ctx) return EFGP_EHIP;
-    DeviceGuard guard(device);
+    DeviceGuard guard(device, (hipStream_t)stream_);
     hipStream_t stream = (hipStream_t)stream_;
     auto* p = new efgp_points_s();
     p->device = device;
@@ -391,7 +391,7 @@ int efgp_points_bounds(efgp_points_t* pts, double* lo_out, double* hi_out) {
 
 int efgp_points_attach_values(efgp_points_t* pts, const double* y, void* stream_) {
     EFGP_REQUIRE(pts, "efgp_points_attach_values: null layout");
-    DeviceGuard guard(pts->device);
+    DeviceGuard guard(pts->device, (hipStream_t)stream_);
     hipStream_t stream = (hipStream_t)stream_;
     pts->values = y;
     pts->pair_scale_ready = false;

@@ -2527,7 +2527,7 @@ int efgp_toeplitz_create(efgp_toeplitz_t** op_out, int device, int dim, const in
     DeviceCtx* ctx = device_ctx(device);
     if (!ctx) return EFGP_EHIP;
     hipStream_t stream = (hipStream_t)stream_;
-    DeviceGuard guard(device);
+    DeviceGuard guard(device, (hipStream_t)stream_);
     auto* op = new efgp_toeplitz_s();
     op->device = device;
     op->ctx = ctx;
@@ -2796,7 +2796,7 @@ int efgp_toeplitz_apply(efgp_toeplitz_t* op, const void* x, int nbatch, void* y,
     EFGP_REQUIRE(op && x && y, "efgp_toeplitz_apply: null argument");
     EFGP_REQUIRE(nbatch >= 1, "efgp_toeplitz_apply: nbatch must be >= 1");
     hipStream_t stream = (hipStream_t)stream_;
-    DeviceGuard guard(op->device);
+    DeviceGuard guard(op->device, (hipStream_t)stream_);
     // bound the scratch: process rows in chunks of at most ~256 MB of padded grid
     const int64_t max_rows = std::max<int64_t>(1, (int64_t)(256ll << 20) / (op->g.Ftot * (int64_t)sizeof(double2)));
     for (int64_t r0 = 0; r0 < nbatch; r0 += max_rows) {
@@ -2822,7 +2822,7 @@ int efgp_toeplitz_apply_scaled(efgp_toeplitz_t* op, const void* x, int x_is_real
     EFGP_REQUIRE(nbatch >= 1, "efgp_toeplitz_apply_scaled: nbatch must be >= 1");
     EFGP_REQUIRE(x != y, "efgp_toeplitz_apply_scaled: x and y must not alias");
     hipStream_t stream = (hipStream_t)stream_;
-    DeviceGuard guard(op->device);
+    DeviceGuard guard(op->device, (hipStream_t)stream_);
     const ToepGeom* gq;
     const double2* const* twq;
     const double2* vq;
@@ -2855,7 +2855,7 @@ int efgp_internal_apply_scaled(efgp_toeplitz_s* op, const void* x, int x_is_real
                                const void* post, void* y, hipStream_t stream) {
     if (pre == nullptr || pre_stride == 1) return efgp_toeplitz_apply_scaled(op, x, x_is_real, nbatch, pre, post, y, stream);
     EFGP_REQUIRE(op && x && y && nbatch >= 1 && x != y && pre_stride >= 1, "efgp_internal_apply_scaled: bad argument");
-    DeviceGuard guard(op->device);
+    DeviceGuard guard(op->device, stream);
     const ToepGeom* gq;
     const double2* const* twq;
     const double2* vq;
@@ -2872,7 +2872,7 @@ int efgp_internal_cg_single_launch(efgp_toeplitz_s* op, const void* ws, double s
     EFGP_REQUIRE(op && ws && b && x && row_iters_dev && nbatch >= 1, "efgp_internal_cg_single_launch: bad argument");
     EFGP_REQUIRE(batched_semantics || nbatch == 1, "efgp_internal_cg_single_launch: single-system semantics need nbatch == 1");
     if (!op->persistent_ok || std::getenv("EFGP_NO_PERSISTENT_CG") != nullptr) return EFGP_EUNSUPPORTED;
-    DeviceGuard guard(op->device);
+    DeviceGuard guard(op->device, stream);
     if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * op->g.M, 2000000000);
     KernelTimer timer("cg_persistent", stream);
     const ToepGeom* gq;
@@ -3116,7 +3116,7 @@ static int cg_solve_impl(efgp_toeplitz_t* op, const void* ws, double sigmasq, in
     EFGP_REQUIRE(batched_semantics || nbatch == 1, "efgp_cg_solve: single-system semantics need nbatch == 1");
     EFGP_REQUIRE(sigmasq > 0.0 || variant == 0, "efgp_cg_solve: sigmasq must be positive for A_var");
     hipStream_t stream = (hipStream_t)stream_;
-    DeviceGuard guard(op->device);
+    DeviceGuard guard(op->device, (hipStream_t)stream_);
     DeviceCtx* ctx = op->ctx;
     const ToepGeom g = op->g;
     if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * g.M, 2000000000);
@@ -3629,7 +3629,7 @@ static int cg_solve_async_impl(efgp_toeplitz_t* op, const void* ws, double sigma
         // co-resident -- reports -3 iterations and keeps x0; the synchronous entry retries those through the multi-launch path)
         if (op->lines_ok && std::getenv("EFGP_NO_CG_COOP") == nullptr && std::getenv("EFGP_NO_CG_LINES") == nullptr) {
             hipStream_t stream_c = (hipStream_t)stream_;
-            DeviceGuard guard_c(op->device);
+            DeviceGuard guard_c(op->device, (hipStream_t)stream_);
             if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * op->g.M, 2000000000);
             return coop_enqueue(op, ws, sigmasq, variant, precond_diag, b, x, nbatch, tol, max_iter, early_stop, batched_semantics,
                                 row_iters_dev, stream_c, nullptr, /*nan_on_dead*/ 1, hermitian, nullptr, 0, zero_x0);
@@ -3638,7 +3638,7 @@ static int cg_solve_async_impl(efgp_toeplitz_t* op, const void* ws, double sigma
         return EFGP_EUNSUPPORTED;
     }
     hipStream_t stream = (hipStream_t)stream_;
-    DeviceGuard guard(op->device);
+    DeviceGuard guard(op->device, (hipStream_t)stream_);
     if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * op->g.M, 2000000000);
     KernelTimer timer("cg_persistent", stream);
     const ToepGeom* gq;
@@ -3661,7 +3661,7 @@ int efgp_lanczos(efgp_toeplitz_t* op, const void* ws, double sigmasq, int varian
         return EFGP_EUNSUPPORTED;
     }
     hipStream_t stream = (hipStream_t)stream_;
-    DeviceGuard guard(op->device);
+    DeviceGuard guard(op->device, (hipStream_t)stream_);
     const LanczosOut lz{steps, alpha_dev, beta_dev, norm2_dev};
     const ToepGeom* gq;
     const double2* const* twq;
@@ -3678,7 +3678,7 @@ int efgp_cg_solve_mean_async(efgp_toeplitz_t* op, const void* ws, double sigmasq
         // 2-D 128^2..512^2: the cooperative launch forms the right-hand side, the diagonal and the zero start itself as well (no
         // prepare launch, no fill, no initial operator application); a dead grid barrier leaves iters = -3 and NaN
         if (op->lines_ok && std::getenv("EFGP_NO_CG_COOP") == nullptr && std::getenv("EFGP_NO_CG_LINES") == nullptr) {
-            DeviceGuard guard_c(op->device);
+            DeviceGuard guard_c(op->device, (hipStream_t)stream_);
             if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * op->g.M, 2000000000);
             return coop_enqueue(op, ws, sigmasq, 0, nullptr, fy, x, 1, tol, max_iter, early_stop, 0, iters_dev, (hipStream_t)stream_, nullptr,
                                 /*nan_on_dead*/ 1, /*hermitian*/ 1, diag_scale_dev, /*b_times_ws*/ 1, /*zero_x0*/ 1);
@@ -3687,7 +3687,7 @@ int efgp_cg_solve_mean_async(efgp_toeplitz_t* op, const void* ws, double sigmasq
         return EFGP_EUNSUPPORTED;
     }
     hipStream_t stream = (hipStream_t)stream_;
-    DeviceGuard guard(op->device);
+    DeviceGuard guard(op->device, (hipStream_t)stream_);
     if (max_iter <= 0) max_iter = (int)std::min<int64_t>(2 * op->g.M, 2000000000);
     KernelTimer timer("cg_persistent", stream);
     const ToepGeom* gq;
@@ -3710,7 +3710,7 @@ int efgp_vdot_real(int device, const void* a, int a_is_complex, const void* b, i
     DeviceCtx* ctx = device_ctx(device);
     if (!ctx) return EFGP_EHIP;
     hipStream_t stream = (hipStream_t)stream_;
-    DeviceGuard guard(device);
+    DeviceGuard guard(device, (hipStream_t)stream_);
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((count + kVecThreads - 1) / kVecThreads, 2048));
     double* partial = (double*)scratch(ctx, SLOT_MISC, (size_t)blocks * sizeof(double));
     double* host = (double*)pinned_host(ctx, (size_t)blocks * sizeof(double));

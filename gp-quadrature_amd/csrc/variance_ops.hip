@@ -181,7 +181,7 @@ int efgp_lag_sums(int device, int dim, int64_t mtot, const void* gamma, const do
     EFGP_REQUIRE(gamma && eta && out, "efgp_lag_sums: null argument");
     DeviceCtx* ctx = device_ctx(device);
     if (!ctx) return EFGP_EHIP;
-    DeviceGuard guard(device);
+    DeviceGuard guard(device, (hipStream_t)stream_);
     hipStream_t stream = (hipStream_t)stream_;
     LagGeom g;
     g.d = dim;
@@ -258,7 +258,7 @@ int efgp_variance_rhs(int device, int dim, int64_t mtot, double h, const double*
     if (npts == 0) return EFGP_OK;
     EFGP_REQUIRE(x_new && ws && rhs, "efgp_variance_rhs: null argument");
     if (!device_ctx(device)) return EFGP_EHIP;
-    DeviceGuard guard(device);
+    DeviceGuard guard(device, (hipStream_t)stream_);
     int64_t M = 1;
     for (int a = 0; a < dim; ++a) M *= mtot;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((M + 255) / 256, 256));
@@ -277,7 +277,7 @@ int efgp_variance_contract(int device, int dim, int64_t mtot, double h, const do
     if (npts == 0) return EFGP_OK;
     EFGP_REQUIRE(x_new && ws && gamma && out, "efgp_variance_contract: null argument");
     if (!device_ctx(device)) return EFGP_EHIP;
-    DeviceGuard guard(device);
+    DeviceGuard guard(device, (hipStream_t)stream_);
     int64_t M = 1;
     for (int a = 0; a < dim; ++a) M *= mtot;
     hipLaunchKernelGGL(variance_contract_kernel, dim3((unsigned)npts), dim3(256), 0, (hipStream_t)stream_, dim, (int)mtot, M, h, x_new,
@@ -293,7 +293,7 @@ int efgp_spectral_weights(int device, int kind, int dim, double nu, double lengt
     EFGP_REQUIRE(kind == 0 || kind == 1, "efgp_spectral_weights: kernel kind %d not built in", kind);
     EFGP_REQUIRE(dim >= 1 && dim <= 3 && mtot >= 1 && (mtot & 1), "efgp_spectral_weights: bad grid");
     if (!device_ctx(device)) return EFGP_EHIP;
-    DeviceGuard guard(device);
+    DeviceGuard guard(device, (hipStream_t)stream_);
     int64_t M = 1;
     for (int a = 0; a < dim; ++a) M *= mtot;
     hipLaunchKernelGGL(spectral_weights_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, kind, dim, nu, lengthscale,
