@@ -58,6 +58,14 @@ __device__ __forceinline__ void lds_add_fixed(double* cell, double a_scaled, dou
     __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(cell), (unsigned long long)m, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// the same sum in a GLOBAL int64 grid (device-scope atomic): the spreader of grids beyond LDS with too few points for the tiled
+// path -- exact and order independent like the LDS form (floating-point atomics made the small-N pair pass differ from run to
+// run in the last bits, which an ill-conditioned CG amplifies into a different iteration count)
+__device__ __forceinline__ void global_add_fixed(double* cell, double a_scaled, double b) {
+    const double t = fma(a_scaled, b, kFixMagic);
+    const long long m = __double_as_longlong(t) - __double_as_longlong(kFixMagic);
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(cell), (unsigned long long)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // "raw" variant: adds the bit pattern of (v*S + 1.5*2^52) itself.  bits(magic) = 0x4338 << 48 has zero low 48
 // bits, so after n additions the low 48 bits of the cell hold (sum of the rounded integers) mod 2^48, which is
 // the exact sum whenever it is below 2^47 in magnitude (guaranteed by the choice of S); the flush
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
         __syncthreads();
     }
     double* acc = USE_LDS ? lds : slab;
-    const double S = USE_LDS ? a.scale[0] : 1.0, S1 = USE_LDS ? a.scale[2] : 1.0;
+    const double S = a.scale[0], S1 = a.scale[2];        // both forms accumulate in fixed point
 
     // contiguous chunk of points per workgroup (streaming, coalesced)
     const int64_t per = (a.npts + gridDim.x - 1) / gridDim.x;
@@ -92,10 +100,8 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
     for (int64_t n = lo + threadIdx.x; n < hi; n += kSpreadThreads) {
         double c0, c1;
         fetch_strength(a.src, batch, n, c0, c1);
-        if (USE_LDS) {
-            c0 *= S;
-            c1 *= S1;
-        }
+        c0 *= S;
+        c1 *= S1;
         double v0[W], v1[W], v2[W];
         int f0 = 0, f1 = 0, f2 = 0;
         {
@@ -114,8 +120,8 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
                     lds_add_fixed(&acc[i], c0, w);
                     if (C == 2) lds_add_fixed(&acc[cells + i], c1, w);
                 } else {
-                    unsafeAtomicAdd(&acc[i], w * c0);
-                    if (C == 2) unsafeAtomicAdd(&acc[cells + i], w * c1);
+                    global_add_fixed(&acc[i], c0, w);
+                    if (C == 2) global_add_fixed(&acc[cells + i], c1, w);
                 }
             }
         } else if (D == 2) {
@@ -131,8 +137,8 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
                         lds_add_fixed(&acc[i], a0, v1[j1]);
                         if (C == 2) lds_add_fixed(&acc[cells + i], a1, v1[j1]);
                     } else {
-                        unsafeAtomicAdd(&acc[i], a0 * v1[j1]);
-                        if (C == 2) unsafeAtomicAdd(&acc[cells + i], a1 * v1[j1]);
+                        global_add_fixed(&acc[i], a0, v1[j1]);
+                        if (C == 2) global_add_fixed(&acc[cells + i], a1, v1[j1]);
                     }
                 }
             }
@@ -150,8 +156,8 @@ __global__ __launch_bounds__(kSpreadThreads) void spread_kernel(SpreadArgs a) {
                             lds_add_fixed(&acc[i], a0, v2[j2]);
                             if (C == 2) lds_add_fixed(&acc[cells + i], a1, v2[j2]);
                         } else {
-                            unsafeAtomicAdd(&acc[i], a0 * v2[j2]);
-                            if (C == 2) unsafeAtomicAdd(&acc[cells + i], a1 * v2[j2]);
+                            global_add_fixed(&acc[i], a0, v2[j2]);
+                            if (C == 2) global_add_fixed(&acc[cells + i], a1, v2[j2]);
                         }
                     }
                 }
@@ -3108,7 +3114,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     const size_t pad_bytes = (size_t)channels * (size_t)(g.cells / nlast) * (size_t)(nlast + w->p.w - 1) * sizeof(double);
     const bool use_pad = use_lds && pad_bytes + 4608 <= (size_t)ctx->max_lds && std::getenv("EFGP_NO_PAD") == nullptr;   // + class lists
     const bool raw48 = use_pad && (double)per * std::ldexp(1.0, -47) <= 0.01 * plan->tol && std::getenv("EFGP_NO_RAW48") == nullptr;
-    if (use_lds) {
+    if (plan->npts > 0) {      // (both forms: LDS tiles per workgroup, or one global int64 grid)
         if (scale_out) *scale_out = d_scale;
         // fixed-point scale from max |c| (device side, no host round trip)
         // raw48: every workgroup's sums stay below 2^46 and reduce_slabs_kernel adds at most 512 of them in int64.
@@ -3188,7 +3194,7 @@ static int spread_and_fft(efgp_nufft_s* plan, WindowSet* w, const double* c, int
     }
     {
         const int blocks = (int)((g.cells + 63) / 64);
-        if (use_lds && plan->npts > 0)
+        if (plan->npts > 0)
             hipLaunchKernelGGL((reduce_slabs_kernel<true>), dim3(blocks, nbatch), dim3(nslab >= 64 ? 1024 : 512), 0, stream,
                                slabs, nslab, channels, g.cells, (const double*)d_scale, fine);
         else
