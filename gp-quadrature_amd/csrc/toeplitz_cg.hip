@@ -2932,7 +2932,11 @@ static int coop_enqueue(efgp_toeplitz_s* op, const void* ws, double sigmasq, int
     const int load_cap = herm ? (kCoopLoads / 2) * kLineThreads / nrow : kCoopLoads * kLineThreads / F0;
     int lpbc = 1;
     while (lpbc * 2 <= std::min(ncol / G, load_cap)) lpbc <<= 1;
-    while (lpbc > 4 && ((size_t)4 * lpbc * (F0 + 1) + (size_t)F0 + (size_t)F1) * sizeof(double2) + 2048 > (size_t)ctx->max_lds) lpbc >>= 1;
+    // LDS of a column pass: two images of lpbc lines (+ the Hermitian kernel's slice of the spectrum).  (Until late in round 4 the
+    // bound was four images: half the columns per pass -- 96^2, one system per workgroup: 50 -> 42 us per iteration; 384^2
+    // general: 30.7 -> 26.9.)
+    const size_t lds_factor = std::getenv("EFGP_COOP_LDSF") ? (size_t)std::atoi(std::getenv("EFGP_COOP_LDSF")) : (herm ? 3 : 2);
+    while (lpbc > 4 && (lds_factor * lpbc * (F0 + 1) + (size_t)F0 + (size_t)F1) * sizeof(double2) + 2048 > (size_t)ctx->max_lds) lpbc >>= 1;
     while (lpbc > 1 && (ncol / G) % lpbc) lpbc >>= 1;           // a pass count per workgroup must be whole (48 R grids: 3 * 2^k lines)
     bool shape_ok = G <= kCoopMaxG && ((nrow + G - 1) / G) * n1 <= ks * kLineThreads && ncol % (G * lpbc) == 0;
     const int rows_wg = (nrow + G - 1) / G, cols_wg = ncol / G;
