@@ -1116,6 +1116,11 @@ struct CoopArgs {
     double* stamps;
 };
 
+// w / F for w < 2^16 and the line lengths of these kernels (96 .. 512) through one multiply-high: magic = floor(2^32 / F) + 1 is
+// exact on that range (F w < 2^32 / F); the loops that scatter rows into LDS images and back did a full integer division per
+// element (~40 instructions each, 16 per thread and phase)
+__device__ __forceinline__ int coop_div(int w, unsigned magic) { return (int)__umulhi((unsigned)w, magic); }
+
 // Jacobi diagonal entry t of the cooperative kernels: explicit array, or scale |ws_t|^2 + sigmasq with the two roundings of the
 // reference's torch expression (efgpnd.py:795-799; pcg::jacobi_entry), or 1
 __device__ __forceinline__ double coop_jacobi(const CoopArgs& a, double2 w, int64_t t) {
@@ -1182,6 +1187,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
     const int n0 = (int)a.g.n[0], n1 = (int)a.g.n[1], F0 = (int)a.g.F[0], F1 = (int)a.g.F[1];
     const int ldr = F1 + 1, ldc = F0 + 1;
     const int lgC = ilog2(a.lpbc);
+    const unsigned magicF1 = 0xFFFFFFFFu / (unsigned)F1 + 1u, magicZ = 0xFFFFFFFFu / (unsigned)max(1, F1 - n1) + 1u;
     const int bufsz = max(a.lines * ldr, a.lpbc * ldc);
     double2* A = lsm;
     double2* B = lsm + bufsz;
@@ -1294,15 +1300,22 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_kernel(CoopArgs a) {
         // R: owned rows in passes of a.lines
         for (int p0 = 0; p0 < nrows; p0 += a.lines) {
             const int nl = min(a.lines, nrows - p0);
-            for (int l = 0; l < nl; ++l)                                      // zero padding behind the n1 inputs of each row
-                for (int i1 = n1 + tid; i1 < F1; i1 += kLineThreads) A[l * ldr + i1] = make_double2(0.0, 0.0);
+            // zero padding behind the n1 inputs of each row, all rows of the pass as one index range (a loop over the rows left
+            // all but F1 - n1 threads idle in each of its trips: 8.4 k of the 100 k ticks of a 96 x 96 iteration)
+            const int zw = F1 - n1;
+            for (int e = tid; e < nl * zw; e += kLineThreads) {
+                const int l = coop_div(e, magicZ);
+                A[l * ldr + n1 + (e - l * zw)] = make_double2(0.0, 0.0);
+            }
 #pragma unroll
             for (int s = 0; s < KS; ++s)
                 if (ok[s] && lrow[s] >= p0 && lrow[s] < p0 + nl) A[(lrow[s] - p0) * ldr + lcol[s]] = cmul(u[s], wsv[s]);
             __syncthreads();
+            COOP_STAMP(12);
             const double2* X = line_fft_fast(A, B, F1, ldr, nl, tw1s);
+            COOP_STAMP(13);
             for (int w = tid; w < nl * F1; w += kLineThreads) {
-                const int l = w / F1, i1 = w - l * F1;
+                const int l = coop_div(w, magicF1), i1 = w - l * F1;
                 store_x2<SOLO>(b1 + (int64_t)(r0 + p0 + l) * F1 + i1, X[l * ldr + i1]);
             }
             __syncthreads();                                                  // the next pass refills the buffers
@@ -1494,6 +1507,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
     const int h0 = (n0 - 1) / 2, h1 = (n1 - 1) / 2, nh = h0 + 1, halfF1 = F1 >> 1;
     const int ldr = F1 + 1, ldc = F0 + 1;
     const int lgC = ilog2(a.lpbc);
+    const unsigned magicF1 = 0xFFFFFFFFu / (unsigned)F1 + 1u;
     const int bufsz = max(a.lines * ldr, a.lpbc * ldc);
     double2* A = lsm;
     double2* B = lsm + bufsz;
@@ -1608,7 +1622,7 @@ __global__ __launch_bounds__(kLineThreads) void cg_coop2d_herm_kernel(CoopArgs a
             __syncthreads();
             const double2* X = line_fft_fast(A, B, F1, ldr, nl, tw1s);
             for (int w = tid; w < nl * F1; w += kLineThreads) {
-                const int l = w / F1, i1 = w - l * F1;
+                const int l = coop_div(w, magicF1), i1 = w - l * F1;
                 store_x2<SOLO>(b1 + (int64_t)(r0 + p0 + l) * F1 + i1, X[l * ldr + i1]);
             }
             __syncthreads();
@@ -3172,14 +3186,14 @@ static int cg_solve_impl(efgp_toeplitz_t* op, const void* ws, double sigmasq, in
             const int dead = host[0];
             const int* hit = host + 16;
             if (ci.dbg == 2) {
-                double hs[12];
+                double hs[14];
                 EFGP_HIP_CHECK(hipMemcpy(hs, ci.stamps, sizeof(hs), hipMemcpyDeviceToHost));
-                const char* nm[12] = {"R compute+store", "barrier 1", "C store", "barrier 2", "Ri load+fft", "pAp sum (incl. barrier)", "update", "rr/rz sum (incl. barrier)",
-                                      "C load", "C transform 1 (+ multiply)", "-", "C transform 2"};
+                const char* nm[14] = {"R store to b1", "barrier 1", "C store", "barrier 2", "Ri load+fft", "pAp sum (incl. barrier)", "update", "rr/rz sum (incl. barrier)",
+                                      "C load", "C transform 1 (+ multiply)", "-", "C transform 2", "R zero fill, ws u", "R transform"};
                 double tot = 0;
-                for (int q = 0; q < 12; ++q) tot += hs[q];
+                for (int q = 0; q < 14; ++q) tot += hs[q];
                 std::fprintf(stderr, "[coop] G = %d, rows/wg %d, lines/pass %d, columns/wg %d, systems/launch %d\n", ci.G, ci.rows_wg, ci.lines, ci.cols_wg, ci.per);
-                for (int q = 0; q < 12; ++q) std::fprintf(stderr, "[coop] %-28s %9.0f cycles/iter %5.1f%%\n", nm[q], hs[q] / std::max(1, hit[0]), 100.0 * hs[q] / tot);
+                for (int q = 0; q < 14; ++q) std::fprintf(stderr, "[coop] %-28s %9.0f cycles/iter %5.1f%%\n", nm[q], hs[q] / std::max(1, hit[0]), 100.0 * hs[q] / tot);
             }
             bool any_dead = dead != 0;
             for (int i = 0; i < nbatch; ++i) any_dead = any_dead || hit[i] < 0;
