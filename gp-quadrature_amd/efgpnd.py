@@ -460,7 +460,7 @@ def _gradient_one_call(kernel, grid, xd, yd, points, sig, N, cg_tol, early_stopp
     if key in _NO_ONE_CALL_STEP or F ** grid.d > 4096 or os.environ.get("EFGP_NO_GRADIENT_STEP") or os.environ.get("EFGP_NO_NATIVE_GRID"):
         return None
     kc = _builtin_kernel_constants(kernel)
-    if kc is None or variance_idx != 1 or trace_idx != [0]:
+    if kc is None or variance_idx != 1 or trace_idx != [0] or T < 1:
         return None
     from efgp_hip.ops import gradient_step
     warm = mean_cg_init is not None and tuple(mean_cg_init.shape) == (grid.M,)
