@@ -61,6 +61,15 @@ DeviceCtx* device_ctx(int device) {
     return raw;
 }
 
+DeviceCtx* device_ctx_lock(int device) {
+    DeviceCtx* ctx = device_ctx(device);
+    if (ctx) ctx->mu.lock();
+    return ctx;
+}
+void device_ctx_unlock(DeviceCtx* ctx) {
+    if (ctx) ctx->mu.unlock();
+}
+
 void stream_handover(int device, hipStream_t stream) {
     DeviceCtx* ctx = device_ctx(device);
     if (!ctx) return;

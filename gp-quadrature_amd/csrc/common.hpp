@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -97,6 +98,8 @@ struct DeviceCtx {
     hipStream_t last_stream = nullptr;
     bool last_stream_set = false;
     hipEvent_t handover_event = nullptr;
+    // one entry point at a time per device (taken by DeviceGuard; recursive: entry points nest)
+    std::recursive_mutex mu;
     // ring of pinned staging slots for small host -> device uploads that must not drain the stream (upload_small)
     static constexpr int kUploadSlots = 8;
     static constexpr size_t kUploadSlotBytes = size_t(64) << 10;
@@ -155,11 +158,17 @@ struct KernelTimer {     // RAII: records start at construction, stop at destruc
 // there, awaited here; a device-wide wait when that fails) instead of racing with it.  Nothing happens while the stream stays
 // the same.  Host threads are not serialised: one thread per device at a time, as before.
 void stream_handover(int device, hipStream_t stream);
+// the per-device lock behind DeviceGuard: returns the context it locked (nullptr when the device has none and none can be made)
+DeviceCtx* device_ctx_lock(int device);
+void device_ctx_unlock(DeviceCtx* ctx);
 
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;
     explicit DeviceGuard(int dev) {
+        // host threads: the device's context (scratch, pool, caches, the stream it is bound to) belongs to one call at a time; the
+        // lock is recursive because entry points call each other (efgp_gradient_step, the synchronous solver's fallbacks)
+        locked = device_ctx_lock(dev);
         if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
         if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
         target = dev;
@@ -168,10 +177,14 @@ struct DeviceGuard {
     DeviceGuard(int dev, hipStream_t stream) : DeviceGuard(dev) {
         if (ok) stream_handover(dev, stream);
     }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
     ~DeviceGuard() {
         if (ok && prev >= 0 && prev != target) (void)hipSetDevice(prev);
+        if (locked) device_ctx_unlock(locked);
     }
     int target = -1;
+    DeviceCtx* locked = nullptr;
 };
 
 inline int64_t next_pow2(int64_t n) {

@@ -15,9 +15,10 @@
  *   - complex = interleaved double pairs (complex128); real = double.
  *   - all work is enqueued on the hipStream_t passed as `stream` (NULL = default stream) and is
  *     asynchronous w.r.t. the host, except where an `*_out` HOST pointer is written (documented).
- *   - one host thread per device at a time (the reference is single-threaded Python).  The objects of a device share scratch
- *     and pooled blocks, so a device's work is single-stream at any moment: an entry point called on another stream than the
- *     previous one is ordered behind everything queued on that one (event hand-over; serialised, never a race).
+ *   - the objects of a device share scratch and pooled blocks: entry points take a per-device lock (host threads are serialised
+ *     per device; the reference is single-threaded Python), and a device's work is single-stream at any moment: an entry point
+ *     called on another stream than the previous one is ordered behind everything queued on that one (event hand-over;
+ *     serialised, never a race).  efgp_release_workspaces must not run concurrently with other calls.
  */
 #ifndef EFGP_HIP_H_
 #define EFGP_HIP_H_

@@ -64,3 +64,40 @@ def test_gradient_steps_on_alternating_streams():
     torch.cuda.synchronize()
     for g in outs:
         assert float((g - g_ref).abs().max()) <= 1e-6 * float(g_ref.abs().max())
+
+
+def test_two_host_threads_on_one_device():
+    """ctypes releases the GIL inside every library call: two Python threads that fit their own models on one device are two
+    host threads inside the library at once.  A device's context belongs to one entry point at a time (the per-device lock of
+    DeviceGuard) and follows the callers from stream to stream: the results are those of the threads run one after the other."""
+    import threading
+    ma, xa = _model(4, 300_000)
+    mb, xb = _model(5, 120_000)
+    ref = []
+    for m, x in ((ma, xa), (mb, xb)):
+        for _ in range(3):                 # (the point layout is built at a model's second pass: the reference fit comes after)
+            m.fit()
+        ref.append((m._beta.clone(), m.predict(x[:4000], return_variance=False)[0].clone()))
+    torch.cuda.synchronize()
+    out, errs = {}, []
+
+    def work(key, m, x, stream):
+        try:
+            with torch.cuda.stream(stream):
+                for _ in range(25):
+                    m.fit()
+                    p = m.predict(x[:4000], return_variance=False)[0]
+                out[key] = (m._beta.clone(), p.clone())
+            stream.synchronize()
+        except Exception as err:          # noqa: BLE001
+            errs.append(err)
+
+    ts = [threading.Thread(target=work, args=(0, ma, xa, torch.cuda.Stream())), threading.Thread(target=work, args=(1, mb, xb, torch.cuda.Stream()))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in (0, 1):
+        assert float((out[i][0] - ref[i][0]).abs().max()) <= 1e-9 * float(ref[i][0].abs().max())
+        assert float((out[i][1] - ref[i][1]).abs().max()) <= 1e-9 * float(ref[i][1].abs().max())
